@@ -1,0 +1,674 @@
+// icp_api.cpp -- the C ABI of libicp_mi355x.so (include/icp_mi355x.h): context, HBM residency,
+// and the ICP driver loops that replace the reference's main() while-loops
+//   src/ICP_CPU.c:217-271, src/ICP_point_to_point.cu:295-423, src/ICP_point_to_plane.cu:517-631.
+//
+// Loop shape (one host round trip per iteration, no H2D traffic at all):
+//
+//   enqueue k:  [transform_error(R_{k-1}, t_{k-1})]  ->  nn_match  ->  moments  ->  finalize
+//               (R, t travel as kernel arguments)        P_k vs Q      fused       32 doubles
+//   <optional all-reduce of the 32-double vector across ranks, in place, on the same stream>
+//   complete k: D2H 256 B, E[k] and the stop rule on the host, 3x3 SVD / 6x6 Cholesky -> R_k, t_k
+//
+// The error of transform k-1 rides in slot 0 of the vector produced by enqueue k, so matching pass k
+// is issued speculatively before the stop rule for E[k] is known; when the rule fires that one
+// pass is discarded (it never touched P).  Correspondences ping-pong between two buffers so the
+// indices of the last CONTRIBUTING pass survive the speculative one.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/icp_mi355x.h"
+#include "icp_host_math.h"
+#include "icp_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(ICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct LoopState {
+    bool active = false;
+    bool done = false;
+    bool pending = false;   // an enqueue awaits its complete
+    bool have_rt = false;   // R, t of the last completed pass are ready to be applied
+    icp_params prm{};
+    int applied = 0;        // transforms applied so far (= index k of the error being produced)
+    int iterations = 0;     // the reference's loop counter at exit
+    int applied_idx = 0;    // idx buffer used by the last applied transform
+    int mom_blocks = 0, err_blocks = 0;
+    double n_total = 0.0;
+    double R[9], t[3];
+    double T[16];
+    std::vector<double> err;
+    double seconds_nn = 0.0;
+    bool timed_nn = false;
+};
+
+}  // namespace
+
+struct icp_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int prec = -1;  // precision of the resident clouds (model and moving must agree)
+    int n = 0, m = 0;
+    bool have_model = false, have_moving = false, have_normals = false;
+    DevBuf P, Q, Nrm, stage;
+    DevBuf part_d, part_idx, idx[2];
+    int cur = 0;  // idx buffer written by the most recent matching pass
+    DevBuf mom_partials, err_partials, mom_own, nbr, cov;
+    double* mom_dev = nullptr;
+    double* h_mom = nullptr;  // pinned
+    icp::NNPlan plan{};
+    LoopState loop;
+};
+
+namespace {
+
+int use(icp_ctx* c)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return ICP_OK;
+}
+
+int ensure_work_buffers(icp_ctx* c)
+{
+    c->plan = icp::nn_plan(c->n, c->m, c->prec, c->num_cus);
+    const icp::NNPlan& pl = c->plan;
+    const size_t es = icp::elem_size(c->prec);
+    const size_t S = pl.splits > 0 ? (size_t)pl.splits : 1;
+    HIP_TRY(c->part_d.ensure(S * (size_t)pl.n_pad * es));
+    HIP_TRY(c->part_idx.ensure(S * (size_t)pl.n_pad * sizeof(int32_t)));
+    HIP_TRY(c->idx[0].ensure((size_t)pl.n_pad * sizeof(int32_t)));
+    HIP_TRY(c->idx[1].ensure((size_t)pl.n_pad * sizeof(int32_t)));
+    const bool fresh = c->mom_partials.cap == 0;
+    HIP_TRY(c->mom_partials.ensure((size_t)icp::MOM_MAX_BLOCKS * ICP_NMOM * sizeof(double)));
+    HIP_TRY(c->err_partials.ensure((size_t)icp::MOM_MAX_BLOCKS * sizeof(double)));
+    HIP_TRY(c->mom_own.ensure(ICP_NMOM * sizeof(double)));
+    if (fresh) {
+        HIP_TRY(hipMemsetAsync(c->mom_partials.p, 0, c->mom_partials.cap, c->stream));
+        HIP_TRY(hipMemsetAsync(c->err_partials.p, 0, c->err_partials.cap, c->stream));
+        HIP_TRY(hipMemsetAsync(c->mom_own.p, 0, c->mom_own.cap, c->stream));
+    }
+    if (!c->mom_dev) c->mom_dev = (double*)c->mom_own.p;
+    return ICP_OK;
+}
+
+// upload a host AoS cloud and convert it to the padded SoA layout
+int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision, DevBuf& dst)
+{
+    const size_t es = icp::elem_size(precision);
+    HIP_TRY(dst.ensure(3 * (size_t)pad * es));
+    if (count <= 0) return ICP_OK;
+    HIP_TRY(c->stage.ensure(3 * (size_t)count * es));
+    HIP_TRY(hipMemcpyAsync(c->stage.p, aos, 3 * (size_t)count * es, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(icp::launch_aos_to_soa(precision, c->stage.p, count, pad, dst.p, c->stream));
+    // the staging buffer is reused by the next upload: order them on the stream, and make sure the
+    // pageable host source has been consumed before returning
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+int check_precision(int precision)
+{
+    if (precision != ICP_F32 && precision != ICP_F64) return fail(ICP_ERR_INVALID, "unknown precision");
+    return ICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icp_abi_version(void) { return ICP_ABI_VERSION; }
+
+const char* icp_strerror(int code)
+{
+    switch (code) {
+        case ICP_OK: return "ok";
+        case ICP_ERR_INVALID: return "invalid argument";
+        case ICP_ERR_NO_DEVICE: return "no usable gfx950 HIP device (there is no CPU fallback)";
+        case ICP_ERR_HIP: return "HIP runtime error";
+        case ICP_ERR_EMPTY: return "empty model cloud";
+        case ICP_ERR_SINGULAR: return "point-to-plane system is not positive definite";
+        case ICP_ERR_IO: return "dataset file missing or malformed";
+        case ICP_ERR_STATE: return "call sequence error";
+        case ICP_ERR_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+const char* icp_last_error(void) { return g_last_error.c_str(); }
+
+int icp_device_count(void)
+{
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ICP_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    return n;
+}
+
+int icp_create(int device, icp_ctx** out)
+{
+    if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    const int nd = icp_device_count();
+    if (nd <= 0) return fail(ICP_ERR_NO_DEVICE, "no HIP device visible: " + g_last_error);
+    if (device < 0 || device >= nd) return fail(ICP_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ICP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    icp_ctx* c = new (std::nothrow) icp_ctx();
+    if (!c) return fail(ICP_ERR_NOMEM, "context allocation failed");
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mom, ICP_NMOM * sizeof(double), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
+        icp_destroy(c);
+        return fail(ICP_ERR_HIP, msg);
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return ICP_OK;
+}
+
+void icp_destroy(icp_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->P, &c->Q, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+                      &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->cov};
+    for (DevBuf* b : bufs) b->release();
+    if (c->h_mom) (void)hipHostFree(c->h_mom);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int icp_set_stream(icp_ctx* c, void* hip_stream)
+{
+    if (int rc = use(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return ICP_OK;
+}
+
+int icp_set_profiling(icp_ctx* c, int enable)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    c->profiling = enable != 0;
+    return ICP_OK;
+}
+
+int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = check_precision(precision)) return rc;
+    if (m < 0 || (m > 0 && !xyz)) return fail(ICP_ERR_INVALID, "bad model cloud");
+    if (c->have_moving && c->prec != precision) { c->have_moving = false; c->n = 0; }
+    c->prec = precision;
+    c->m = m;
+    c->have_normals = false;
+    c->loop.active = false;
+    if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q)) return rc;
+    c->have_model = true;
+    return ICP_OK;
+}
+
+int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = check_precision(precision)) return rc;
+    if (n < 0 || (n > 0 && !xyz)) return fail(ICP_ERR_INVALID, "bad moving cloud");
+    if (c->have_model && c->prec != precision)
+        return fail(ICP_ERR_INVALID, "moving cloud precision differs from the resident model");
+    c->prec = precision;
+    c->n = n;
+    c->loop.active = false;
+    if (int rc = upload_cloud(c, xyz, n, icp::pad_moving(n), precision, c->P)) return rc;
+    c->have_moving = true;
+    return ICP_OK;
+}
+
+int icp_set_model_normals(icp_ctx* c, const void* nxyz, int m)
+{
+    if (int rc = use(c)) return rc;
+    if (!c->have_model) return fail(ICP_ERR_STATE, "set the model before its normals");
+    if (m != c->m || (m > 0 && !nxyz)) return fail(ICP_ERR_INVALID, "normal count must equal the model size");
+    if (int rc = upload_cloud(c, nxyz, m, icp::pad_model(m), c->prec, c->Nrm)) return rc;
+    c->have_normals = true;
+    return ICP_OK;
+}
+
+int icp_get_moving(icp_ctx* c, void* out)
+{
+    if (int rc = use(c)) return rc;
+    if (!c->have_moving) return fail(ICP_ERR_STATE, "no moving cloud resident");
+    if (c->n == 0) return ICP_OK;
+    if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
+    const size_t bytes = 3 * (size_t)c->n * icp::elem_size(c->prec);
+    HIP_TRY(c->stage.ensure(bytes));
+    HIP_TRY(icp::launch_soa_to_aos(c->prec, c->P.p, c->n, icp::pad_moving(c->n), c->stage.p, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->stage.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+static int download_idx(icp_ctx* c, int which, int32_t* out)
+{
+    if (c->n == 0) return ICP_OK;
+    if (!out) return fail(ICP_ERR_INVALID, "idx_out == NULL");
+    if (!c->idx[which].p) return fail(ICP_ERR_STATE, "no matching pass has run");
+    HIP_TRY(hipMemcpyAsync(out, c->idx[which].p, (size_t)c->n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+int icp_get_indices(icp_ctx* c, int32_t* out)
+{
+    if (int rc = use(c)) return rc;
+    return download_idx(c, c->cur, out);
+}
+
+static int require_clouds(icp_ctx* c)
+{
+    if (!c->have_model || !c->have_moving) return fail(ICP_ERR_STATE, "model and moving clouds must be resident");
+    if (c->n > 0 && c->m == 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    return ICP_OK;
+}
+
+int icp_nn_match_resident(icp_ctx* c, float* kernel_ms)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = require_clouds(c)) return rc;
+    if (int rc = ensure_work_buffers(c)) return rc;
+    if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, c->stream));
+    if (kernel_ms) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(icp::launch_merge(c->plan, c->part_d.p, (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, c->ev0, c->ev1));
+    return ICP_OK;
+}
+
+int icp_nn_match_bench(icp_ctx* c, int reps, float* total_ms)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = require_clouds(c)) return rc;
+    if (reps <= 0 || !total_ms) return fail(ICP_ERR_INVALID, "reps/total_ms");
+    if (int rc = ensure_work_buffers(c)) return rc;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; ++r)
+        HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventElapsedTime(total_ms, c->ev0, c->ev1));
+    return ICP_OK;
+}
+
+int icp_nn_launch_info(icp_ctx* c, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    if (splits) *splits = c->plan.splits;
+    if (blocks) *blocks = c->plan.blocks_x * c->plan.splits;
+    if (threads) *threads = icp::NN_BLOCK;
+    if (n_pad) *n_pad = c->plan.n_pad;
+    if (m_pad) *m_pad = c->plan.m_pad;
+    return ICP_OK;
+}
+
+static int nn_match_host(icp_ctx* c, const void* P, int n, const void* Q, int m, int precision, int32_t* idx)
+{
+    if (int rc = use(c)) return rc;
+    if (n < 0 || m < 0) return fail(ICP_ERR_INVALID, "negative size");
+    if (n == 0) return ICP_OK;
+    if (m == 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    if (!P || !Q || !idx) return fail(ICP_ERR_INVALID, "null pointer");
+    if (int rc = icp_set_model(c, Q, m, precision)) return rc;
+    if (int rc = icp_set_moving(c, P, n, precision)) return rc;
+    if (int rc = icp_nn_match_resident(c, nullptr)) return rc;
+    return download_idx(c, c->cur, idx);
+}
+
+int icp_nn_match_f32(icp_ctx* c, const float* P, int n, const float* Q, int m, int32_t* idx)
+{
+    return nn_match_host(c, P, n, Q, m, ICP_F32, idx);
+}
+
+int icp_nn_match_f64(icp_ctx* c, const double* P, int n, const double* Q, int m, int32_t* idx)
+{
+    return nn_match_host(c, P, n, Q, m, ICP_F64, idx);
+}
+
+// ---- normals -----------------------------------------------------------------------------------
+int icp_estimate_normals(icp_ctx* c, void* nxyz_out, int32_t* nbr_out)
+{
+    if (int rc = use(c)) return rc;
+    if (!c->have_model) return fail(ICP_ERR_STATE, "no model resident");
+    const int m = c->m;
+    if (m == 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    if (m < 5) return fail(ICP_ERR_INVALID, "normals need at least 5 model points (k = 4 neighbours + self)");
+    icp::NNPlan pl = icp::nn_plan(m, m, c->prec, c->num_cus);
+    HIP_TRY(c->nbr.ensure((size_t)m * 4 * sizeof(int32_t)));
+    HIP_TRY(c->cov.ensure((size_t)m * 6 * sizeof(float)));
+    HIP_TRY(icp::launch_knn4(pl, c->Q.p, (int32_t*)c->nbr.p, c->stream));
+    HIP_TRY(icp::launch_normal_cov(c->prec, c->Q.p, m, pl.m_pad, (const int32_t*)c->nbr.p, (float*)c->cov.p, c->stream));
+    std::vector<float> cov((size_t)m * 6);
+    HIP_TRY(hipMemcpyAsync(cov.data(), c->cov.p, cov.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (nbr_out)
+        HIP_TRY(hipMemcpyAsync(nbr_out, c->nbr.p, (size_t)m * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // eigenvector of the eigenvalue of smallest magnitude (cblas_isamin over ssyev's ascending w,
+    // src/ICP_point_to_plane.cu:435-437); fp64 Jacobi on the fp32 covariance
+    const size_t es = icp::elem_size(c->prec);
+    std::vector<unsigned char> nrm(3 * (size_t)m * es);
+    for (int i = 0; i < m; ++i) {
+        const float* a = &cov[(size_t)i * 6];
+        const double A[9] = {a[0], a[1], a[2], 0, a[3], a[4], 0, 0, a[5]};
+        double w[3], Z[9];
+        icp::eigh3(A, w, Z);
+        int k = 0;
+        for (int e = 1; e < 3; ++e)
+            if (std::fabs((float)w[e]) < std::fabs((float)w[k])) k = e;
+        for (int j = 0; j < 3; ++j) {
+            if (c->prec == ICP_F64) ((double*)nrm.data())[3 * (size_t)i + j] = Z[j * 3 + k];
+            else ((float*)nrm.data())[3 * (size_t)i + j] = (float)Z[j * 3 + k];
+        }
+    }
+    if (nxyz_out) std::memcpy(nxyz_out, nrm.data(), nrm.size());
+    return icp_set_model_normals(c, nrm.data(), m);
+}
+
+// ---- the loop ----------------------------------------------------------------------------------
+int icp_loop_begin(icp_ctx* c, const icp_params* prm)
+{
+    if (int rc = use(c)) return rc;
+    if (!prm) return fail(ICP_ERR_INVALID, "params == NULL");
+    if (int rc = require_clouds(c)) return rc;
+    if (prm->max_iter < 1) return fail(ICP_ERR_INVALID, "max_iter must be >= 1");
+    if (prm->metric != ICP_POINT_TO_POINT && prm->metric != ICP_POINT_TO_PLANE) return fail(ICP_ERR_INVALID, "unknown metric");
+    if (prm->precision != c->prec) return fail(ICP_ERR_INVALID, "params precision differs from the resident clouds");
+    if (prm->metric == ICP_POINT_TO_PLANE && !c->have_normals) return fail(ICP_ERR_STATE, "point-to-plane needs model normals");
+    if (c->n == 0) return fail(ICP_ERR_INVALID, "empty moving cloud");
+    if (int rc = ensure_work_buffers(c)) return rc;
+    LoopState& L = c->loop;
+    L = LoopState();
+    L.active = true;
+    L.prm = *prm;
+    L.err.assign((size_t)prm->max_iter + 1, 0.0);
+    for (int i = 0; i < 16; ++i) L.T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    return ICP_OK;
+}
+
+int icp_loop_enqueue(icp_ctx* c)
+{
+    if (int rc = use(c)) return rc;
+    LoopState& L = c->loop;
+    if (!L.active || L.done || L.pending) return fail(ICP_ERR_STATE, "enqueue: loop not ready");
+    const icp::NNPlan& pl = c->plan;
+    L.err_blocks = 0;
+    L.mom_blocks = 0;
+    if (L.have_rt) {
+        HIP_TRY(icp::launch_transform_error(c->prec, c->P.p, c->n, pl.n_pad, L.R, L.t, c->Q.p, pl.m_pad,
+                                            (const int32_t*)c->idx[c->cur].p, (double*)c->err_partials.p,
+                                            &L.err_blocks, c->stream));
+        // compose with the values that were actually applied (rounded to the storage precision)
+        double Tk[16] = {0};
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b)
+                Tk[a * 4 + b] = c->prec == ICP_F64 ? L.R[a * 3 + b] : (double)(float)L.R[a * 3 + b];
+            Tk[a * 4 + 3] = c->prec == ICP_F64 ? L.t[a] : (double)(float)L.t[a];
+        }
+        Tk[15] = 1.0;
+        double Tn[16];
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                double s = 0;
+                for (int k = 0; k < 4; ++k) s += Tk[a * 4 + k] * L.T[k * 4 + b];
+                Tn[a * 4 + b] = s;
+            }
+        std::memcpy(L.T, Tn, sizeof Tn);
+        L.applied_idx = c->cur;
+        L.applied += 1;
+        L.have_rt = false;
+    }
+    const bool final_only = L.applied >= L.prm.max_iter;  // the loop ends after this error whatever it is
+    L.timed_nn = false;
+    if (!final_only) {
+        c->cur ^= 1;
+        if (c->profiling) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); }
+        HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, c->stream));
+        if (c->profiling) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); L.timed_nn = true; }
+        HIP_TRY(icp::launch_moments(pl, L.prm.metric, c->P.p, c->Q.p, c->Nrm.p, c->part_d.p,
+                                    (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p,
+                                    (double*)c->mom_partials.p, &L.mom_blocks, c->stream));
+    }
+    HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
+                                 (const double*)c->err_partials.p, L.err_blocks, c->stream));
+    L.pending = true;
+    return ICP_OK;
+}
+
+void* icp_loop_moments_dev(icp_ctx* c) { return c ? (void*)c->mom_dev : nullptr; }
+
+int icp_loop_set_moments_dev(icp_ctx* c, void* dev_ptr)
+{
+    if (int rc = use(c)) return rc;
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    if (!dev_ptr) {
+        HIP_TRY(c->mom_own.ensure(ICP_NMOM * sizeof(double)));
+        c->mom_dev = (double*)c->mom_own.p;
+    } else {
+        c->mom_dev = (double*)dev_ptr;
+    }
+    return ICP_OK;
+}
+
+int icp_loop_complete(icp_ctx* c, int* done)
+{
+    if (int rc = use(c)) return rc;
+    LoopState& L = c->loop;
+    if (!L.active || !L.pending) return fail(ICP_ERR_STATE, "complete without enqueue");
+    HIP_TRY(hipMemcpyAsync(c->h_mom, c->mom_dev, ICP_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    L.pending = false;
+    if (L.timed_nn) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        L.seconds_nn += 1e-3 * ms;
+    }
+    const double* mom = c->h_mom;
+    if (mom[ICP_MOM_CNT] > 0) L.n_total = mom[ICP_MOM_CNT];
+    const int k = L.applied;
+    if (k >= 1) {
+        // E[k] = || q[idx_{k-1}] - p_k ||_2 / sqrt(N)   (src/ICP_CPU.c:266)
+        L.err[k] = std::sqrt(mom[ICP_MOM_ERR]) / std::sqrt(L.n_total);
+        const bool stop = !L.prm.fixed_iterations &&
+                          ((L.err[k] < L.prm.tol) || (std::fabs(L.err[k] - L.err[k - 1]) < L.prm.tol));
+        if (stop) {
+            L.iterations = k - 1;  // break before the counter is incremented (src/ICP_CPU.c:267)
+            L.done = true;
+        } else {
+            L.iterations = k;
+            if (k > L.prm.max_iter - 1) L.done = true;  // src/ICP_CPU.c:268-269
+        }
+    }
+    if (!L.done) {
+        const int rc = L.prm.metric == ICP_POINT_TO_PLANE ? icp::solve_point_to_plane(mom, L.R, L.t, nullptr)
+                                                          : icp::solve_point_to_point(mom, L.R, L.t);
+        if (rc != ICP_OK) {
+            L.done = true;
+            if (done) *done = 1;
+            return fail(rc, "minimisation failed (degenerate correspondences)");
+        }
+        L.have_rt = true;
+    }
+    if (done) *done = L.done ? 1 : 0;
+    return ICP_OK;
+}
+
+int icp_loop_state(icp_ctx* c, int* iterations, int* passes, double* err, int err_cap, double* T16)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    const LoopState& L = c->loop;
+    if (!L.active) return fail(ICP_ERR_STATE, "no loop");
+    if (iterations) *iterations = L.iterations;
+    if (passes) *passes = L.applied;
+    if (err) {
+        const int cnt = (int)L.err.size() < err_cap ? (int)L.err.size() : err_cap;
+        for (int i = 0; i < cnt; ++i) err[i] = L.err[i];
+    }
+    if (T16) std::memcpy(T16, L.T, sizeof L.T);
+    return ICP_OK;
+}
+
+int icp_loop_indices(icp_ctx* c, int32_t* out)
+{
+    if (int rc = use(c)) return rc;
+    if (!c->loop.active) return fail(ICP_ERR_STATE, "no loop");
+    return download_idx(c, c->loop.applied > 0 ? c->loop.applied_idx : c->cur, out);
+}
+
+static int run_loop(icp_ctx* c, const icp_params* prm, icp_result* out)
+{
+    if (int rc = icp_loop_begin(c, prm)) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    int done = 0;
+    while (!done) {
+        if (int rc = icp_loop_enqueue(c)) return rc;
+        if (int rc = icp_loop_complete(c, &done)) return rc;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const LoopState& L = c->loop;
+    if (out) {
+        std::memcpy(out->T, L.T, sizeof L.T);
+        out->iterations = L.iterations;
+        out->passes = L.applied;
+        out->seconds_total = std::chrono::duration<double>(t1 - t0).count();
+        out->seconds_nn = L.seconds_nn;
+        if (out->err)
+            for (size_t i = 0; i < L.err.size(); ++i) out->err[i] = L.err[i];
+        if (out->idx)
+            if (int rc = icp_loop_indices(c, out->idx)) return rc;
+        if (out->moved)
+            if (int rc = icp_get_moving(c, out->moved)) return rc;
+    }
+    return ICP_OK;
+}
+
+int icp_point_to_point(icp_ctx* c, const void* data, int n, const void* model, int m, const icp_params* prm,
+                       icp_result* out)
+{
+    if (int rc = use(c)) return rc;
+    if (!prm) return fail(ICP_ERR_INVALID, "params == NULL");
+    if (n <= 0) return fail(ICP_ERR_INVALID, "empty moving cloud");
+    if (m <= 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    icp_params p = *prm;
+    p.metric = ICP_POINT_TO_POINT;
+    if (int rc = icp_set_model(c, model, m, p.precision)) return rc;
+    if (int rc = icp_set_moving(c, data, n, p.precision)) return rc;
+    return run_loop(c, &p, out);
+}
+
+int icp_point_to_plane(icp_ctx* c, const void* data, int n, const void* model, int m, const void* normals,
+                       const icp_params* prm, icp_result* out)
+{
+    if (int rc = use(c)) return rc;
+    if (!prm) return fail(ICP_ERR_INVALID, "params == NULL");
+    if (n <= 0) return fail(ICP_ERR_INVALID, "empty moving cloud");
+    if (m <= 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    icp_params p = *prm;
+    p.metric = ICP_POINT_TO_PLANE;
+    if (int rc = icp_set_model(c, model, m, p.precision)) return rc;
+    if (normals) {
+        if (int rc = icp_set_model_normals(c, normals, m)) return rc;
+    } else {
+        if (int rc = icp_estimate_normals(c, nullptr, nullptr)) return rc;
+    }
+    if (int rc = icp_set_moving(c, data, n, p.precision)) return rc;
+    return run_loop(c, &p, out);
+}
+
+int icp_os1_to_cartesian(icp_ctx* c, const uint32_t* ranges, int n, uint32_t encoder0, const float alt16[16],
+                         const float az16[16], float* xyz_out)
+{
+    if (int rc = use(c)) return rc;
+    if (n < 0 || (n > 0 && (!ranges || !xyz_out)) || !alt16 || !az16) return fail(ICP_ERR_INVALID, "bad arguments");
+    if (n == 0) return ICP_OK;
+    DevBuf d_r, d_ang, d_xyz;
+    int rc = ICP_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(d_r.ensure((size_t)n * sizeof(uint32_t)));
+        HIP_TRY(d_ang.ensure(32 * sizeof(float)));
+        HIP_TRY(d_xyz.ensure(3 * (size_t)n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(d_r.p, ranges, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_ang.p, alt16, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync((float*)d_ang.p + 16, az16, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(icp::launch_os1_conversion((const uint32_t*)d_r.p, n, encoder0, (const float*)d_ang.p,
+                                           (const float*)d_ang.p + 16, (float*)d_xyz.p, c->stream));
+        HIP_TRY(hipMemcpyAsync(xyz_out, d_xyz.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return ICP_OK;
+    };
+    rc = body();
+    d_r.release();
+    d_ang.release();
+    d_xyz.release();
+    return rc;
+}
+
+}  // extern "C"

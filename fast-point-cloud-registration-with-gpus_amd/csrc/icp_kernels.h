@@ -1,0 +1,70 @@
+// icp_kernels.h -- host-callable launchers of the gfx950 kernels (icp_kernels.hip).
+// Internal to libicp_mi355x.so; the public surface is include/icp_mi355x.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/icp_mi355x.h"
+
+namespace icp {
+
+// Internal HBM layout of a cloud: SoA, x[pad] | y[pad] | z[pad], `pad` >= count.
+//   moving cloud: pad = multiple of NN_POINT_ALIGN (whole NN blocks, no bounds checks in the hot loop)
+//   model  cloud: pad = multiple of NN_CHUNK; entries [m, m_pad) replicate point m-1, which can
+//                 never win a first-minimum search against its lower-index original.
+constexpr int NN_BLOCK = 256;        // threads per matching block (4 wave64)
+constexpr int NN_POINT_ALIGN = 1024; // moving-point padding granule
+constexpr int NN_CHUNK = 16;         // model points per index-tracking chunk
+
+struct NNPlan {
+    int precision;  // ICP_F32 / ICP_F64
+    int n, m;       // real counts
+    int n_pad, m_pad;
+    int pts_per_thread; // T
+    int blocks_x;       // n_pad / (NN_BLOCK * T)
+    int splits;         // S: model segments scanned by different blocks (grid.y)
+    int seg_len;        // model points per segment (multiple of NN_CHUNK)
+};
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+inline int pad_moving(int n) { return n <= 0 ? 0 : round_up(n, NN_POINT_ALIGN); }
+inline int pad_model(int m) { return m <= 0 ? 0 : round_up(m, NN_CHUNK); }
+
+// Choose the launch geometry.  `num_cus` comes from hipDeviceProp_t::multiProcessorCount.
+NNPlan nn_plan(int n, int m, int precision, int num_cus);
+
+size_t elem_size(int precision);
+
+// matching: per (segment, point) partial minimum + index
+hipError_t launch_nn(const NNPlan& pl, const void* P_soa, const void* Q_soa, void* part_d, int32_t* part_idx,
+                     hipStream_t st);
+// stand-alone merge of the segment partials into idx (icp_nn_match_* only; the ICP loop merges
+// inside the moments kernel)
+hipError_t launch_merge(const NNPlan& pl, const void* part_d, const int32_t* part_idx, int32_t* idx, hipStream_t st);
+
+constexpr int MOM_MAX_BLOCKS = 1024;
+// fused: merge segment partials -> idx, gather q[idx], accumulate the metric's moments in fp64.
+// partials: [blocks][ICP_NMOM] doubles; returns the number of blocks used in *blocks.
+hipError_t launch_moments(const NNPlan& pl, int metric, const void* P_soa, const void* Q_soa, const void* N_soa,
+                          const void* part_d, const int32_t* part_idx, int32_t* idx, double* partials, int* blocks,
+                          hipStream_t st);
+// p <- R p + t in place (storage precision, separately rounded mul/add), and
+// sum |p_new - q[idx]|^2 in fp64 -> err_partials[block]
+hipError_t launch_transform_error(int precision, void* P_soa, int n, int n_pad, const double* R9, const double* t3,
+                                  const void* Q_soa, int m_pad, const int32_t* idx, double* err_partials,
+                                  int* blocks, hipStream_t st);
+// deterministic fixed-order reduction of the per-block partials into the ICP_NMOM-vector
+hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_blocks, const double* err_partials,
+                           int err_blocks, hipStream_t st);
+
+hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st);
+hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, void* aos, hipStream_t st);
+
+// model-on-model 4 nearest neighbours (self / rank 0 dropped) + covariance of the neighbours
+hipError_t launch_knn4(const NNPlan& pl, const void* Q_soa, int32_t* nbr /*[m][4]*/, hipStream_t st);
+hipError_t launch_normal_cov(int precision, const void* Q_soa, int m, int m_pad, const int32_t* nbr,
+                             float* cov6 /*[m][6] upper triangle*/, hipStream_t st);
+hipError_t launch_os1_conversion(const uint32_t* ranges, int n, uint32_t encoder0, const float* alt16,
+                                 const float* az16, float* xyz_aos, hipStream_t st);
+
+}  // namespace icp

@@ -1,0 +1,667 @@
+// icp_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ICP hot path.
+//
+// Kernel inventory (reference statement each one replaces; file:line relative to the reference):
+//   nn_match_kernel        Matching<<<>>>  src/CUDA/GPU_point_to_point_real.cu:38-79 (fp32),
+//                          MKL matching loop src/ICP_CPU.c:220-234 (fp64)
+//   moments_kernel         Q_index + 2x cublasSgemv + deviation + cublasSgemm
+//                          src/ICP_point_to_point.cu:308-357; Cxb + 2x Sgemv
+//                          src/CUDA/GPU_point_to_plane_real.cu:246-288,532-549
+//   transform_error_kernel RyT + Scopy + Scopy/Saxpy/Snrm2  src/ICP_point_to_point.cu:81-88,403-416
+//   finalize_kernel        (the reductions hidden inside cuBLAS)
+//   knn4_kernel/normal_cov knn + Normals  src/CUDA/GPU_point_to_plane_real.cu:54-128
+//   os1_conversion_kernel  Conversion     src/CUDA/GPU_point_to_point_real.cu:20-36
+//
+// Numerics contract of the matching kernels: the squared distance is evaluated exactly as the CPU
+// path does -- dx = q-p; dx*dx; (dx2+dy2)+dz2, every operation rounded separately -- so the file is
+// compiled with FP contraction OFF and tests/test_build.py greps the ISA of nn_match_kernel for
+// fma/mad/fmac.  Ties resolve to the lowest model index.
+#include "icp_kernels.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#pragma clang fp contract(off)
+
+namespace icp {
+
+size_t elem_size(int precision) { return precision == ICP_F64 ? sizeof(double) : sizeof(float); }
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+template <typename F> struct Vec16;  // 16-byte vector of F
+template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+
+__device__ __forceinline__ float vget(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ double vget(const double2& v, int i) { return i == 0 ? v.x : v.y; }
+
+__device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double fmin_(double a, double b) { return __builtin_fmin(a, b); }
+
+template <typename F> __device__ __forceinline__ F inf_();
+template <> __device__ __forceinline__ float inf_<float>() { return __builtin_huge_valf(); }
+template <> __device__ __forceinline__ double inf_<double>() { return __builtin_huge_val(); }
+
+// (dx*dx + dy*dy) + dz*dz, each op rounded on its own (contraction is off for this TU)
+template <typename F>
+__device__ __forceinline__ F dist2(F px, F py, F pz, F qx, F qy, F qz)
+{
+    F dx = qx - px;
+    F dy = qy - py;
+    F dz = qz - pz;
+    dx = dx * dx;
+    dy = dy * dy;
+    dz = dz * dz;
+    F d = dx + dy;
+    return d + dz;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-wide sum of NACC per-thread doubles -> out[0..NACC) (written by threads 0..NACC-1).
+// Fixed combination order => bitwise reproducible for a fixed launch geometry.
+template <int NACC, int BLOCK>
+__device__ __forceinline__ void block_sum_store(const double (&acc)[NACC], double* out)
+{
+    constexpr int NW = BLOCK / 64;
+    __shared__ double red[NW][NACC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) red[w][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double s = red[0][threadIdx.x];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) s += red[ww][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion
+// ------------------------------------------------------------------------------------------------
+template <typename F>
+__global__ void aos_to_soa_kernel(const F* __restrict__ aos, int n, int n_pad, F* __restrict__ soa)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    const int s = i < n ? i : n - 1;  // padding replicates the last real point
+    soa[i] = aos[3 * (size_t)s + 0];
+    soa[(size_t)n_pad + i] = aos[3 * (size_t)s + 1];
+    soa[2 * (size_t)n_pad + i] = aos[3 * (size_t)s + 2];
+}
+
+template <typename F>
+__global__ void soa_to_aos_kernel(const F* __restrict__ soa, int n, int n_pad, F* __restrict__ aos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    aos[3 * (size_t)i + 0] = soa[i];
+    aos[3 * (size_t)i + 1] = soa[(size_t)n_pad + i];
+    aos[3 * (size_t)i + 2] = soa[2 * (size_t)n_pad + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// matching
+//
+// grid = (n_pad / (256*T), S).  A block owns 256*T moving points (T per lane, in registers) and one
+// segment [q0, q1) of the model.  The segment streams through LDS in SoA tiles; every lane reads the
+// SAME LDS address (broadcast, conflict-free), 16 bytes per ds_read.
+//
+// The inner loop keeps only the running MINIMUM per moving point (8 rounding-exact VALU ops per
+// pair + a min), not the arg-min: per NN_CHUNK model points one compare records the id of the
+// chunk that last lowered the minimum.  Because the compare is strict, that is the FIRST chunk
+// holding the final minimum; the index is recovered afterwards by re-evaluating just that chunk
+// (16 pairs per moving point) and taking the lowest j with d_j == min.  Same answer as the
+// reference's ascending strict-< scan, ~25% fewer VALU ops per pair.
+// ------------------------------------------------------------------------------------------------
+template <typename F, int T, int TQ>
+__global__ __launch_bounds__(NN_BLOCK) void nn_match_kernel(const F* __restrict__ P, int n_pad,
+                                                            const F* __restrict__ Q, int m_pad, int seg_len,
+                                                            F* __restrict__ part_d, int32_t* __restrict__ part_idx)
+{
+    using V = typename Vec16<F>::type;
+    constexpr int VN = Vec16<F>::N;
+    constexpr int C = NN_CHUNK;
+    __shared__ __attribute__((aligned(16))) F sq[3 * TQ];
+
+    const int q0 = blockIdx.y * seg_len;
+    const int q1 = min(q0 + seg_len, m_pad);
+    const int ibase = blockIdx.x * (NN_BLOCK * T) + threadIdx.x;
+
+    F px[T], py[T], pz[T], best[T];
+    int cst[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int i = ibase + t * NN_BLOCK;
+        px[t] = P[i];
+        py[t] = P[(size_t)n_pad + i];
+        pz[t] = P[2 * (size_t)n_pad + i];
+        best[t] = inf_<F>();
+        cst[t] = q0 / C;
+    }
+
+    for (int tile = q0; tile < q1; tile += TQ) {
+        const int len = min(TQ, q1 - tile);  // multiple of C
+        __syncthreads();
+        for (int e = threadIdx.x * VN; e < len; e += NN_BLOCK * VN) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                *reinterpret_cast<V*>(&sq[a * TQ + e]) =
+                    *reinterpret_cast<const V*>(&Q[(size_t)a * m_pad + tile + e]);
+        }
+        __syncthreads();
+
+        for (int c = 0; c < len; c += C) {
+            F bo[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) bo[t] = best[t];
+#pragma unroll
+            for (int k = 0; k < C; k += VN) {
+                const V qx = *reinterpret_cast<const V*>(&sq[c + k]);
+                const V qy = *reinterpret_cast<const V*>(&sq[TQ + c + k]);
+                const V qz = *reinterpret_cast<const V*>(&sq[2 * TQ + c + k]);
+#pragma unroll
+                for (int v = 0; v < VN; ++v) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const F d = dist2<F>(px[t], py[t], pz[t], vget(qx, v), vget(qy, v), vget(qz, v));
+                        best[t] = fmin_(best[t], d);
+                    }
+                }
+            }
+            const int cid = (tile + c) / C;
+#pragma unroll
+            for (int t = 0; t < T; ++t) cst[t] = (best[t] < bo[t]) ? cid : cst[t];
+        }
+    }
+
+    // index recovery inside the winning chunk (global memory, L2-resident)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int base = cst[t] * C;
+        int idx = base;
+        const F b = best[t];
+        for (int k = C - 1; k >= 0; --k) {
+            const int j = base + k;
+            const F d = dist2<F>(px[t], py[t], pz[t], Q[j], Q[(size_t)m_pad + j], Q[2 * (size_t)m_pad + j]);
+            idx = (d == b) ? j : idx;
+        }
+        const size_t o = (size_t)blockIdx.y * n_pad + ibase + t * NN_BLOCK;
+        part_d[o] = b;
+        part_idx[o] = idx;
+    }
+}
+
+// lexicographic (d, j) minimum over the S segment partials: segments are ascending model ranges,
+// so the first strict minimum in segment order is the lowest index.
+template <typename F>
+__device__ __forceinline__ int merge_partials(const F* __restrict__ part_d, const int32_t* __restrict__ part_idx,
+                                              int S, int n_pad, int i)
+{
+    F best = part_d[i];
+    int bi = part_idx[i];
+    for (int s = 1; s < S; ++s) {
+        const F d = part_d[(size_t)s * n_pad + i];
+        const int j = part_idx[(size_t)s * n_pad + i];
+        if (d < best) { best = d; bi = j; }
+    }
+    return bi;
+}
+
+template <typename F>
+__global__ void merge_kernel(const F* __restrict__ part_d, const int32_t* __restrict__ part_idx, int S, int n_pad,
+                             int n, int m, int32_t* __restrict__ idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int j = merge_partials<F>(part_d, part_idx, S, n_pad, i);
+    idx[i] = j < m ? j : m - 1;  // unreachable clamp (padding never wins); keeps idx in range by construction
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused merge + gather + moments.  HBM-bound: per moving point 12 B (p) + 8*S B (partials)
+// + 4 B (idx store) + 12 B gathered (q) [+ 12 B normals], accumulated in fp64.
+// ------------------------------------------------------------------------------------------------
+constexpr int MOM_BLOCK = 256;
+
+template <typename F, int METRIC>
+__global__ __launch_bounds__(MOM_BLOCK) void moments_kernel(const F* __restrict__ P, int n, int n_pad,
+                                                            const F* __restrict__ Q, int m, int m_pad,
+                                                            const F* __restrict__ Nrm,
+                                                            const F* __restrict__ part_d,
+                                                            const int32_t* __restrict__ part_idx, int S,
+                                                            int32_t* __restrict__ idx_out,
+                                                            double* __restrict__ partials)
+{
+    constexpr int NACC = (METRIC == ICP_POINT_TO_POINT) ? 18 : 28;
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+
+    for (int i = blockIdx.x * MOM_BLOCK + threadIdx.x; i < n; i += gridDim.x * MOM_BLOCK) {
+        int j = merge_partials<F>(part_d, part_idx, S, n_pad, i);
+        j = j < m ? j : m - 1;
+        idx_out[i] = j;
+        const double px = (double)P[i], py = (double)P[(size_t)n_pad + i], pz = (double)P[2 * (size_t)n_pad + i];
+        const double qx = (double)Q[j], qy = (double)Q[(size_t)m_pad + j], qz = (double)Q[2 * (size_t)m_pad + j];
+        acc[0] += 1.0;
+        if constexpr (METRIC == ICP_POINT_TO_POINT) {
+            acc[1] += px; acc[2] += py; acc[3] += pz;
+            acc[4] += qx; acc[5] += qy; acc[6] += qz;
+            acc[7] += qx * px; acc[8] += qx * py; acc[9] += qx * pz;
+            acc[10] += qy * px; acc[11] += qy * py; acc[12] += qy * pz;
+            acc[13] += qz * px; acc[14] += qz * py; acc[15] += qz * pz;
+            acc[16] += px * px + py * py + pz * pz;
+            acc[17] += qx * qx + qy * qy + qz * qz;
+        } else {
+            const double nx = (double)Nrm[j], ny = (double)Nrm[(size_t)m_pad + j], nz = (double)Nrm[2 * (size_t)m_pad + j];
+            double cn[6];
+            cn[0] = py * nz - pz * ny;
+            cn[1] = pz * nx - px * nz;
+            cn[2] = px * ny - py * nx;
+            cn[3] = nx; cn[4] = ny; cn[5] = nz;
+            const double bi = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
+            int o = 1;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = a; c < 6; ++c) acc[o++] += cn[a] * cn[c];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[22 + a] -= cn[a] * bi;
+        }
+    }
+    // slot 0 of the moment vector is the error of the preceding transform (written by finalize)
+    block_sum_store<NACC, MOM_BLOCK>(acc, partials + (size_t)blockIdx.x * ICP_NMOM + 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// in-place transform + error.  HBM-bound: 12 B read + 12 B written per moving point, + 4 B idx
+// + 12 B gathered q.  The products and sums are rounded separately in the storage precision
+// ((r0*x + r1*y) + r2*z) + t, the association of RyT (src/ICP_point_to_point.cu:85).
+// ------------------------------------------------------------------------------------------------
+template <typename F> struct RT { F r[9]; F t[3]; };
+constexpr int TR_BLOCK = 256;
+
+template <typename F>
+__global__ __launch_bounds__(TR_BLOCK) void transform_error_kernel(F* __restrict__ P, int n, int n_pad, RT<F> rt,
+                                                                    const F* __restrict__ Q, int m_pad,
+                                                                    const int32_t* __restrict__ idx,
+                                                                    double* __restrict__ err_partials)
+{
+    double acc[1] = {0.0};
+    for (int i = blockIdx.x * TR_BLOCK + threadIdx.x; i < n_pad; i += gridDim.x * TR_BLOCK) {
+        const F x = P[i], y = P[(size_t)n_pad + i], z = P[2 * (size_t)n_pad + i];
+        F o[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            F c = rt.r[a * 3 + 0] * x;
+            c = c + rt.r[a * 3 + 1] * y;
+            c = c + rt.r[a * 3 + 2] * z;
+            o[a] = c + rt.t[a];
+        }
+        P[i] = o[0];
+        P[(size_t)n_pad + i] = o[1];
+        P[2 * (size_t)n_pad + i] = o[2];
+        if (i < n) {
+            const int j = idx[i];
+            const double dx = (double)Q[j] - (double)o[0];
+            const double dy = (double)Q[(size_t)m_pad + j] - (double)o[1];
+            const double dz = (double)Q[2 * (size_t)m_pad + j] - (double)o[2];
+            acc[0] += dx * dx + dy * dy + dz * dz;
+        }
+    }
+    block_sum_store<1, TR_BLOCK>(acc, err_partials + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: one block, fixed-order sums of the per-block partials -> the ICP_NMOM vector.
+// thread (k = tid % 32, part = tid / 32) sums blocks part, part+8, ... of slot k.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(double* __restrict__ mom, const double* __restrict__ mom_partials,
+                                                       int mom_blocks, const double* __restrict__ err_partials,
+                                                       int err_blocks)
+{
+    __shared__ double red[8][ICP_NMOM];
+    const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
+    double s = 0.0;
+    if (k == 0) {
+        for (int b = part; b < err_blocks; b += 8) s += err_partials[b];
+    } else {
+        for (int b = part; b < mom_blocks; b += 8) s += mom_partials[(size_t)b * ICP_NMOM + k];
+    }
+    red[part][k] = s;
+    __syncthreads();
+    if (threadIdx.x < ICP_NMOM) {
+        double tot = red[0][k];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) tot += red[p][k];
+        mom[k] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// point-to-plane front end: 4 nearest model neighbours of every model point (self dropped).
+// One lane per model point, whole model streamed through LDS; a sorted (d, j) top-5 lives in
+// registers, insertion happens under a (rare) wave-level branch.  Candidates arrive in ascending
+// j, so "insert after every entry with d_e <= d" reproduces the reference's k+1 passes of
+// first-arg-min with overwrite (src/CUDA/GPU_point_to_plane_real.cu:83-89).
+// ------------------------------------------------------------------------------------------------
+template <typename F, int TQ>
+__global__ __launch_bounds__(NN_BLOCK) void knn4_kernel(const F* __restrict__ Q, int m, int m_pad,
+                                                        int32_t* __restrict__ nbr)
+{
+    using V = typename Vec16<F>::type;
+    constexpr int VN = Vec16<F>::N;
+    __shared__ __attribute__((aligned(16))) F sq[3 * TQ];
+    const int i = blockIdx.x * NN_BLOCK + threadIdx.x;
+    const int is = i < m ? i : m - 1;
+    const F px = Q[is], py = Q[(size_t)m_pad + is], pz = Q[2 * (size_t)m_pad + is];
+    F bd[5];
+    int bj[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) { bd[r] = inf_<F>(); bj[r] = 0; }
+
+    for (int tile = 0; tile < m; tile += TQ) {
+        const int len = min(TQ, m_pad - tile);
+        __syncthreads();
+        for (int e = threadIdx.x * VN; e < len; e += NN_BLOCK * VN) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                *reinterpret_cast<V*>(&sq[a * TQ + e]) =
+                    *reinterpret_cast<const V*>(&Q[(size_t)a * m_pad + tile + e]);
+        }
+        __syncthreads();
+        const int real = min(len, m - tile);  // padded duplicates must not enter a top-k
+        for (int c = 0; c < real; ++c) {
+            const F d = dist2<F>(px, py, pz, sq[c], sq[TQ + c], sq[2 * TQ + c]);
+            if (d < bd[4]) {
+                const int j = tile + c;
+                // insert keeping (d, j) ascending; equal d keeps the earlier (lower) j first
+                F cd = d;
+                int cj = j;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const bool sw = cd < bd[r];
+                    const F td = bd[r];
+                    const int tj = bj[r];
+                    bd[r] = sw ? cd : td;
+                    bj[r] = sw ? cj : tj;
+                    cd = sw ? td : cd;
+                    cj = sw ? tj : cj;
+                }
+            }
+        }
+    }
+    if (i < m) {
+#pragma unroll
+        for (int r = 1; r < 5; ++r) nbr[(size_t)i * 4 + (r - 1)] = bj[r];
+    }
+}
+
+// covariance (upper triangle, not divided by k) of the 4 neighbours, float arithmetic in the
+// order of src/CUDA/CPU_ICP_point_to-plane.cpp:217-246: bar = (sum) * 0.25f, A += (x-bar)(y-bar).
+template <typename F>
+__global__ void normal_cov_kernel(const F* __restrict__ Q, int m, int m_pad, const int32_t* __restrict__ nbr,
+                                  float* __restrict__ cov6)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    float x[4], y[4], z[4];
+    float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int s = nbr[(size_t)i * 4 + j];
+        x[j] = (float)Q[s];
+        y[j] = (float)Q[(size_t)m_pad + s];
+        z[j] = (float)Q[2 * (size_t)m_pad + s];
+        bx += x[j]; by += y[j]; bz += z[j];
+    }
+    const float a = 1.0f / 4.0f;
+    bx *= a; by *= a; bz *= a;
+    float A[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dx = x[j] - bx, dy = y[j] - by, dz = z[j] - bz;
+        A[0] += dx * dx; A[1] += dx * dy; A[2] += dx * dz;
+        A[3] += dy * dy; A[4] += dy * dz; A[5] += dz * dz;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov6[(size_t)i * 6 + k] = A[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// OS1-16 polar -> Cartesian (mm), one range per lane
+// ------------------------------------------------------------------------------------------------
+__global__ void os1_conversion_kernel(const uint32_t* __restrict__ r, int n, uint32_t encoder0,
+                                      const float* __restrict__ altitude, const float* __restrict__ azimuth,
+                                      float* __restrict__ xyz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int azimuth_block = i / 16, channel = i % 16;
+    const unsigned long long counter = ((unsigned long long)encoder0 + (unsigned long long)azimuth_block * 88ull) % 90112ull;
+    const float theta = (float)(2.0 * M_PI * ((double)counter / 90112.0 + (double)azimuth[channel] / 360.0));
+    const float phi = (float)(2.0 * M_PI * (double)altitude[channel] / 360.0);
+    const float rr = (float)r[i];
+    const float ct = cosf(theta), st = sinf(theta), cp = cosf(phi), sp = sinf(phi);
+    xyz[3 * (size_t)i + 0] = rr * ct * cp;
+    xyz[3 * (size_t)i + 1] = -rr * st * cp;
+    xyz[3 * (size_t)i + 2] = rr * sp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch geometry + launchers
+// ------------------------------------------------------------------------------------------------
+template <typename F> struct NNCfg;
+template <> struct NNCfg<float> { static constexpr int T = 4; static constexpr int TQ = 2048; };
+template <> struct NNCfg<double> { static constexpr int T = 2; static constexpr int TQ = 1024; };
+
+// tuning knobs (read once): ICP_NN_T = points per lane {1,2,4,8}, ICP_NN_SPLITS = forced segment
+// count, ICP_NN_BLOCKS_PER_CU = occupancy target used to derive the segment count.
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+
+NNPlan nn_plan(int n, int m, int precision, int num_cus)
+{
+    NNPlan pl{};
+    pl.precision = precision;
+    pl.n = n;
+    pl.m = m;
+    pl.n_pad = pad_moving(n);
+    pl.m_pad = pad_model(m);
+    static const int env_T = env_int("ICP_NN_T", 0);
+    static const int env_S = env_int("ICP_NN_SPLITS", 0);
+    static const int env_bpc = env_int("ICP_NN_BLOCKS_PER_CU", 0);
+    int T = precision == ICP_F64 ? NNCfg<double>::T : NNCfg<float>::T;
+    if (env_T == 1 || env_T == 2 || env_T == 4 || env_T == 8) T = env_T;
+    if (precision == ICP_F64 && T > 4) T = 4;
+    pl.pts_per_thread = T;
+    pl.blocks_x = pl.n_pad / (NN_BLOCK * pl.pts_per_thread);
+    if (n <= 0 || m <= 0) { pl.splits = 0; pl.seg_len = 0; return pl; }
+    // small clouds cannot fill 256 CUs along the moving axis alone: split the model range over
+    // grid.y until every CU holds `bpc` blocks of 4 waves.
+    if (num_cus <= 0) num_cus = 256;
+    const int bpc = env_bpc > 0 ? env_bpc : 2;
+    const int target_blocks = num_cus * bpc;
+    int S = (target_blocks + pl.blocks_x - 1) / pl.blocks_x;
+    const int max_S = (pl.m_pad + 255) / 256;  // keep >= 256 model points per segment
+    if (S > max_S) S = max_S;
+    if (env_S > 0) S = env_S;
+    if (S < 1) S = 1;
+    int seg = round_up((pl.m_pad + S - 1) / S, NN_CHUNK);
+    S = (pl.m_pad + seg - 1) / seg;
+    pl.splits = S;
+    pl.seg_len = seg;
+    return pl;
+}
+
+template <typename F>
+static hipError_t launch_nn_t(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
+                              hipStream_t st)
+{
+    constexpr int TQ = NNCfg<F>::TQ;
+    dim3 grid(pl.blocks_x, pl.splits);
+#define ICP_LAUNCH_NN(TT)                                                                                          \
+    hipLaunchKernelGGL((nn_match_kernel<F, TT, TQ>), grid, dim3(NN_BLOCK), 0, st, (const F*)P, pl.n_pad, (const F*)Q, \
+                       pl.m_pad, pl.seg_len, (F*)part_d, part_idx)
+    switch (pl.pts_per_thread) {
+        case 1: ICP_LAUNCH_NN(1); break;
+        case 2: ICP_LAUNCH_NN(2); break;
+        case 8: if constexpr (sizeof(F) == 4) { ICP_LAUNCH_NN(8); break; }
+        default: ICP_LAUNCH_NN(4); break;
+    }
+#undef ICP_LAUNCH_NN
+    return hipGetLastError();
+}
+
+hipError_t launch_nn(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx, hipStream_t st)
+{
+    if (pl.n <= 0 || pl.m <= 0) return hipSuccess;
+    return pl.precision == ICP_F64 ? launch_nn_t<double>(pl, P, Q, part_d, part_idx, st)
+                                   : launch_nn_t<float>(pl, P, Q, part_d, part_idx, st);
+}
+
+hipError_t launch_merge(const NNPlan& pl, const void* part_d, const int32_t* part_idx, int32_t* idx, hipStream_t st)
+{
+    if (pl.n <= 0 || pl.m <= 0) return hipSuccess;
+    const int blocks = (pl.n + 255) / 256;
+    if (pl.precision == ICP_F64)
+        hipLaunchKernelGGL((merge_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)part_d, part_idx,
+                           pl.splits, pl.n_pad, pl.n, pl.m, idx);
+    else
+        hipLaunchKernelGGL((merge_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)part_d, part_idx,
+                           pl.splits, pl.n_pad, pl.n, pl.m, idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_moments(const NNPlan& pl, int metric, const void* P, const void* Q, const void* Nrm,
+                          const void* part_d, const int32_t* part_idx, int32_t* idx, double* partials, int* blocks,
+                          hipStream_t st)
+{
+    int nb = (pl.n + MOM_BLOCK - 1) / MOM_BLOCK;
+    if (nb > MOM_MAX_BLOCKS) nb = MOM_MAX_BLOCKS;
+    *blocks = nb;
+    if (nb <= 0) return hipSuccess;
+#define ICP_LAUNCH_MOM(F, MET)                                                                                     \
+    hipLaunchKernelGGL((moments_kernel<F, MET>), dim3(nb), dim3(MOM_BLOCK), 0, st, (const F*)P, pl.n, pl.n_pad,      \
+                       (const F*)Q, pl.m, pl.m_pad, (const F*)Nrm, (const F*)part_d, part_idx, pl.splits, idx, partials)
+    if (pl.precision == ICP_F64) {
+        if (metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_MOM(double, ICP_POINT_TO_PLANE);
+        else ICP_LAUNCH_MOM(double, ICP_POINT_TO_POINT);
+    } else {
+        if (metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_MOM(float, ICP_POINT_TO_PLANE);
+        else ICP_LAUNCH_MOM(float, ICP_POINT_TO_POINT);
+    }
+#undef ICP_LAUNCH_MOM
+    return hipGetLastError();
+}
+
+hipError_t launch_transform_error(int precision, void* P, int n, int n_pad, const double* R9, const double* t3,
+                                  const void* Q, int m_pad, const int32_t* idx, double* err_partials, int* blocks,
+                                  hipStream_t st)
+{
+    int nb = (n_pad + TR_BLOCK - 1) / TR_BLOCK;
+    if (nb > MOM_MAX_BLOCKS) nb = MOM_MAX_BLOCKS;
+    *blocks = nb;
+    if (nb <= 0) return hipSuccess;
+    if (precision == ICP_F64) {
+        RT<double> rt;
+        for (int k = 0; k < 9; ++k) rt.r[k] = R9[k];
+        for (int k = 0; k < 3; ++k) rt.t[k] = t3[k];
+        hipLaunchKernelGGL((transform_error_kernel<double>), dim3(nb), dim3(TR_BLOCK), 0, st, (double*)P, n, n_pad, rt,
+                           (const double*)Q, m_pad, idx, err_partials);
+    } else {
+        RT<float> rt;
+        for (int k = 0; k < 9; ++k) rt.r[k] = (float)R9[k];
+        for (int k = 0; k < 3; ++k) rt.t[k] = (float)t3[k];
+        hipLaunchKernelGGL((transform_error_kernel<float>), dim3(nb), dim3(TR_BLOCK), 0, st, (float*)P, n, n_pad, rt,
+                           (const float*)Q, m_pad, idx, err_partials);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_blocks, const double* err_partials,
+                           int err_blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, mom_out, mom_partials, mom_blocks, err_partials,
+                       err_blocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int blocks = (n_pad + 255) / 256;
+    if (precision == ICP_F64)
+        hipLaunchKernelGGL((aos_to_soa_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)aos, n, n_pad,
+                           (double*)soa);
+    else
+        hipLaunchKernelGGL((aos_to_soa_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)aos, n, n_pad,
+                           (float*)soa);
+    return hipGetLastError();
+}
+
+hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, void* aos, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int blocks = (n + 255) / 256;
+    if (precision == ICP_F64)
+        hipLaunchKernelGGL((soa_to_aos_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)soa, n, n_pad,
+                           (double*)aos);
+    else
+        hipLaunchKernelGGL((soa_to_aos_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)soa, n, n_pad,
+                           (float*)aos);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn4(const NNPlan& pl, const void* Q, int32_t* nbr, hipStream_t st)
+{
+    if (pl.m <= 0) return hipSuccess;
+    const int blocks = (pl.m + NN_BLOCK - 1) / NN_BLOCK;
+    if (pl.precision == ICP_F64)
+        hipLaunchKernelGGL((knn4_kernel<double, 1024>), dim3(blocks), dim3(NN_BLOCK), 0, st, (const double*)Q, pl.m,
+                           pl.m_pad, nbr);
+    else
+        hipLaunchKernelGGL((knn4_kernel<float, 2048>), dim3(blocks), dim3(NN_BLOCK), 0, st, (const float*)Q, pl.m,
+                           pl.m_pad, nbr);
+    return hipGetLastError();
+}
+
+hipError_t launch_normal_cov(int precision, const void* Q, int m, int m_pad, const int32_t* nbr, float* cov6,
+                             hipStream_t st)
+{
+    if (m <= 0) return hipSuccess;
+    const int blocks = (m + 255) / 256;
+    if (precision == ICP_F64)
+        hipLaunchKernelGGL((normal_cov_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)Q, m, m_pad, nbr,
+                           cov6);
+    else
+        hipLaunchKernelGGL((normal_cov_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)Q, m, m_pad, nbr,
+                           cov6);
+    return hipGetLastError();
+}
+
+hipError_t launch_os1_conversion(const uint32_t* ranges, int n, uint32_t encoder0, const float* alt16,
+                                 const float* az16, float* xyz_aos, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(os1_conversion_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ranges, n, encoder0, alt16, az16,
+                       xyz_aos);
+    return hipGetLastError();
+}
+
+}  // namespace icp
