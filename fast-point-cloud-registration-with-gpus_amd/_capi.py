@@ -69,6 +69,7 @@ SIGNATURES = {
     "icp_loop_set_moments_dev": (_i, [_vp, _vp]),
     "icp_loop_complete": (_i, [_vp, _pi]),
     "icp_loop_state": (_i, [_vp, _pi, _pi, _pd, _i, _pd]),
+    "icp_loop_timing": (_i, [_vp, _pd, _pi]),
     "icp_loop_indices": (_i, [_vp, _vp]),
     "icp_solve_point_to_point": (_i, [_pd, _pd, _pd]),
     "icp_solve_point_to_plane": (_i, [_pd, _pd, _pd, _pd]),

@@ -80,6 +80,7 @@ struct LoopState {
     double T[16];
     std::vector<double> err;
     double seconds_nn = 0.0;
+    int nn_launches = 0;
     bool timed_nn = false;
 };
 
@@ -530,6 +531,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         L.seconds_nn += 1e-3 * ms;
+        L.nn_launches += 1;
     }
     const double* mom = c->h_mom;
     if (mom[ICP_MOM_CNT] > 0) L.n_total = mom[ICP_MOM_CNT];
@@ -573,6 +575,15 @@ int icp_loop_state(icp_ctx* c, int* iterations, int* passes, double* err, int er
         for (int i = 0; i < cnt; ++i) err[i] = L.err[i];
     }
     if (T16) std::memcpy(T16, L.T, sizeof L.T);
+    return ICP_OK;
+}
+
+int icp_loop_timing(icp_ctx* c, double* seconds_nn, int* nn_launches)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    if (!c->loop.active) return fail(ICP_ERR_STATE, "no loop");
+    if (seconds_nn) *seconds_nn = c->loop.seconds_nn;
+    if (nn_launches) *nn_launches = c->loop.nn_launches;
     return ICP_OK;
 }
 

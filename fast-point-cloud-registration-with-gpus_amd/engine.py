@@ -204,6 +204,11 @@ class Context:
                                             err.size, T.ctypes.data_as(C.POINTER(C.c_double))), "icp_loop_state")
         return dict(iterations=it.value, passes=ps.value, err=err[: ps.value + 1].copy(), T=T.reshape(4, 4))
 
+    def loop_timing(self):
+        sec, cnt = C.c_double(0), C.c_int(0)
+        capi.check(self._lib.icp_loop_timing(self._h, C.byref(sec), C.byref(cnt)), "icp_loop_timing")
+        return sec.value, cnt.value
+
     def loop_indices(self):
         out = np.empty(self._n, dtype=np.int32)
         capi.check(self._lib.icp_loop_indices(self._h, out.ctypes.data), "icp_loop_indices")

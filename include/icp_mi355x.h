@@ -148,6 +148,9 @@ int icp_loop_set_moments_dev(icp_ctx* ctx, void* dev_ptr_32_doubles);
 int icp_loop_complete(icp_ctx* ctx, int* done);
 /* current state: iterations so far, error series (count doubles), composed transform */
 int icp_loop_state(icp_ctx* ctx, int* iterations, int* passes, double* err, int err_cap, double* T16);
+/* with icp_set_profiling(ctx, 1): summed hipEvent time of the matching kernel launches of this loop
+ * and their count (the bench's roofline leg reads the timed region through this) */
+int icp_loop_timing(icp_ctx* ctx, double* seconds_nn, int* nn_launches);
 /* correspondences of the last pass that contributed to T (ping-pong buffer), n int32 */
 int icp_loop_indices(icp_ctx* ctx, int32_t* idx_out);
 

@@ -214,6 +214,65 @@ int orc_solve6(const double* C, const double* b, double* x)
 #undef SUF
 
 /* ------------------------------------------------------------------------------------------
+ * fp32 clouds, fp64 minimisation ("f32x").  The fp32 twin above follows the reference file to the
+ * letter, including its naive sequential float sums for the centroids
+ * (src/CUDA/CPU_ICP_point_to_point.cpp:335-352), which carry ~1e-5 of summation noise at 16 384
+ * points.  The product keeps the reference's fp32 matching arithmetic (that is what decides the
+ * indices) but reduces in fp64, i.e. it applies src/ICP_CPU.c's fp64 minimisation (:237-248) to the
+ * fp32 cloud.  This variant restates exactly that combination: orc_nn_f32 for the matching,
+ * orc_p2p_minimize_f64 on the widened cloud, R and t rounded to float, orc_transform_f32, and the
+ * error norm of src/ICP_CPU.c:257-266 in double.
+ * ---------------------------------------------------------------------------------------- */
+int orc_icp_p2p_f32x(const float* D, const float* M, int n, int m, int max_iter, double tol, int fixed,
+                     double* E, double* T_total, int* idx_last, float* pt_out, int* passes)
+{
+    const size_t ns = (size_t)n, ms = (size_t)m;
+    float* pt = (float*)malloc(3 * ns * sizeof(float));
+    double* ptd = (double*)malloc(3 * ns * sizeof(double));
+    double* qd = (double*)malloc(3 * ms * sizeof(double));
+    int* q_idx = (int*)malloc(ns * sizeof(int));
+    if (!pt || !ptd || !qd || !q_idx) { free(pt); free(ptd); free(qd); free(q_idx); return -1; }
+    memcpy(pt, D, 3 * ns * sizeof(float));
+    for (size_t i = 0; i < 3 * ms; i++) qd[i] = (double)M[i];
+    for (int k = 0; k <= max_iter; k++) E[k] = 0;
+    double T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    int i = 0, npass = 0;
+    while (1) {
+        orc_nn_f32(pt, n, M, m, q_idx);
+        npass++;
+        for (size_t k = 0; k < 3 * ns; k++) ptd[k] = (double)pt[k];
+        double Rd[9], td[3];
+        if (orc_p2p_minimize_f64(ptd, n, qd, m, q_idx, Rd, td, NULL)) { i = -1; break; }
+        float R[9], t[3];
+        for (int k = 0; k < 9; k++) R[k] = (float)Rd[k];
+        for (int k = 0; k < 3; k++) t[k] = (float)td[k];
+        orc_transform_f32(pt, n, R, t);
+        {
+            double Tk[16] = {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2], 0, 0, 0, 1};
+            double Tn[16];
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++) {
+                    double s = 0;
+                    for (int k = 0; k < 4; k++) s += Tk[a * 4 + k] * T[k * 4 + b];
+                    Tn[a * 4 + b] = s;
+                }
+            memcpy(T, Tn, sizeof T);
+        }
+        for (size_t k = 0; k < 3 * ns; k++) ptd[k] = (double)pt[k];
+        E[i + 1] = orc_rms_error_f64(ptd, n, qd, m, q_idx);
+        if (!fixed && ((E[i + 1] < tol) || (fabs(E[i + 1] - E[i]) < tol))) break;
+        i++;
+        if (i > max_iter - 1) break;
+    }
+    if (T_total) memcpy(T_total, T, sizeof T);
+    if (idx_last) memcpy(idx_last, q_idx, ns * sizeof(int));
+    if (pt_out) memcpy(pt_out, pt, 3 * ns * sizeof(float));
+    if (passes) *passes = npass;
+    free(pt); free(ptd); free(qd); free(q_idx);
+    return i;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic clouds.
  * ---------------------------------------------------------------------------------------- */
 

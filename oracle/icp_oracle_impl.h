@@ -59,10 +59,16 @@ void FN(orc_centroid_deviation)(const REAL* cloud, int cloud_size, const int* in
         y += cloud[k + cs];
         z += cloud[k + 2 * cs];
     }
-    const REAL inv = (REAL)1.0 / (REAL)cloud_size;
-    bar[0] = x * inv;
-    bar[1] = y * inv;
-    bar[2] = z * inv;
+    if (sizeof(REAL) == 8) {
+        const REAL inv = (REAL)1.0 / (REAL)cloud_size;
+        bar[0] = x * inv;
+        bar[1] = y * inv;
+        bar[2] = z * inv;
+    } else { /* the fp32 twin divides: CPU_ICP_point_to_point.cpp:355-357 */
+        bar[0] = x / (REAL)cloud_size;
+        bar[1] = y / (REAL)cloud_size;
+        bar[2] = z / (REAL)cloud_size;
+    }
     for (int i = 0; i < cloud_size; i++) {
         const int k = index ? index[i] : i;
         for (int j = 0; j < 3; j++) mark[i + cs * j] = cloud[k + cs * j] - bar[j];
@@ -94,8 +100,13 @@ int FN(orc_p2p_minimize)(const REAL* pt, int n, const REAL* q, int m, const int*
             y += q[k + ms];
             z += q[k + 2 * ms];
         }
-        const REAL inv = (REAL)1.0 / (REAL)n;
-        q_bar[0] = x * inv; q_bar[1] = y * inv; q_bar[2] = z * inv;
+        /* ICP_CPU.c:355 multiplies by 1.0/n; the fp32 twin divides (CPU_ICP_point_to_point.cpp:355-363) */
+        if (sizeof(REAL) == 8) {
+            const REAL inv = (REAL)1.0 / (REAL)n;
+            q_bar[0] = x * inv; q_bar[1] = y * inv; q_bar[2] = z * inv;
+        } else {
+            q_bar[0] = x / (REAL)n; q_bar[1] = y / (REAL)n; q_bar[2] = z / (REAL)n;
+        }
         for (int i = 0; i < n; i++) {
             const int k = q_idx[i];
             for (int j = 0; j < 3; j++) q_mark[i + ns * j] = q[k + ms * j] - q_bar[j];

@@ -102,6 +102,24 @@ class Oracle:
         return dict(iterations=it, passes=passes.value, err=E[: passes.value + 1].astype(np.float64), T=T.reshape(4, 4),
                     idx=idx, moved=aos(pt, n))
 
+    def icp_p2p_f32x(self, D, M, max_iter, tol, fixed=False):
+        """fp32 matching + fp64 minimisation (see oracle/icp_oracle.c, orc_icp_p2p_f32x)"""
+        D = np.ascontiguousarray(D, dtype=np.float32)
+        M = np.ascontiguousarray(M, dtype=np.float32)
+        n, m = D.shape[0], M.shape[0]
+        ds, ms = soa(D), soa(M)
+        E = np.zeros(max_iter + 1, dtype=np.float64)
+        T = np.zeros(16)
+        idx = np.zeros(n, dtype=np.int32)
+        pt = np.zeros(3 * n, dtype=np.float32)
+        passes = C.c_int(0)
+        self.lib.orc_icp_p2p_f32x.restype = C.c_int
+        it = self.lib.orc_icp_p2p_f32x(ds.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p), n, m, int(max_iter), C.c_double(tol),
+                                       1 if fixed else 0, E.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p),
+                                       idx.ctypes.data_as(C.c_void_p), pt.ctypes.data_as(C.c_void_p), C.byref(passes))
+        assert it >= 0
+        return dict(iterations=it, passes=passes.value, err=E[: passes.value + 1].copy(), T=T.reshape(4, 4), idx=idx, moved=aos(pt, n))
+
     # ---- synthetic clouds -----------------------------------------------------------------------
     def synth_icp_cpu(self, W):
         n = W * W

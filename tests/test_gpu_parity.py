@@ -1,0 +1,254 @@
+"""GPU: parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Bar: correspondence indices bit-exact; composed transform within 1e-5 relative (north_star); error
+series within 1e-5 absolute of the oracle's.  Trajectory parity is pinned PER ITERATION from captured
+inputs (P_k downloaded from the device, idx_k compared with the oracle's matching of that same P_k), so a
+last-bit difference in one transform cannot hide behind -- or be blamed on -- a later near-tie.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_T = 1e-5      # relative, composed 4x4 transform (BASELINE.json north_star)
+TOL_E = 1e-5      # absolute, RMS error series
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(np.asarray(b)).max()))
+
+
+TWIN_TOL = 2e-4   # the fp32 twin's own summation noise (naive float centroid sums over 16 384 points)
+
+
+def assert_close_to_fp32_twin(res, twin):
+    """loose: the letter-faithful fp32 twin (src/CUDA/CPU_ICP_point_to_point.cpp) carries ~1e-5..1e-4 of
+    float summation noise in its centroids; the product (fp64 reductions) must stay inside that band."""
+    n = min(len(res.err), len(twin["err"]))
+    assert np.abs(res.err[:n] - twin["err"][:n]).max() < TWIN_TOL
+    assert rel(res.T, twin["T"]) < TWIN_TOL
+
+
+def assert_same_run(res_iterations, res_err, res_T, want, tol, fp32):
+    """same trajectory as the oracle.  The fp64 path must stop at the same iteration.  The fp32 oracle
+    (like the reference's snrm2) sums its error norm in float, ~1e-7 of noise on a 1e-6 stop threshold, so a
+    run may legitimately stop one pass apart -- but only if the deciding |dE| really sits on the threshold."""
+    n = min(len(res_err), len(want["err"]))
+    assert np.abs(np.asarray(res_err)[:n] - want["err"][:n]).max() < TOL_E
+    if res_iterations != want["iterations"]:
+        assert fp32 and abs(res_iterations - want["iterations"]) == 1, (res_iterations, want["iterations"])
+        k = min(res_iterations, want["iterations"]) + 1          # the error whose stop test disagreed
+        dE = abs(want["err"][k] - want["err"][k - 1])
+        assert abs(dE - tol) < 5e-7 or abs(want["err"][k] - tol) < 5e-7, f"stop rule disagreed away from the threshold: dE={dE}"
+    assert rel(res_T, want["T"]) < TOL_T
+
+
+# ---------------------------------------------------------------------------------------------------
+# matching seam
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_matching_synthetic(ctx, pkg, orc, dtype):
+    if dtype == np.float64:
+        D, M = orc.synth_icp_cpu(32)          # configs[0]: the CPU program's own cloud
+    else:
+        D = pkg.datasets.synthetic_grid(32, np.float32)
+        M = pkg.datasets.make_model_standard(D)
+    idx = ctx.Matching(D, M)
+    assert idx.dtype == np.int32 and np.array_equal(idx, orc.nn(D, M))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,m", [(1, 1), (1, 5), (3, 17), (1000, 255), (1025, 257), (2049, 4097), (777, 16), (5000, 3000)])
+def test_matching_ragged_sizes(ctx, orc, dtype, n, m):
+    rng = np.random.default_rng(n * 7919 + m)
+    P = rng.standard_normal((n, 3)).astype(dtype)
+    Q = rng.standard_normal((m, 3)).astype(dtype)
+    idx = ctx.Matching(P, Q)
+    assert idx.min() >= 0 and idx.max() < m
+    assert np.array_equal(idx, orc.nn(P, Q))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_matching_ties_resolve_to_lowest_index(ctx, orc, dtype):
+    # integer lattice + duplicated model points: equal distances everywhere
+    g = np.stack(np.meshgrid(np.arange(12.0), np.arange(12.0), np.arange(5.0), indexing="ij"), -1).reshape(-1, 3)
+    Q = np.concatenate([g, g[::3], g[5:40]]).astype(dtype)       # exact duplicates at higher indices
+    P = np.concatenate([g[::2] + 0.5, g[1::5]]).astype(dtype)    # cell centres (8-way ties) and exact hits
+    idx = ctx.Matching(P, Q)
+    assert np.array_equal(idx, orc.nn(P, Q))
+    # every model point is a copy of one point
+    Q1 = np.tile(np.array([[0.25, -1.5, 3.0]], dtype=dtype), (1000, 1))
+    assert (ctx.Matching(P[:300], Q1) == 0).all()
+
+
+def test_matching_hall_and_bunny(ctx, pkg, orc, golden):
+    P, Q = orc.hall_clouds(golden)     # configs[2]: 16384 pts, 4361 coincident points at the origin
+    idx = ctx.Matching(P, Q)
+    assert np.array_equal(idx, orc.nn(P, Q))
+    B = np.fromfile(os.path.join(golden, "bunny_res_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
+    BM = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
+    assert np.array_equal(ctx.Matching(B, BM), orc.nn(B, BM))
+
+
+def test_matching_edge_cases(ctx, pkg):
+    P = np.zeros((0, 3), dtype=np.float32)
+    Q = np.ones((4, 3), dtype=np.float32)
+    assert ctx.Matching(P, Q).shape == (0,)                    # empty moving cloud: nothing to do
+    with pytest.raises(pkg.IcpError) as e:
+        ctx.Matching(Q, P)                                     # empty model: loud
+    assert e.value.code == pkg.capi.ICP_ERR_EMPTY
+    with pytest.raises(pkg.IcpError):
+        ctx.point_to_point(Q, P)
+    with pytest.raises(pkg.IcpError):
+        ctx.point_to_point(Q, Q, max_iter=0)
+
+
+def test_matching_full_size_properties(ctx, pkg, golden):
+    """BASELINE configs[1] size (Bunny.csv, 35 947 pts): size-independent properties, no oracle."""
+    B = np.fromfile(os.path.join(golden, "bunny_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
+    M = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
+    idx = ctx.Matching(B, M)
+    assert idx.min() >= 0 and idx.max() < M.shape[0]
+
+    def d2(P, Q, j):
+        d = Q[j] - P
+        d = d * d
+        return (d[:, 0] + d[:, 1]) + d[:, 2]
+
+    best = d2(B, M, idx)
+    rng = np.random.default_rng(0)
+    for _ in range(8):                                   # nothing sampled beats the reported minimum
+        j = rng.integers(0, M.shape[0], size=B.shape[0])
+        assert (best <= d2(B, M, j)).all()
+    # self-match: every point finds itself (or an exact lower-index duplicate)
+    s = ctx.Matching(M, M)
+    assert (s <= np.arange(M.shape[0])).all() and np.array_equal(M[s], M)
+    # sharding the moving axis does not change any answer (what the multi-GPU split relies on)
+    a, b = 12345, 30001
+    assert np.array_equal(ctx.Matching(B[a:b], M), idx[a:b])
+    # permuting the model permutes the answers consistently (distances identical, ties aside)
+    perm = rng.permutation(M.shape[0])
+    idx2 = ctx.Matching(B, M[perm])
+    assert np.array_equal(d2(B, M[perm], idx2), best)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the loop, pass by pass, from captured inputs
+# ---------------------------------------------------------------------------------------------------
+def _stepwise(ctx, pkg, orc, D, M, max_iter, tol, metric=None, fixed=False, check_every=1):
+    ctx.set_model(M)
+    ctx.set_moving(D)
+    ctx.loop_begin(metric if metric is not None else pkg.ICP_POINT_TO_POINT, max_iter=max_iter, tol=tol, fixed_iterations=fixed)
+    k = 0
+    while True:
+        ctx.loop_enqueue()          # [transform of pass k-1] + matching/moments of pass k
+        if ctx.loop_complete():
+            break
+        if k % check_every == 0:
+            Pk = ctx.get_moving()   # the cloud pass k was matched on, as the device holds it
+            assert np.array_equal(ctx.get_indices(), orc.nn(Pk, M)), f"pass {k}: indices differ from the oracle on the same input"
+        k += 1
+    return ctx.loop_state()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_loop_indices_bit_exact_every_pass(ctx, pkg, orc, dtype):
+    if dtype == np.float64:
+        D, M = orc.synth_icp_cpu(32)
+        st = _stepwise(ctx, pkg, orc, D, M, 200, 1e-5)
+        want = orc.icp_p2p(D, M, 200, 1e-5)
+    else:
+        D = pkg.datasets.synthetic_grid(32, np.float32)
+        M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+        st = _stepwise(ctx, pkg, orc, D, M, 40, 1e-6)
+        want = orc.icp_p2p_f32x(D, M, 40, 1e-6)
+    assert_same_run(st["iterations"], st["err"], st["T"], want, 1e-5 if dtype == np.float64 else 1e-6, fp32=(dtype == np.float32))
+
+
+def test_single_pass_transform_and_error(ctx, pkg, orc):
+    """one pass from identical inputs: R,t / moved cloud / E against the oracle's statements"""
+    D, M = orc.synth_icp_cpu(24)
+    res = ctx.point_to_point(D, M, max_iter=1, tol=1e-5)
+    idx = orc.nn(D, M)
+    R, t, _ = orc.p2p_minimize(D, M, idx)
+    moved = orc.transform(D, R, t)
+    assert res.passes == 1 and np.array_equal(res.idx, idx)
+    assert rel(res.T[:3, :3], R) < 1e-12 and rel(res.T[:3, 3], t) < 1e-12
+    assert rel(res.moved, moved) < 1e-11
+    assert abs(res.err[1] - orc.rms_error(moved, M, idx)) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------
+# full runs (the reference programs' configurations)
+# ---------------------------------------------------------------------------------------------------
+def test_icp_cpu_config_f64(ctx, orc):
+    """configs[0]: src/ICP_CPU.c (fp64, tol 1e-5, MAX_ITER 200) at WIDTH 32 -- and the oracle itself
+    reproduces the reference's recorded 56 iterations for this input (tests/test_oracle.py)."""
+    D, M = orc.synth_icp_cpu(32)
+    res = ctx.point_to_point(D, M, max_iter=200, tol=1e-5)
+    want = orc.icp_p2p(D, M, 200, 1e-5)
+    assert res.iterations == want["iterations"] == 56
+    assert rel(res.T, want["T"]) < TOL_T
+    assert np.abs(res.err - want["err"]).max() < TOL_E
+    assert rel(res.moved, want["moved"]) < TOL_T
+
+
+def test_icp_standard_config(ctx, pkg, orc):
+    D = pkg.datasets.synthetic_grid(32, np.float32)
+    M = pkg.datasets.make_model_standard(D)
+    res = ctx.point_to_point(D, M, max_iter=40, tol=0.0, fixed_iterations=True)
+    want = orc.icp_p2p_f32x(D, M, 40, 0.0, fixed=True)
+    assert_close_to_fp32_twin(res, orc.icp_p2p(D, M, 40, 0.0, fixed=True))
+    assert res.passes == want["passes"] == 40 and res.iterations == 40
+    assert rel(res.T, want["T"]) < TOL_T
+    assert np.abs(res.err - want["err"]).max() < TOL_E
+
+
+def test_icp_point_to_point_128(ctx, pkg, orc):
+    D = pkg.datasets.synthetic_grid(128, np.float32)          # src/ICP_point_to_point.cu as shipped
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    res = ctx.point_to_point(D, M, max_iter=40, tol=1e-6)
+    want = orc.icp_p2p_f32x(D, M, 40, 1e-6)
+    assert_close_to_fp32_twin(res, orc.icp_p2p(D, M, 40, 1e-6))
+    assert_same_run(res.iterations, res.err, res.T, want, 1e-6, fp32=True)
+
+
+def test_icp_hall(ctx, pkg, orc, golden):
+    """configs[2]: hall LiDAR scan, point-to-point, fp32.  Clouds built by the product path (device
+    polar->Cartesian) must agree with the oracle's; the run must recover the baked-in motion."""
+    r = np.fromfile(os.path.join(golden, "hall_ranges_u32.bin"), dtype=np.uint32)
+    alt, az = pkg.datasets.read_os1_intrinsics(os.path.join(golden, "beam_intrinsics.csv"))
+    P, Q = pkg.datasets.hall_clouds(ctx, r, 33616, alt, az)
+    Po, Qo = orc.hall_clouds(golden)
+    assert np.abs(P - Po).max() < 2e-5 * np.abs(Po).max() and np.abs(Q - Qo).max() < 2e-5 * np.abs(Qo).max()
+    # parity on the oracle-built clouds (identical inputs on both sides)
+    res = ctx.point_to_point(Po, Qo, max_iter=100, tol=1e-6)
+    want = orc.icp_p2p_f32x(Po, Qo, 100, 1e-6)
+    assert_close_to_fp32_twin(res, orc.icp_p2p(Po, Qo, 100, 1e-6))
+    assert_same_run(res.iterations, res.err, res.T, want, 1e-6, fp32=True)
+    # ground truth baked into the dataset (mm translation scaled to metres): sanity bound
+    ang, t_mm = pkg.datasets.HALL_MM
+    assert np.abs(res.T[:3, 3] - np.array(t_mm) / 1000.0).max() < 5e-3
+    assert abs(res.T[1, 0] - np.sin(ang[2])) < 5e-3
+
+
+def test_icp_bunny(ctx, pkg, orc, golden):
+    B = np.fromfile(os.path.join(golden, "bunny_res_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
+    M = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
+    res = ctx.point_to_point(B, M, max_iter=100, tol=1e-6)
+    want = orc.icp_p2p_f32x(B, M, 100, 1e-6)
+    assert_close_to_fp32_twin(res, orc.icp_p2p(B, M, 100, 1e-6))
+    assert_same_run(res.iterations, res.err, res.T, want, 1e-6, fp32=True)
+
+
+def test_loop_is_reentrant_and_deterministic(ctx, pkg):
+    D = pkg.datasets.synthetic_grid(48, np.float32)
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    a = ctx.point_to_point(D, M, max_iter=15, tol=1e-6)
+    b = ctx.point_to_point(D, M, max_iter=15, tol=1e-6)
+    assert np.array_equal(a.T, b.T) and np.array_equal(a.idx, b.idx) and np.array_equal(a.err, b.err)
+    with pkg.Context(0) as other:          # a second context is independent
+        c = other.point_to_point(D, M, max_iter=15, tol=1e-6)
+    assert np.array_equal(a.T, c.T)
