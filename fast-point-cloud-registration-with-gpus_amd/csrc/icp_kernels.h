@@ -24,6 +24,8 @@ struct NNPlan {
     int blocks_x;       // n_pad / (NN_BLOCK * T)
     int splits;         // S: model segments scanned by different blocks (grid.y)
     int seg_len;        // model points per segment (multiple of NN_CHUNK)
+    int version;        // 1: generic kernel (fp64, A/B), 2: packed fp32 kernel
+    int chunk;          // index-tracking chunk of the launched kernel
 };
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }

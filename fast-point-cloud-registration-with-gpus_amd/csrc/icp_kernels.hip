@@ -202,6 +202,173 @@ __global__ __launch_bounds__(NN_BLOCK) void nn_match_kernel(const F* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// matching, fp32, v2 -- the shipped fp32 kernel.
+//
+// What the gfx950 VALU probe (profiles/r1/valu_rate_gfx950.txt) says and how the kernel answers:
+//   * one wave issues a VALU instruction only every ~6 cycles whatever its ILP; a SIMD saturates
+//     at ~8 resident waves  -> <= 64 VGPRs (launch_bounds(256, 8)), 16 KB LDS per block;
+//   * v_pk_add/mul_f32 retire 2 results per issue slot (70 T results/s vs 51 T for plain ops)
+//     -> every sub/mul/add of the distance is a packed op over TWO MOVING POINTS of the lane; the
+//     model coordinate is broadcast into both halves with op_sel straight from the LDS quad,
+//     no v_mov.  Each half is an ordinary IEEE add/mul, so rounding is identical to the scalar form;
+//   * v_cndmask (VCC read) costs ~9 issue slots -> the chunk-id update sits behind a wave-uniform
+//     branch that is skipped while no lane's minimum moved.
+// Small clouds cannot fill 8 waves x 1024 SIMDs along the moving axis, so the model range is split
+// twice: grid.y segments (merged later from the partials) and, inside a block, one contiguous
+// quarter of the segment per wave (merged through LDS in ascending order, strict <, so the lowest
+// index still wins).  All four waves of a block own the SAME 64*T moving points.
+// ------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// (q.lo - p.lo, q.lo - p.hi) / (q.hi - p.lo, q.hi - p.hi): src0 half broadcast by op_sel, src1 negated
+template <int HI>
+__device__ __forceinline__ f2 pk_sub_bcast(f2 q, f2 p)
+{
+    f2 r;
+    if constexpr (HI == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(q), "v"(p));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(q), "v"(p));
+    return r;
+}
+
+template <int HI>
+__device__ __forceinline__ f2 pk_dist2(f2 qx, f2 qy, f2 qz, f2 px, f2 py, f2 pz)
+{
+    f2 dx = pk_sub_bcast<HI>(qx, px);
+    f2 dy = pk_sub_bcast<HI>(qy, py);
+    f2 dz = pk_sub_bcast<HI>(qz, pz);
+    dx = dx * dx;
+    dy = dy * dy;
+    dz = dz * dz;
+    f2 d = dx + dy;
+    return d + dz;
+}
+
+constexpr int NN2_TQW = 256;  // model points per wave per LDS tile step
+
+template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/>
+__global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(const float* __restrict__ P, int n_pad,
+                                                               const float* __restrict__ Q, int m_pad, int seg_len,
+                                                               float* __restrict__ part_d,
+                                                               int32_t* __restrict__ part_idx)
+{
+    constexpr int TP = T / 2;  // packed pairs of moving points per lane
+    __shared__ __attribute__((aligned(16))) float sq[4][3][NN2_TQW];
+    __shared__ float md[4][64 * T];
+    __shared__ int mi[4][64 * T];
+
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int wseg = seg_len >> 2;              // model points per wave (multiple of C)
+    const int q0 = blockIdx.y * seg_len;
+    const int my0 = q0 + w * wseg;
+    const int my1 = min(my0 + wseg, m_pad);     // may be <= my0: this wave's range is empty
+    const int ibase = blockIdx.x * (64 * T) + lane;
+
+    f2 px[TP], py[TP], pz[TP];
+    float best[T];
+    int cst[T];
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        const int i0 = ibase + (2 * u) * 64, i1 = i0 + 64;
+        px[u] = f2{P[i0], P[i1]};
+        py[u] = f2{P[(size_t)n_pad + i0], P[(size_t)n_pad + i1]};
+        pz[u] = f2{P[2 * (size_t)n_pad + i0], P[2 * (size_t)n_pad + i1]};
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) { best[t] = inf_<float>(); cst[t] = my0 / C; }
+
+    const int ntile = (wseg + NN2_TQW - 1) / NN2_TQW;
+    for (int k = 0; k < ntile; ++k) {
+        __syncthreads();
+        // cooperative fill of the four per-wave sub-tiles: 4 x 3 x 256 floats = 768 float4, 3 per thread
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int v = threadIdx.x + r * NN_BLOCK;      // 0..767
+            const int ww = v / 192, rem = v % 192;         // 192 float4 per wave sub-tile
+            const int a = rem / 64, e = (rem % 64) * 4;    // coordinate array, element offset
+            const int off = k * NN2_TQW + e;               // offset inside the wave's range
+            const int src = q0 + ww * wseg + off;
+            if (off < wseg && src < m_pad)
+                *reinterpret_cast<float4*>(&sq[ww][a][e]) = *reinterpret_cast<const float4*>(&Q[(size_t)a * m_pad + src]);
+        }
+        __syncthreads();
+
+        const int tile0 = my0 + k * NN2_TQW;
+        const int len = min(NN2_TQW, my1 - tile0);  // multiple of C, <= 0 when exhausted
+        for (int c = 0; c < len; c += C) {
+            float bo[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) bo[t] = best[t];
+#pragma unroll
+            for (int kk = 0; kk < C; kk += 4) {
+                const float4 qx4 = *reinterpret_cast<const float4*>(&sq[w][0][c + kk]);
+                const float4 qy4 = *reinterpret_cast<const float4*>(&sq[w][1][c + kk]);
+                const float4 qz4 = *reinterpret_cast<const float4*>(&sq[w][2][c + kk]);
+                const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+                const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+                const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+#pragma unroll
+                for (int u = 0; u < TP; ++u) {
+                    const f2 d0 = pk_dist2<0>(qxa, qya, qza, px[u], py[u], pz[u]);
+                    const f2 d1 = pk_dist2<1>(qxa, qya, qza, px[u], py[u], pz[u]);
+                    const f2 d2 = pk_dist2<0>(qxb, qyb, qzb, px[u], py[u], pz[u]);
+                    const f2 d3 = pk_dist2<1>(qxb, qyb, qzb, px[u], py[u], pz[u]);
+                    best[2 * u] = fmin_(fmin_(best[2 * u], d0.x), d1.x);
+                    best[2 * u] = fmin_(fmin_(best[2 * u], d2.x), d3.x);
+                    best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d0.y), d1.y);
+                    best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d2.y), d3.y);
+                }
+            }
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < T; ++t) any |= best[t] < bo[t];
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // wave-uniform: skipped while no minimum moved
+                const int cid = (tile0 + c) / C;
+#pragma unroll
+                for (int t = 0; t < T; ++t) cst[t] = (best[t] < bo[t]) ? cid : cst[t];
+            }
+        }
+    }
+
+    // index recovery inside the winning chunk (lowest j with d_j == min), then the in-block merge
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float pxt = (t & 1) ? px[t >> 1].y : px[t >> 1].x;
+        const float pyt = (t & 1) ? py[t >> 1].y : py[t >> 1].x;
+        const float pzt = (t & 1) ? pz[t >> 1].y : pz[t >> 1].x;
+        const int base = cst[t] * C;
+        int idx = base;
+        const float b = best[t];
+        if (my1 > my0) {
+#pragma unroll 4
+            for (int kk = C - 1; kk >= 0; --kk) {
+                const int j = base + kk;
+                const float d = dist2<float>(pxt, pyt, pzt, Q[j], Q[(size_t)m_pad + j], Q[2 * (size_t)m_pad + j]);
+                idx = (d == b) ? j : idx;
+            }
+        }
+        md[w][lane + t * 64] = b;
+        mi[w][lane + t * 64] = idx;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 * T) {
+        float b = md[0][threadIdx.x];
+        int bi = mi[0][threadIdx.x];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const float d = md[ww][threadIdx.x];
+            const int j = mi[ww][threadIdx.x];
+            if (d < b) { b = d; bi = j; }
+        }
+        const size_t o = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * (64 * T) + threadIdx.x;
+        part_d[o] = b;
+        part_idx[o] = bi;
+    }
+}
+
 // lexicographic (d, j) minimum over the S segment partials: segments are ascending model ranges,
 // so the first strict minimum in segment order is the lowest index.
 template <typename F>
@@ -486,6 +653,34 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus)
     static const int env_T = env_int("ICP_NN_T", 0);
     static const int env_S = env_int("ICP_NN_SPLITS", 0);
     static const int env_bpc = env_int("ICP_NN_BLOCKS_PER_CU", 0);
+    static const int env_v1 = env_int("ICP_NN_V1", 0);
+    static const int env_C = env_int("ICP_NN_CHUNK", 0);
+    if (num_cus <= 0) num_cus = 256;
+    pl.version = (precision == ICP_F32 && !env_v1) ? 2 : 1;
+    pl.chunk = NN_CHUNK;
+    if (pl.version == 2) {
+        // v2: a block (4 waves) owns 64*T moving points, each wave a quarter of the block's segment.
+        // 8 resident waves per SIMD = 8 blocks per CU saturate the VALU (valu_rate probe).
+        const int bpc = env_bpc > 0 ? env_bpc : 8;
+        const int target_blocks = num_cus * bpc;
+        int T = (pl.n_pad / 256 >= target_blocks) ? 4 : 2;   // big clouds: 4 points per lane halve the LDS reads
+        if (env_T == 2 || env_T == 4) T = env_T;
+        pl.chunk = (env_C == 8 || env_C == 16) ? env_C : 16;
+        pl.pts_per_thread = T;
+        pl.blocks_x = pl.n_pad / (64 * T);
+        if (n <= 0 || m <= 0) { pl.splits = 0; pl.seg_len = 0; return pl; }
+        const int gran = 4 * pl.chunk;                        // four wave quarters of whole chunks
+        int S = (target_blocks + pl.blocks_x - 1) / pl.blocks_x;
+        const int max_S = (pl.m_pad + 511) / 512;             // keep >= 128 model points per wave
+        if (S > max_S) S = max_S;
+        if (env_S > 0) S = env_S;
+        if (S < 1) S = 1;
+        int seg = round_up((pl.m_pad + S - 1) / S, gran);
+        S = (pl.m_pad + seg - 1) / seg;
+        pl.splits = S;
+        pl.seg_len = seg;
+        return pl;
+    }
     int T = precision == ICP_F64 ? NNCfg<double>::T : NNCfg<float>::T;
     if (env_T == 1 || env_T == 2 || env_T == 4 || env_T == 8) T = env_T;
     if (precision == ICP_F64 && T > 4) T = 4;
@@ -494,7 +689,6 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus)
     if (n <= 0 || m <= 0) { pl.splits = 0; pl.seg_len = 0; return pl; }
     // small clouds cannot fill 256 CUs along the moving axis alone: split the model range over
     // grid.y until every CU holds `bpc` blocks of 4 waves.
-    if (num_cus <= 0) num_cus = 256;
     const int bpc = env_bpc > 0 ? env_bpc : 2;
     const int target_blocks = num_cus * bpc;
     int S = (target_blocks + pl.blocks_x - 1) / pl.blocks_x;
@@ -528,9 +722,26 @@ static hipError_t launch_nn_t(const NNPlan& pl, const void* P, const void* Q, vo
     return hipGetLastError();
 }
 
+static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
+                               hipStream_t st)
+{
+    dim3 grid(pl.blocks_x, pl.splits);
+#define ICP_LAUNCH_NN2(TT, CC)                                                                                      \
+    hipLaunchKernelGGL((nn_match_f32_v2<TT, CC>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,            \
+                       (const float*)Q, pl.m_pad, pl.seg_len, (float*)part_d, part_idx)
+    if (pl.pts_per_thread == 4) {
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8); else ICP_LAUNCH_NN2(4, 16);
+    } else {
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8); else ICP_LAUNCH_NN2(2, 16);
+    }
+#undef ICP_LAUNCH_NN2
+    return hipGetLastError();
+}
+
 hipError_t launch_nn(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx, hipStream_t st)
 {
     if (pl.n <= 0 || pl.m <= 0) return hipSuccess;
+    if (pl.version == 2) return launch_nn_v2(pl, P, Q, part_d, part_idx, st);
     return pl.precision == ICP_F64 ? launch_nn_t<double>(pl, P, Q, part_d, part_idx, st)
                                    : launch_nn_t<float>(pl, P, Q, part_d, part_idx, st);
 }
