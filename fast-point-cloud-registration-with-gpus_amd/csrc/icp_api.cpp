@@ -15,6 +15,7 @@
 // indices of the last CONTRIBUTING pass survive the speculative one.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -82,6 +83,7 @@ struct LoopState {
     double seconds_nn = 0.0;
     int nn_launches = 0;
     bool timed_nn = false;
+    bool host_reduce = false;  // how the pending enqueue's partial rows are being reduced
 };
 
 }  // namespace
@@ -97,12 +99,27 @@ struct icp_ctx {
     int prec = -1;  // precision of the resident clouds (model and moving must agree)
     int n = 0, m = 0;
     bool have_model = false, have_moving = false, have_normals = false;
-    DevBuf P, Q, Nrm, stage;
+    DevBuf P, P2, Q, Nrm, stage;  // P2: ping-pong target of the transform fused into the matching kernel
     DevBuf part_d, part_idx, idx[2];
     int cur = 0;  // idx buffer written by the most recent matching pass
     DevBuf mom_partials, err_partials, mom_own, nbr, cov;
     double* mom_dev = nullptr;
-    double* h_mom = nullptr;  // pinned
+    double* h_mom = nullptr;  // pinned: the reduced ICP_NMOM vector as the host solve reads it
+    // single-GPU fast path: the moments / transform kernels store their per-block partial rows straight
+    // into mapped pinned host memory and the host adds them in block order -- no finalize launch, no
+    // D2H blit.  (With an external moments buffer, i.e. the multi-GPU driver, the device finalize runs.)
+    double* h_mom_partials = nullptr;  // [MOM_MAX_BLOCKS][ICP_NMOM]
+    double* h_err_partials = nullptr;  // [err_cap]
+    size_t err_cap = 0;                // rows available in err_partials / h_err_partials
+    uint64_t tag_seq = 0;              // completion tag of the most recent moments launch (exact in a double)
+    int profile_stride = 0;            // time every n-th matching launch (0 = never)
+    uint64_t nn_launch_count = 0;
+    // ICP_TRACE=1: host-side time split of the loop, printed by icp_destroy
+    bool trace = false;
+    double tr_enqueue = 0, tr_wait = 0, tr_reduce = 0, tr_solve = 0;
+    uint64_t tr_n = 0;
+    bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
+    bool host_reduce() const { return mom_dev == (double*)mom_own.p && h_mom_partials != nullptr; }
     icp::NNPlan plan{};
     LoopState loop;
 };
@@ -128,7 +145,17 @@ int ensure_work_buffers(icp_ctx* c)
     HIP_TRY(c->idx[1].ensure((size_t)pl.n_pad * sizeof(int32_t)));
     const bool fresh = c->mom_partials.cap == 0;
     HIP_TRY(c->mom_partials.ensure((size_t)icp::MOM_MAX_BLOCKS * ICP_NMOM * sizeof(double)));
-    HIP_TRY(c->err_partials.ensure((size_t)icp::MOM_MAX_BLOCKS * sizeof(double)));
+    // one error row per matching block row (fused transform) or per transform block
+    size_t err_rows = (size_t)icp::MOM_MAX_BLOCKS;
+    if ((size_t)pl.blocks_x > err_rows) err_rows = (size_t)pl.blocks_x;
+    if (err_rows > c->err_cap) {
+        if (c->h_err_partials) { (void)hipHostFree(c->h_err_partials); c->h_err_partials = nullptr; }
+        HIP_TRY(hipHostMalloc((void**)&c->h_err_partials, err_rows * sizeof(double), hipHostMallocMapped));
+        std::memset(c->h_err_partials, 0, err_rows * sizeof(double));
+        c->err_cap = err_rows;
+    }
+    HIP_TRY(c->err_partials.ensure(err_rows * sizeof(double)));
+    if (icp::nn_can_fuse_transform(pl)) HIP_TRY(c->P2.ensure(3 * (size_t)pl.n_pad * es));
     HIP_TRY(c->mom_own.ensure(ICP_NMOM * sizeof(double)));
     if (fresh) {
         HIP_TRY(hipMemsetAsync(c->mom_partials.p, 0, c->mom_partials.cap, c->stream));
@@ -215,12 +242,18 @@ int icp_create(int device, icp_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mom, ICP_NMOM * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void**)&c->h_mom_partials, (size_t)icp::MOM_MAX_BLOCKS * ICP_NMOM * sizeof(double),
+                          hipHostMallocMapped);
+    if (e == hipSuccess) std::memset(c->h_mom_partials, 0, (size_t)icp::MOM_MAX_BLOCKS * ICP_NMOM * sizeof(double));
     if (e != hipSuccess) {
         const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
         icp_destroy(c);
         return fail(ICP_ERR_HIP, msg);
     }
     c->stream = c->own_stream;
+    if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
+    if (const char* v = std::getenv("ICP_TRACE")) c->trace = v[0] == '1';
     *out = c;
     return ICP_OK;
 }
@@ -228,12 +261,18 @@ int icp_create(int device, icp_ctx** out)
 void icp_destroy(icp_ctx* c)
 {
     if (!c) return;
+    if (c->trace && c->tr_n)
+        std::fprintf(stderr, "[icp trace] %llu iterations: enqueue %.2f us, wait %.2f us, reduce %.2f us, solve %.2f us (host, per iteration)\n",
+                     (unsigned long long)c->tr_n, 1e6 * c->tr_enqueue / c->tr_n, 1e6 * c->tr_wait / c->tr_n,
+                     1e6 * c->tr_reduce / c->tr_n, 1e6 * c->tr_solve / c->tr_n);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->P, &c->Q, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->P, &c->P2, &c->Q, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->cov};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
+    if (c->h_mom_partials) (void)hipHostFree(c->h_mom_partials);
+    if (c->h_err_partials) (void)hipHostFree(c->h_err_partials);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -252,6 +291,7 @@ int icp_set_profiling(icp_ctx* c, int enable)
 {
     if (!c) return fail(ICP_ERR_INVALID, "null context");
     c->profiling = enable != 0;
+    c->profile_stride = enable > 0 ? enable : 0;
     return ICP_OK;
 }
 
@@ -338,7 +378,7 @@ int icp_nn_match_resident(icp_ctx* c, float* kernel_ms)
     if (int rc = require_clouds(c)) return rc;
     if (int rc = ensure_work_buffers(c)) return rc;
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, c->stream));
+    HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, c->stream));
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(icp::launch_merge(c->plan, c->part_d.p, (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -354,7 +394,7 @@ int icp_nn_match_bench(icp_ctx* c, int reps, float* total_ms)
     if (int rc = ensure_work_buffers(c)) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; ++r)
-        HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, c->stream));
+        HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventElapsedTime(total_ms, c->ev0, c->ev1));
@@ -460,13 +500,22 @@ int icp_loop_enqueue(icp_ctx* c)
     if (int rc = use(c)) return rc;
     LoopState& L = c->loop;
     if (!L.active || L.done || L.pending) return fail(ICP_ERR_STATE, "enqueue: loop not ready");
+    const auto tr0 = std::chrono::steady_clock::now();
     const icp::NNPlan& pl = c->plan;
     L.err_blocks = 0;
     L.mom_blocks = 0;
-    if (L.have_rt) {
-        HIP_TRY(icp::launch_transform_error(c->prec, c->P.p, c->n, pl.n_pad, L.R, L.t, c->Q.p, pl.m_pad,
-                                            (const int32_t*)c->idx[c->cur].p, (double*)c->err_partials.p,
-                                            &L.err_blocks, c->stream));
+    const bool host_reduce = c->host_reduce();
+    double* mom_rows = host_reduce ? c->h_mom_partials : (double*)c->mom_partials.p;
+    double* err_rows = host_reduce ? c->h_err_partials : (double*)c->err_partials.p;
+    const bool apply = L.have_rt;
+    const bool final_only = L.applied + (apply ? 1 : 0) >= L.prm.max_iter;  // the loop ends after this error
+    // the transform of the previous pass rides in the front of the matching kernel when that kernel
+    // supports it; otherwise (fp64, or nothing left to match) it is its own launch
+    const bool fused = apply && !final_only && icp::nn_can_fuse_transform(pl);
+    if (apply) {
+        if (!fused)
+            HIP_TRY(icp::launch_transform_error(c->prec, c->P.p, c->n, pl.n_pad, L.R, L.t, c->Q.p, pl.m_pad,
+                                                (const int32_t*)c->idx[c->cur].p, err_rows, &L.err_blocks, c->stream));
         // compose with the values that were actually applied (rounded to the storage precision)
         double Tk[16] = {0};
         for (int a = 0; a < 3; ++a) {
@@ -487,20 +536,30 @@ int icp_loop_enqueue(icp_ctx* c)
         L.applied += 1;
         L.have_rt = false;
     }
-    const bool final_only = L.applied >= L.prm.max_iter;  // the loop ends after this error whatever it is
     L.timed_nn = false;
     if (!final_only) {
         c->cur ^= 1;
-        if (c->profiling) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); }
-        HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, c->stream));
-        if (c->profiling) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); L.timed_nn = true; }
+        const bool time_this = c->profile_stride > 0 && (c->nn_launch_count++ % (uint64_t)c->profile_stride) == 0;
+        if (time_this) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); }
+        if (fused) {
+            icp::NNFusedTransform ft{L.R, L.t, (const int32_t*)c->idx[L.applied_idx].p, c->P2.p, err_rows};
+            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, c->stream));
+            std::swap(c->P, c->P2);  // the moved cloud is the current one from here on
+            L.err_blocks = pl.blocks_x;
+        } else {
+            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, c->stream));
+        }
+        if (time_this) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); L.timed_nn = true; }
         HIP_TRY(icp::launch_moments(pl, L.prm.metric, c->P.p, c->Q.p, c->Nrm.p, c->part_d.p,
-                                    (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p,
-                                    (double*)c->mom_partials.p, &L.mom_blocks, c->stream));
+                                    (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, mom_rows,
+                                    &L.mom_blocks, (double)(++c->tag_seq), c->stream));
     }
-    HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
-                                 (const double*)c->err_partials.p, L.err_blocks, c->stream));
+    if (!host_reduce)
+        HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
+                                     (const double*)c->err_partials.p, L.err_blocks, c->stream));
+    L.host_reduce = host_reduce;
     L.pending = true;
+    if (c->trace) c->tr_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
     return ICP_OK;
 }
 
@@ -524,8 +583,44 @@ int icp_loop_complete(icp_ctx* c, int* done)
     if (int rc = use(c)) return rc;
     LoopState& L = c->loop;
     if (!L.active || !L.pending) return fail(ICP_ERR_STATE, "complete without enqueue");
-    HIP_TRY(hipMemcpyAsync(c->h_mom, c->mom_dev, ICP_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr1 = tr0;
+    if (L.host_reduce) {
+        // the kernels wrote their partial rows into mapped pinned memory.  Instead of a stream
+        // synchronisation the host polls the per-row completion tags (each row is released to system
+        // scope before its tag); the matching kernel's error rows were complete before the moments
+        // kernel started.  Fixed block order => the same bits every run.
+        bool polled = false;
+        if (L.mom_blocks > 0 && !L.timed_nn && c->poll) {
+            const double want = (double)c->tag_seq;
+            const auto t0 = std::chrono::steady_clock::now();
+            int b = 0;
+            unsigned spins = 0;
+            while (b < L.mom_blocks) {
+                const volatile double* tagp = c->h_mom_partials + (size_t)b * ICP_NMOM + (ICP_NMOM - 1);
+                if (*tagp == want) { ++b; continue; }
+                if ((++spins & 0x3ff) == 0 &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
+                    break;  // something is wrong (fault, hang): let the runtime report it
+            }
+            polled = b == L.mom_blocks;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!polled) HIP_TRY(hipStreamSynchronize(c->stream));
+        tr1 = std::chrono::steady_clock::now();
+        double* mom = c->h_mom;
+        for (int k = 0; k < ICP_NMOM; ++k) mom[k] = 0.0;
+        for (int b = 0; b < L.err_blocks; ++b) mom[ICP_MOM_ERR] += c->h_err_partials[b];
+        for (int b = 0; b < L.mom_blocks; ++b) {
+            const double* row = c->h_mom_partials + (size_t)b * ICP_NMOM;
+            for (int k = 1; k < ICP_NMOM; ++k) mom[k] += row[k];
+        }
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->h_mom, c->mom_dev, ICP_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        tr1 = std::chrono::steady_clock::now();
+    }
+    const auto tr2 = std::chrono::steady_clock::now();
     L.pending = false;
     if (L.timed_nn) {
         float ms = 0.f;
@@ -558,6 +653,13 @@ int icp_loop_complete(icp_ctx* c, int* done)
             return fail(rc, "minimisation failed (degenerate correspondences)");
         }
         L.have_rt = true;
+    }
+    if (c->trace) {
+        const auto tr3 = std::chrono::steady_clock::now();
+        c->tr_wait += std::chrono::duration<double>(tr1 - tr0).count();
+        c->tr_reduce += std::chrono::duration<double>(tr2 - tr1).count();
+        c->tr_solve += std::chrono::duration<double>(tr3 - tr2).count();
+        c->tr_n += 1;
     }
     if (done) *done = L.done ? 1 : 0;
     return ICP_OK;

@@ -37,9 +37,20 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus);
 
 size_t elem_size(int precision);
 
-// matching: per (segment, point) partial minimum + index
+// the transform of the previous pass, fused into the front of the matching kernel (fp32 kernel only):
+// P_out <- R * P_in + t, err_rows[block_x] <- sum |p_new - q[idx_prev]|^2
+struct NNFusedTransform {
+    const double* R9;
+    const double* t3;
+    const int32_t* idx_prev;
+    void* P_out;       // SoA, same padding as the input; must not alias it
+    double* err_rows;  // >= blocks_x doubles
+};
+bool nn_can_fuse_transform(const NNPlan& pl);
+
+// matching: per (segment, point) partial minimum + index.  `ft` (optional) = fused transform.
 hipError_t launch_nn(const NNPlan& pl, const void* P_soa, const void* Q_soa, void* part_d, int32_t* part_idx,
-                     hipStream_t st);
+                     const NNFusedTransform* ft, hipStream_t st);
 // stand-alone merge of the segment partials into idx (icp_nn_match_* only; the ICP loop merges
 // inside the moments kernel)
 hipError_t launch_merge(const NNPlan& pl, const void* part_d, const int32_t* part_idx, int32_t* idx, hipStream_t st);
@@ -49,6 +60,7 @@ constexpr int MOM_MAX_BLOCKS = 1024;
 // partials: [blocks][ICP_NMOM] doubles; returns the number of blocks used in *blocks.
 hipError_t launch_moments(const NNPlan& pl, int metric, const void* P_soa, const void* Q_soa, const void* N_soa,
                           const void* part_d, const int32_t* part_idx, int32_t* idx, double* partials, int* blocks,
+                          double tag /* stored in slot ICP_NMOM-1 of every row once the row is complete */,
                           hipStream_t st);
 // p <- R p + t in place (storage precision, separately rounded mul/add), and
 // sum |p_new - q[idx]|^2 in fp64 -> err_partials[block]

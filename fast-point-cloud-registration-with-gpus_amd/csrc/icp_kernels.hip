@@ -70,8 +70,23 @@ template <int NACC, int BLOCK>
 __device__ __forceinline__ void block_sum_store(const double (&acc)[NACC], double* out)
 {
     constexpr int NW = BLOCK / 64;
-    __shared__ double red[NW][NACC];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if constexpr (NW == 1 && NACC > 2) {
+        // single wave, many slots: transpose through LDS (rows padded to 65 doubles: lane k reads bank 2k)
+        // and let lane k add its slot's 64 entries in lane order -- far fewer cross-lane ops than NACC butterflies
+        __shared__ double tr[NACC][65];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
+        __syncthreads();
+        if (lane < NACC) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int l = 0; l < 64; ++l) s += tr[lane][l];
+            out[lane] = s;
+        }
+        return;
+    }
+    __shared__ double red[NW][NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
         const double s = wave_sum(acc[k]);
@@ -248,11 +263,41 @@ __device__ __forceinline__ f2 pk_dist2(f2 qx, f2 qy, f2 qz, f2 px, f2 py, f2 pz)
 
 constexpr int NN2_TQW = 256;  // model points per wave per LDS tile step
 
+// rigid motion applied to the moving cloud; travels by value in the kernel-argument segment
+template <typename F> struct RT { F r[9]; F t[3]; };
+
+// ((r0*x + r1*y) + r2*z) + t with separately rounded products and sums -- the association of RyT
+// (src/ICP_point_to_point.cu:85).  One definition for every kernel that moves points, so the fused
+// and the stand-alone transform produce the same bits.
+template <typename F>
+__device__ __forceinline__ void apply_rt(const RT<F>& rt, F x, F y, F z, F& ox, F& oy, F& oz)
+{
+    F o[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        F c = rt.r[a * 3 + 0] * x;
+        c = c + rt.r[a * 3 + 1] * y;
+        c = c + rt.r[a * 3 + 2] * z;
+        o[a] = c + rt.t[a];
+    }
+    ox = o[0]; oy = o[1]; oz = o[2];
+}
+
+// optional fused front end of the matching kernel: the transform of the PREVIOUS pass
+struct NNFuse {
+    int apply;               // 0: match P as it is
+    int n;                   // real moving points (the error skips the padding)
+    const int32_t* idx_prev; // correspondences the applied (R, t) came from
+    float* P_out;            // transformed cloud (written by the grid.y == 0 blocks only)
+    double* err_rows;        // [gridDim.x] sum |p_new - q[idx_prev]|^2 per block
+};
+
 template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/>
 __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(const float* __restrict__ P, int n_pad,
                                                                const float* __restrict__ Q, int m_pad, int seg_len,
                                                                float* __restrict__ part_d,
-                                                               int32_t* __restrict__ part_idx)
+                                                               int32_t* __restrict__ part_idx, RT<float> rt,
+                                                               NNFuse fuse)
 {
     constexpr int TP = T / 2;  // packed pairs of moving points per lane
     __shared__ __attribute__((aligned(16))) float sq[4][3][NN2_TQW];
@@ -276,6 +321,35 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
         px[u] = f2{P[i0], P[i1]};
         py[u] = f2{P[(size_t)n_pad + i0], P[(size_t)n_pad + i1]};
         pz[u] = f2{P[2 * (size_t)n_pad + i0], P[2 * (size_t)n_pad + i1]};
+    }
+    if (fuse.apply) {
+        // every block re-derives the moved points in registers (same instructions => same bits);
+        // the grid.y == 0 row stores them and accounts the error of the pass that produced (R, t)
+        double err = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int u = t >> 1;
+            float x = (t & 1) ? px[u].y : px[u].x, y = (t & 1) ? py[u].y : py[u].x, z = (t & 1) ? pz[u].y : pz[u].x;
+            apply_rt<float>(rt, x, y, z, x, y, z);
+            if (t & 1) { px[u].y = x; py[u].y = y; pz[u].y = z; } else { px[u].x = x; py[u].x = y; pz[u].x = z; }
+            if (blockIdx.y == 0 && w == 0) {
+                const int i = ibase + t * 64;
+                fuse.P_out[i] = x;
+                fuse.P_out[(size_t)n_pad + i] = y;
+                fuse.P_out[2 * (size_t)n_pad + i] = z;
+                if (i < fuse.n) {
+                    const int j = fuse.idx_prev[i];
+                    const double ex = (double)Q[j] - (double)x;
+                    const double ey = (double)Q[(size_t)m_pad + j] - (double)y;
+                    const double ez = (double)Q[2 * (size_t)m_pad + j] - (double)z;
+                    err += ex * ex + ey * ey + ez * ez;
+                }
+            }
+        }
+        if (blockIdx.y == 0 && w == 0) {
+            err = wave_sum(err);
+            if (lane == 0) fuse.err_rows[blockIdx.x] = err;
+        }
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) { best[t] = inf_<float>(); cst[t] = my0 / C; }
@@ -377,7 +451,20 @@ __device__ __forceinline__ int merge_partials(const F* __restrict__ part_d, cons
 {
     F best = part_d[i];
     int bi = part_idx[i];
-    for (int s = 1; s < S; ++s) {
+    int s = 1;
+    for (; s + 8 <= S; s += 8) {  // 16 independent loads in flight, then the ordered compare chain
+        F d[8];
+        int j[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            d[u] = part_d[(size_t)(s + u) * n_pad + i];
+            j[u] = part_idx[(size_t)(s + u) * n_pad + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (d[u] < best) { best = d[u]; bi = j[u]; }
+    }
+    for (; s < S; ++s) {
         const F d = part_d[(size_t)s * n_pad + i];
         const int j = part_idx[(size_t)s * n_pad + i];
         if (d < best) { best = d; bi = j; }
@@ -399,7 +486,7 @@ __global__ void merge_kernel(const F* __restrict__ part_d, const int32_t* __rest
 // fused merge + gather + moments.  HBM-bound: per moving point 12 B (p) + 8*S B (partials)
 // + 4 B (idx store) + 12 B gathered (q) [+ 12 B normals], accumulated in fp64.
 // ------------------------------------------------------------------------------------------------
-constexpr int MOM_BLOCK = 256;
+constexpr int MOM_BLOCK = 64;  // one wave per block: no LDS, no barrier; 256 blocks already at 16 384 points
 
 template <typename F, int METRIC>
 __global__ __launch_bounds__(MOM_BLOCK) void moments_kernel(const F* __restrict__ P, int n, int n_pad,
@@ -408,7 +495,7 @@ __global__ __launch_bounds__(MOM_BLOCK) void moments_kernel(const F* __restrict_
                                                             const F* __restrict__ part_d,
                                                             const int32_t* __restrict__ part_idx, int S,
                                                             int32_t* __restrict__ idx_out,
-                                                            double* __restrict__ partials)
+                                                            double* __restrict__ partials, double tag)
 {
     constexpr int NACC = (METRIC == ICP_POINT_TO_POINT) ? 18 : 28;
     double acc[NACC];
@@ -449,6 +536,11 @@ __global__ __launch_bounds__(MOM_BLOCK) void moments_kernel(const F* __restrict_
     }
     // slot 0 of the moment vector is the error of the preceding transform (written by finalize)
     block_sum_store<NACC, MOM_BLOCK>(acc, partials + (size_t)blockIdx.x * ICP_NMOM + 1);
+    // completion tag for a host that polls the (pinned, mapped) rows instead of synchronising the
+    // stream: the row's data is released to system scope before the tag becomes visible
+    static_assert(MOM_BLOCK == 64, "the tag protocol assumes one wave per block");
+    __threadfence_system();
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * ICP_NMOM + (ICP_NMOM - 1)] = tag;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -456,7 +548,6 @@ __global__ __launch_bounds__(MOM_BLOCK) void moments_kernel(const F* __restrict_
 // + 12 B gathered q.  The products and sums are rounded separately in the storage precision
 // ((r0*x + r1*y) + r2*z) + t, the association of RyT (src/ICP_point_to_point.cu:85).
 // ------------------------------------------------------------------------------------------------
-template <typename F> struct RT { F r[9]; F t[3]; };
 constexpr int TR_BLOCK = 256;
 
 template <typename F>
@@ -469,13 +560,7 @@ __global__ __launch_bounds__(TR_BLOCK) void transform_error_kernel(F* __restrict
     for (int i = blockIdx.x * TR_BLOCK + threadIdx.x; i < n_pad; i += gridDim.x * TR_BLOCK) {
         const F x = P[i], y = P[(size_t)n_pad + i], z = P[2 * (size_t)n_pad + i];
         F o[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            F c = rt.r[a * 3 + 0] * x;
-            c = c + rt.r[a * 3 + 1] * y;
-            c = c + rt.r[a * 3 + 2] * z;
-            o[a] = c + rt.t[a];
-        }
+        apply_rt<F>(rt, x, y, z, o[0], o[1], o[2]);
         P[i] = o[0];
         P[(size_t)n_pad + i] = o[1];
         P[2 * (size_t)n_pad + i] = o[2];
@@ -723,12 +808,23 @@ static hipError_t launch_nn_t(const NNPlan& pl, const void* P, const void* Q, vo
 }
 
 static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
-                               hipStream_t st)
+                               const NNFusedTransform* ft, hipStream_t st)
 {
     dim3 grid(pl.blocks_x, pl.splits);
+    RT<float> rt{};
+    NNFuse fuse{};
+    if (ft) {
+        for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
+        for (int k = 0; k < 3; ++k) rt.t[k] = (float)ft->t3[k];
+        fuse.apply = 1;
+        fuse.n = pl.n;
+        fuse.idx_prev = ft->idx_prev;
+        fuse.P_out = (float*)ft->P_out;
+        fuse.err_rows = ft->err_rows;
+    }
 #define ICP_LAUNCH_NN2(TT, CC)                                                                                      \
     hipLaunchKernelGGL((nn_match_f32_v2<TT, CC>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,            \
-                       (const float*)Q, pl.m_pad, pl.seg_len, (float*)part_d, part_idx)
+                       (const float*)Q, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse)
     if (pl.pts_per_thread == 4) {
         if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8); else ICP_LAUNCH_NN2(4, 16);
     } else {
@@ -738,10 +834,14 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     return hipGetLastError();
 }
 
-hipError_t launch_nn(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx, hipStream_t st)
+bool nn_can_fuse_transform(const NNPlan& pl) { return pl.version == 2 && pl.n > 0 && pl.m > 0; }
+
+hipError_t launch_nn(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
+                     const NNFusedTransform* ft, hipStream_t st)
 {
     if (pl.n <= 0 || pl.m <= 0) return hipSuccess;
-    if (pl.version == 2) return launch_nn_v2(pl, P, Q, part_d, part_idx, st);
+    if (pl.version == 2) return launch_nn_v2(pl, P, Q, part_d, part_idx, ft, st);
+    if (ft) return hipErrorInvalidValue;  // only the packed fp32 kernel carries the fused front end
     return pl.precision == ICP_F64 ? launch_nn_t<double>(pl, P, Q, part_d, part_idx, st)
                                    : launch_nn_t<float>(pl, P, Q, part_d, part_idx, st);
 }
@@ -761,7 +861,7 @@ hipError_t launch_merge(const NNPlan& pl, const void* part_d, const int32_t* par
 
 hipError_t launch_moments(const NNPlan& pl, int metric, const void* P, const void* Q, const void* Nrm,
                           const void* part_d, const int32_t* part_idx, int32_t* idx, double* partials, int* blocks,
-                          hipStream_t st)
+                          double tag, hipStream_t st)
 {
     int nb = (pl.n + MOM_BLOCK - 1) / MOM_BLOCK;
     if (nb > MOM_MAX_BLOCKS) nb = MOM_MAX_BLOCKS;
@@ -769,7 +869,7 @@ hipError_t launch_moments(const NNPlan& pl, int metric, const void* P, const voi
     if (nb <= 0) return hipSuccess;
 #define ICP_LAUNCH_MOM(F, MET)                                                                                     \
     hipLaunchKernelGGL((moments_kernel<F, MET>), dim3(nb), dim3(MOM_BLOCK), 0, st, (const F*)P, pl.n, pl.n_pad,      \
-                       (const F*)Q, pl.m, pl.m_pad, (const F*)Nrm, (const F*)part_d, part_idx, pl.splits, idx, partials)
+                       (const F*)Q, pl.m, pl.m_pad, (const F*)Nrm, (const F*)part_d, part_idx, pl.splits, idx, partials, tag)
     if (pl.precision == ICP_F64) {
         if (metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_MOM(double, ICP_POINT_TO_PLANE);
         else ICP_LAUNCH_MOM(double, ICP_POINT_TO_POINT);

@@ -91,8 +91,9 @@ void icp_destroy(icp_ctx* ctx);
 /* run all work of this context on an externally owned hipStream_t (e.g. torch's current stream);
  * NULL restores the context's own stream */
 int icp_set_stream(icp_ctx* ctx, void* hip_stream);
-/* collect per-kernel hipEvent timings (adds two event records per launch) */
-int icp_set_profiling(icp_ctx* ctx, int enable);
+/* hipEvent timing of the matching kernel inside the loop: 0 = off, n > 0 = time every n-th launch
+ * (two event records + a stream synchronisation on the timed iterations only) */
+int icp_set_profiling(icp_ctx* ctx, int every_nth);
 
 /* ---- matching seam: replaces  Matching<<<>>>(n, P, Q, q_points, idx)
  *      src/CUDA/GPU_point_to_point_real.cu:38-79, src/ICP_point_to_point.cu:31-57 (fp32) and the

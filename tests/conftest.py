@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own HIP runtime: when both live in one process torch must be loaded first
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

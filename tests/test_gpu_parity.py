@@ -252,3 +252,33 @@ def test_loop_is_reentrant_and_deterministic(ctx, pkg):
     with pkg.Context(0) as other:          # a second context is independent
         c = other.point_to_point(D, M, max_iter=15, tol=1e-6)
     assert np.array_equal(a.T, c.T)
+
+
+def test_external_moments_buffer_and_stream(ctx, pkg):
+    """the multi-GPU driver's plumbing on one device: the loop writes its 32-double vector into a torch
+    tensor on torch's stream (device finalize path); results must agree with the single-GPU host-reduce path."""
+    import torch
+    D = pkg.datasets.synthetic_grid(64, np.float32)
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    want = ctx.point_to_point(D, M, max_iter=12, tol=1e-6)
+    mom = torch.zeros(pkg.ICP_NMOM, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.set_model(M)
+    ctx.set_moving(D)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.loop_set_moments_dev(mom.data_ptr())
+    try:
+        ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=12, tol=1e-6)
+        seen_counts = []
+        while True:
+            ctx.loop_enqueue()
+            seen_counts.append(float(mom[1].item()))     # ordered behind the finalize kernel on torch's stream
+            if ctx.loop_complete():
+                break
+        st = ctx.loop_state()
+    finally:
+        ctx.loop_set_moments_dev(0)
+        ctx.set_stream(0)
+    assert st["iterations"] == want.iterations
+    assert rel(st["T"], want.T) < 1e-12 and np.abs(st["err"] - want.err).max() < 1e-12
+    assert seen_counts[0] == D.shape[0]
