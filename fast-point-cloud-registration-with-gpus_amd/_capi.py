@@ -59,6 +59,7 @@ SIGNATURES = {
     "icp_get_indices": (_i, [_vp, _vp]),
     "icp_nn_match_resident": (_i, [_vp, _pf]),
     "icp_nn_match_bench": (_i, [_vp, _i, _pf]),
+    "icp_nn_match_bench_ex": (_i, [_vp, _i, _i, _pf]),
     "icp_nn_launch_info": (_i, [_vp, _pi, _pi, _pi, _pi, _pi]),
     "icp_estimate_normals": (_i, [_vp, _vp, _vp]),
     "icp_point_to_point": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(icp_params), C.POINTER(icp_result)]),

@@ -15,8 +15,10 @@
 // indices of the last CONTRIBUTING pass survive the speculative one.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <limits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -84,6 +86,7 @@ struct LoopState {
     int nn_launches = 0;
     bool timed_nn = false;
     bool host_reduce = false;  // how the pending enqueue's partial rows are being reduced
+    bool matched = false;      // a matching pass of THIS loop has filled idx[cur]
 };
 
 }  // namespace
@@ -99,9 +102,12 @@ struct icp_ctx {
     int prec = -1;  // precision of the resident clouds (model and moving must agree)
     int n = 0, m = 0;
     bool have_model = false, have_moving = false, have_normals = false;
-    DevBuf P, P2, Q, Nrm, stage;  // P2: ping-pong target of the transform fused into the matching kernel
+    DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
+    bool have_scan_copy = false;
+    int voided = 0;  // P2: ping-pong target of the transform fused into the matching kernel
     DevBuf part_d, part_idx, idx[2];
     int cur = 0;  // idx buffer written by the most recent matching pass
+    bool idx_valid = false;  // idx[cur] holds matches of the resident clouds
     DevBuf mom_partials, err_partials, mom_own, nbr, cov;
     double* mom_dev = nullptr;
     double* h_mom = nullptr;  // pinned: the reduced ICP_NMOM vector as the host solve reads it
@@ -179,6 +185,44 @@ int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision,
     // pageable host source has been consumed before returning
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ICP_OK;
+}
+
+// AoS in (m points) -> AoS out (m_pad points): a point whose (x, y, z) equals that of a LOWER index is
+// replaced by (+inf, +inf, +inf), and so is the padding.  -0 and +0 compare equal (they give identical
+// distances); NaN coordinates are never treated as duplicates.  O(m log m), once per model.
+int void_duplicate_points(const float* in, int m, int m_pad, float* out)
+{
+    std::vector<int> order((size_t)m);
+    for (int i = 0; i < m; ++i) order[i] = i;
+    auto key = [&](int i, int a) -> uint32_t {
+        float v = in[3 * (size_t)i + a];
+        if (v == 0.0f) v = 0.0f;  // canonical zero
+        uint32_t b;
+        std::memcpy(&b, &v, 4);
+        return b;
+    };
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t ka = key(a, k), kb = key(b, k);
+            if (ka != kb) return ka < kb;
+        }
+        return a < b;
+    });
+    const float inf = std::numeric_limits<float>::infinity();
+    std::memcpy(out, in, 3 * (size_t)m * sizeof(float));
+    int voided = 0;
+    for (int s = 1; s < m; ++s) {
+        const int a = order[s - 1], b = order[s];
+        const bool same = key(a, 0) == key(b, 0) && key(a, 1) == key(b, 1) && key(a, 2) == key(b, 2);
+        const bool nan = in[3 * (size_t)b] != in[3 * (size_t)b] || in[3 * (size_t)b + 1] != in[3 * (size_t)b + 1] ||
+                         in[3 * (size_t)b + 2] != in[3 * (size_t)b + 2];
+        if (same && !nan) {  // b has a lower-index twin (runs are index-ascending inside equal keys)
+            out[3 * (size_t)b] = out[3 * (size_t)b + 1] = out[3 * (size_t)b + 2] = inf;
+            ++voided;
+        }
+    }
+    for (size_t i = 3 * (size_t)m; i < 3 * (size_t)m_pad; ++i) out[i] = inf;
+    return voided;
 }
 
 int check_precision(int precision)
@@ -267,7 +311,7 @@ void icp_destroy(icp_ctx* c)
                      1e6 * c->tr_reduce / c->tr_n, 1e6 * c->tr_solve / c->tr_n);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->P, &c->P2, &c->Q, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->P, &c->P2, &c->Q, &c->Qs, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->cov};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -305,7 +349,18 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
     c->m = m;
     c->have_normals = false;
     c->loop.active = false;
+    c->idx_valid = false;
     if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q)) return rc;
+    c->have_scan_copy = false;
+    if (precision == ICP_F32 && m > 0) {
+        // scan copy for the early-out matching kernel: exact duplicates of a lower-index point (and the
+        // padding) voided to +inf -- they can never be the lowest-index minimum (see NNCullInputs)
+        const int m_pad = icp::pad_model(m);
+        std::vector<float> scan(3 * (size_t)m_pad);
+        c->voided = void_duplicate_points((const float*)xyz, m, m_pad, scan.data());
+        if (int rc = upload_cloud(c, scan.data(), m_pad, m_pad, precision, c->Qs)) return rc;
+        c->have_scan_copy = true;
+    }
     c->have_model = true;
     return ICP_OK;
 }
@@ -320,6 +375,7 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
     c->prec = precision;
     c->n = n;
     c->loop.active = false;
+    c->idx_valid = false;
     if (int rc = upload_cloud(c, xyz, n, icp::pad_moving(n), precision, c->P)) return rc;
     c->have_moving = true;
     return ICP_OK;
@@ -378,23 +434,30 @@ int icp_nn_match_resident(icp_ctx* c, float* kernel_ms)
     if (int rc = require_clouds(c)) return rc;
     if (int rc = ensure_work_buffers(c)) return rc;
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, c->stream));
+    const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr, nullptr};
+    HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, c->stream));
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(icp::launch_merge(c->plan, c->part_d.p, (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->idx_valid = true;
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, c->ev0, c->ev1));
     return ICP_OK;
 }
 
-int icp_nn_match_bench(icp_ctx* c, int reps, float* total_ms)
+int icp_nn_match_bench(icp_ctx* c, int reps, float* total_ms) { return icp_nn_match_bench_ex(c, reps, 1, total_ms); }
+
+int icp_nn_match_bench_ex(icp_ctx* c, int reps, int seeded, float* total_ms)
 {
     if (int rc = use(c)) return rc;
     if (int rc = require_clouds(c)) return rc;
     if (reps <= 0 || !total_ms) return fail(ICP_ERR_INVALID, "reps/total_ms");
     if (int rc = ensure_work_buffers(c)) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // seeded with the most recent correspondences when there are any: this is how the loop launches it
+    const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
+                                 (seeded && c->idx_valid) ? (const int32_t*)c->idx[c->cur].p : nullptr};
     for (int r = 0; r < reps; ++r)
-        HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, c->stream));
+        HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventElapsedTime(total_ms, c->ev0, c->ev1));
@@ -538,16 +601,21 @@ int icp_loop_enqueue(icp_ctx* c)
     }
     L.timed_nn = false;
     if (!final_only) {
+        // the previous pass's matches seed the early-out bound (any valid index would do)
+        const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
+                                     L.matched ? (const int32_t*)c->idx[c->cur].p : nullptr};
         c->cur ^= 1;
+        L.matched = true;
+        c->idx_valid = true;
         const bool time_this = c->profile_stride > 0 && (c->nn_launch_count++ % (uint64_t)c->profile_stride) == 0;
         if (time_this) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); }
         if (fused) {
             icp::NNFusedTransform ft{L.R, L.t, (const int32_t*)c->idx[L.applied_idx].p, c->P2.p, err_rows};
-            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, c->stream));
+            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, c->stream));
             std::swap(c->P, c->P2);  // the moved cloud is the current one from here on
             L.err_blocks = pl.blocks_x;
         } else {
-            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, c->stream));
+            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, c->stream));
         }
         if (time_this) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); L.timed_nn = true; }
         HIP_TRY(icp::launch_moments(pl, L.prm.metric, c->P.p, c->Q.p, c->Nrm.p, c->part_d.p,

@@ -26,6 +26,7 @@ struct NNPlan {
     int seg_len;        // model points per segment (multiple of NN_CHUNK)
     int version;        // 1: generic kernel (fp64, A/B), 2: packed fp32 kernel
     int chunk;          // index-tracking chunk of the launched kernel
+    int cull;           // the packed kernel may use the seeded-bound / xy early-out variant
 };
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -48,9 +49,22 @@ struct NNFusedTransform {
 };
 bool nn_can_fuse_transform(const NNPlan& pl);
 
-// matching: per (segment, point) partial minimum + index.  `ft` (optional) = fused transform.
+// inputs of the early-out ("cull") variant of the packed kernel.  Q_scan is a copy of the model whose
+// exact duplicates (same x,y,z as a LOWER index) are voided to +inf: such a point can never be the
+// lowest-index minimum, and voiding it keeps one coincident cluster (e.g. the hall scan's 4361
+// no-return points) from defeating the early-out for every chunk.  seed_idx: any valid model index
+// per moving point (the previous pass's match) or NULL.
+struct NNCullInputs {
+    const void* Q_scan;
+    const int32_t* seed_idx;
+};
+
+// matching: per (segment, point) partial minimum + index.  `ft` (optional) = fused transform,
+// `opt` (optional) = early-out inputs.
 hipError_t launch_nn(const NNPlan& pl, const void* P_soa, const void* Q_soa, void* part_d, int32_t* part_idx,
-                     const NNFusedTransform* ft, hipStream_t st);
+                     const NNFusedTransform* ft, const NNCullInputs* opt, hipStream_t st);
+// void the exact duplicates of a padded SoA model (host side, O(m) hash); returns how many were voided
+int void_duplicate_points_f32(const float* Q_soa_host, int m, int m_pad, float* out_soa_host);
 // stand-alone merge of the segment partials into idx (icp_nn_match_* only; the ICP loop merges
 // inside the moments kernel)
 hipError_t launch_merge(const NNPlan& pl, const void* part_d, const int32_t* part_idx, int32_t* idx, hipStream_t st);

@@ -290,9 +290,12 @@ struct NNFuse {
     const int32_t* idx_prev; // correspondences the applied (R, t) came from
     float* P_out;            // transformed cloud (written by the grid.y == 0 blocks only)
     double* err_rows;        // [gridDim.x] sum |p_new - q[idx_prev]|^2 per block
+    const int32_t* seed_idx; // CULL kernels: any valid model index per moving point (or NULL); it only
+                             // tightens the starting bound, the result does not depend on it
+    const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
 };
 
-template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/>
+template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/, bool CULL /*seeded bound + xy early-out*/>
 __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(const float* __restrict__ P, int n_pad,
                                                                const float* __restrict__ Q, int m_pad, int seg_len,
                                                                float* __restrict__ part_d,
@@ -339,9 +342,10 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
                 fuse.P_out[2 * (size_t)n_pad + i] = z;
                 if (i < fuse.n) {
                     const int j = fuse.idx_prev[i];
-                    const double ex = (double)Q[j] - (double)x;
-                    const double ey = (double)Q[(size_t)m_pad + j] - (double)y;
-                    const double ez = (double)Q[2 * (size_t)m_pad + j] - (double)z;
+                    const float* Qg = fuse.Q_gather;
+                    const double ex = (double)Qg[j] - (double)x;
+                    const double ey = (double)Qg[(size_t)m_pad + j] - (double)y;
+                    const double ez = (double)Qg[2 * (size_t)m_pad + j] - (double)z;
                     err += ex * ex + ey * ey + ez * ez;
                 }
             }
@@ -352,7 +356,24 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
         }
     }
 #pragma unroll
-    for (int t = 0; t < T; ++t) { best[t] = inf_<float>(); cst[t] = my0 / C; }
+    for (int t = 0; t < T; ++t) { best[t] = inf_<float>(); cst[t] = -1; }
+    if constexpr (CULL) {
+        // Seeded bound: start from the distance to ANY model point (last pass's match) bumped by one ulp.
+        // The true minimum is <= that distance < bound, so the ordinary ascending strict-< scan still ends
+        // on the first index of the minimum -- the seed changes how much work is skipped, never the answer.
+        if (fuse.seed_idx) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int u = t >> 1;
+                const float x = (t & 1) ? px[u].y : px[u].x, y = (t & 1) ? py[u].y : py[u].x, z = (t & 1) ? pz[u].y : pz[u].x;
+                const int j = fuse.seed_idx[ibase + t * 64];
+                const float* Qg = fuse.Q_gather;
+                const float d = dist2<float>(x, y, z, Qg[j], Qg[(size_t)m_pad + j], Qg[2 * (size_t)m_pad + j]);
+                // next float above d (d >= 0, finite): bit pattern + 1; inf stays inf
+                best[t] = (d < inf_<float>()) ? __uint_as_float(__float_as_uint(d) + 1u) : d;
+            }
+        }
+    }
 
     const int ntile = (wseg + NN2_TQW - 1) / NN2_TQW;
     for (int k = 0; k < ntile; ++k) {
@@ -376,24 +397,79 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
             float bo[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) bo[t] = best[t];
+            if constexpr (CULL) {
+                // phase A: the inner sum of the reference's association, pxy = dx*dx + dy*dy, for the whole
+                // chunk.  d = fl(pxy + dz*dz) >= pxy, so a chunk whose smallest pxy is not below any lane's
+                // running minimum cannot lower it (nor win a tie: ascending order, strict <) -- skip its z half.
+                f2 pxy[TP][C];
+                float mxy[T];
 #pragma unroll
-            for (int kk = 0; kk < C; kk += 4) {
-                const float4 qx4 = *reinterpret_cast<const float4*>(&sq[w][0][c + kk]);
-                const float4 qy4 = *reinterpret_cast<const float4*>(&sq[w][1][c + kk]);
-                const float4 qz4 = *reinterpret_cast<const float4*>(&sq[w][2][c + kk]);
-                const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
-                const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
-                const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+                for (int t = 0; t < T; ++t) mxy[t] = inf_<float>();
 #pragma unroll
-                for (int u = 0; u < TP; ++u) {
-                    const f2 d0 = pk_dist2<0>(qxa, qya, qza, px[u], py[u], pz[u]);
-                    const f2 d1 = pk_dist2<1>(qxa, qya, qza, px[u], py[u], pz[u]);
-                    const f2 d2 = pk_dist2<0>(qxb, qyb, qzb, px[u], py[u], pz[u]);
-                    const f2 d3 = pk_dist2<1>(qxb, qyb, qzb, px[u], py[u], pz[u]);
-                    best[2 * u] = fmin_(fmin_(best[2 * u], d0.x), d1.x);
-                    best[2 * u] = fmin_(fmin_(best[2 * u], d2.x), d3.x);
-                    best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d0.y), d1.y);
-                    best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d2.y), d3.y);
+                for (int kk = 0; kk < C; kk += 4) {
+                    const float4 qx4 = *reinterpret_cast<const float4*>(&sq[w][0][c + kk]);
+                    const float4 qy4 = *reinterpret_cast<const float4*>(&sq[w][1][c + kk]);
+                    const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+                    const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) {
+                        f2 ax, ay;
+                        ax = pk_sub_bcast<0>(qxa, px[u]); ay = pk_sub_bcast<0>(qya, py[u]);
+                        pxy[u][kk + 0] = ax * ax + ay * ay;
+                        ax = pk_sub_bcast<1>(qxa, px[u]); ay = pk_sub_bcast<1>(qya, py[u]);
+                        pxy[u][kk + 1] = ax * ax + ay * ay;
+                        ax = pk_sub_bcast<0>(qxb, px[u]); ay = pk_sub_bcast<0>(qyb, py[u]);
+                        pxy[u][kk + 2] = ax * ax + ay * ay;
+                        ax = pk_sub_bcast<1>(qxb, px[u]); ay = pk_sub_bcast<1>(qyb, py[u]);
+                        pxy[u][kk + 3] = ax * ax + ay * ay;
+                        mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk].x), pxy[u][kk + 1].x);
+                        mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk + 2].x), pxy[u][kk + 3].x);
+                        mxy[2 * u + 1] = fmin_(fmin_(mxy[2 * u + 1], pxy[u][kk].y), pxy[u][kk + 1].y);
+                        mxy[2 * u + 1] = fmin_(fmin_(mxy[2 * u + 1], pxy[u][kk + 2].y), pxy[u][kk + 3].y);
+                    }
+                }
+                bool need = false;
+#pragma unroll
+                for (int t = 0; t < T; ++t) need |= mxy[t] < best[t];
+                if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;  // wave-uniform early-out
+                // phase B: finish the chunk exactly as the un-culled kernel would have
+#pragma unroll
+                for (int kk = 0; kk < C; kk += 4) {
+                    const float4 qz4 = *reinterpret_cast<const float4*>(&sq[w][2][c + kk]);
+                    const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) {
+                        f2 az;
+                        az = pk_sub_bcast<0>(qza, pz[u]); const f2 d0 = pxy[u][kk + 0] + az * az;
+                        az = pk_sub_bcast<1>(qza, pz[u]); const f2 d1 = pxy[u][kk + 1] + az * az;
+                        az = pk_sub_bcast<0>(qzb, pz[u]); const f2 d2 = pxy[u][kk + 2] + az * az;
+                        az = pk_sub_bcast<1>(qzb, pz[u]); const f2 d3 = pxy[u][kk + 3] + az * az;
+                        best[2 * u] = fmin_(fmin_(best[2 * u], d0.x), d1.x);
+                        best[2 * u] = fmin_(fmin_(best[2 * u], d2.x), d3.x);
+                        best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d0.y), d1.y);
+                        best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d2.y), d3.y);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < C; kk += 4) {
+                    const float4 qx4 = *reinterpret_cast<const float4*>(&sq[w][0][c + kk]);
+                    const float4 qy4 = *reinterpret_cast<const float4*>(&sq[w][1][c + kk]);
+                    const float4 qz4 = *reinterpret_cast<const float4*>(&sq[w][2][c + kk]);
+                    const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+                    const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+                    const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) {
+                        const f2 d0 = pk_dist2<0>(qxa, qya, qza, px[u], py[u], pz[u]);
+                        const f2 d1 = pk_dist2<1>(qxa, qya, qza, px[u], py[u], pz[u]);
+                        const f2 d2 = pk_dist2<0>(qxb, qyb, qzb, px[u], py[u], pz[u]);
+                        const f2 d3 = pk_dist2<1>(qxb, qyb, qzb, px[u], py[u], pz[u]);
+                        best[2 * u] = fmin_(fmin_(best[2 * u], d0.x), d1.x);
+                        best[2 * u] = fmin_(fmin_(best[2 * u], d2.x), d3.x);
+                        best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d0.y), d1.y);
+                        best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d2.y), d3.y);
+                    }
                 }
             }
             bool any = false;
@@ -413,10 +489,12 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
         const float pxt = (t & 1) ? px[t >> 1].y : px[t >> 1].x;
         const float pyt = (t & 1) ? py[t >> 1].y : py[t >> 1].x;
         const float pzt = (t & 1) ? pz[t >> 1].y : pz[t >> 1].x;
-        const int base = cst[t] * C;
-        int idx = base;
-        const float b = best[t];
-        if (my1 > my0) {
+        const bool found = cst[t] >= 0;  // this wave's range lowered the (possibly seeded) bound at least once
+        const int base = found ? cst[t] * C : 0;
+        int idx = 0x7fffffff;
+        const float b = found ? best[t] : inf_<float>();
+        if (found) {
+            idx = base;
 #pragma unroll 4
             for (int kk = C - 1; kk >= 0; --kk) {
                 const int j = base + kk;
@@ -751,6 +829,9 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus)
         int T = (pl.n_pad / 256 >= target_blocks) ? 4 : 2;   // big clouds: 4 points per lane halve the LDS reads
         if (env_T == 2 || env_T == 4) T = env_T;
         pl.chunk = (env_C == 8 || env_C == 16) ? env_C : 16;
+        static const int env_cull = env_int("ICP_NN_CULL", 1);
+        pl.cull = (T == 2 && env_cull) ? 1 : 0;
+        if (pl.cull && env_C == 0) pl.chunk = 8;  // 16 partial sums per chunk would spill under the 64-VGPR cap
         pl.pts_per_thread = T;
         pl.blocks_x = pl.n_pad / (64 * T);
         if (n <= 0 || m <= 0) { pl.splits = 0; pl.seg_len = 0; return pl; }
@@ -808,11 +889,17 @@ static hipError_t launch_nn_t(const NNPlan& pl, const void* P, const void* Q, vo
 }
 
 static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
-                               const NNFusedTransform* ft, hipStream_t st)
+                               const NNFusedTransform* ft, const NNCullInputs* opt, hipStream_t st)
 {
     dim3 grid(pl.blocks_x, pl.splits);
     RT<float> rt{};
     NNFuse fuse{};
+    fuse.Q_gather = (const float*)Q;
+    const void* Qscan = Q;
+    if (pl.cull && opt && opt->Q_scan) {
+        Qscan = opt->Q_scan;
+        fuse.seed_idx = opt->seed_idx;
+    }
     if (ft) {
         for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
         for (int k = 0; k < 3; ++k) rt.t[k] = (float)ft->t3[k];
@@ -822,13 +909,16 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         fuse.P_out = (float*)ft->P_out;
         fuse.err_rows = ft->err_rows;
     }
-#define ICP_LAUNCH_NN2(TT, CC)                                                                                      \
-    hipLaunchKernelGGL((nn_match_f32_v2<TT, CC>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,            \
-                       (const float*)Q, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse)
+#define ICP_LAUNCH_NN2(TT, CC, CU)                                                                                  \
+    hipLaunchKernelGGL((nn_match_f32_v2<TT, CC, CU>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,        \
+                       (const float*)Qscan, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse)
+    const bool cull = pl.cull && Qscan != Q;
     if (pl.pts_per_thread == 4) {
-        if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8); else ICP_LAUNCH_NN2(4, 16);
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8, false); else ICP_LAUNCH_NN2(4, 16, false);
+    } else if (cull) {
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, true); else ICP_LAUNCH_NN2(2, 16, true);
     } else {
-        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8); else ICP_LAUNCH_NN2(2, 16);
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, false); else ICP_LAUNCH_NN2(2, 16, false);
     }
 #undef ICP_LAUNCH_NN2
     return hipGetLastError();
@@ -837,10 +927,10 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
 bool nn_can_fuse_transform(const NNPlan& pl) { return pl.version == 2 && pl.n > 0 && pl.m > 0; }
 
 hipError_t launch_nn(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
-                     const NNFusedTransform* ft, hipStream_t st)
+                     const NNFusedTransform* ft, const NNCullInputs* opt, hipStream_t st)
 {
     if (pl.n <= 0 || pl.m <= 0) return hipSuccess;
-    if (pl.version == 2) return launch_nn_v2(pl, P, Q, part_d, part_idx, ft, st);
+    if (pl.version == 2) return launch_nn_v2(pl, P, Q, part_d, part_idx, ft, opt, st);
     if (ft) return hipErrorInvalidValue;  // only the packed fp32 kernel carries the fused front end
     return pl.precision == ICP_F64 ? launch_nn_t<double>(pl, P, Q, part_d, part_idx, st)
                                    : launch_nn_t<float>(pl, P, Q, part_d, part_idx, st);

@@ -126,9 +126,9 @@ class Context:
         capi.check(self._lib.icp_nn_match_resident(self._h, C.byref(ms) if timed else None), "icp_nn_match_resident")
         return ms.value
 
-    def nn_match_bench(self, reps):
+    def nn_match_bench(self, reps, seeded=True):
         ms = C.c_float(0)
-        capi.check(self._lib.icp_nn_match_bench(self._h, int(reps), C.byref(ms)), "icp_nn_match_bench")
+        capi.check(self._lib.icp_nn_match_bench_ex(self._h, int(reps), 1 if seeded else 0, C.byref(ms)), "icp_nn_match_bench_ex")
         return ms.value
 
     def nn_launch_info(self):

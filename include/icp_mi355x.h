@@ -116,6 +116,9 @@ int icp_nn_match_resident(icp_ctx* ctx, float* kernel_ms);
 /* `reps` back-to-back launches of the matching kernel alone between two hipEvents on the context's
  * stream; total_ms / reps is the kernel's average launch duration (bench.py roofline leg) */
 int icp_nn_match_bench(icp_ctx* ctx, int reps, float* total_ms);
+/* same; seeded != 0 hands the kernel the most recent correspondences as its starting bound (what the ICP
+ * loop does from its second pass on), seeded == 0 starts it cold (what icp_nn_match_* does) */
+int icp_nn_match_bench_ex(icp_ctx* ctx, int reps, int seeded, float* total_ms);
 /* geometry of the last matching launch, for the roofline arithmetic in bench.py */
 int icp_nn_launch_info(icp_ctx* ctx, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad);
 

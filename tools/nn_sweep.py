@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CHILD = r'''
 import os, sys, json, zlib, numpy as np
+SEED = bool(int(os.environ.get('SWEEP_SEEDED', '1')))
 sys.path.insert(0, %(root)r)
 from __graft_entry__ import load_package
 pkg = load_package()
@@ -36,8 +37,8 @@ ctx.set_model(Q); ctx.set_moving(P)
 ctx.nn_match_resident()
 idx = ctx.get_indices()
 reps = 30 if P.shape[0] < 100000 else 3
-ctx.nn_match_bench(3)
-ms = min(ctx.nn_match_bench(reps) / reps for _ in range(3))
+ctx.nn_match_bench(3, seeded=SEED)
+ms = min(ctx.nn_match_bench(reps, seeded=SEED) / reps for _ in range(3))
 info = ctx.nn_launch_info()
 print(json.dumps(dict(us=1e3 * ms, crc=zlib.crc32(idx.tobytes()), n=int(P.shape[0]), m=int(Q.shape[0]), **info)))
 '''
@@ -56,9 +57,9 @@ def main():
     names = sys.argv[1:] or ["hall"]
     for name in names:
         base = None
-        settings = [dict(ICP_NN_V1=1)]
-        for T, C, bpc in itertools.product((2, 4), (8, 16), (4, 6, 8, 12)):
-            settings.append(dict(ICP_NN_T=T, ICP_NN_CHUNK=C, ICP_NN_BLOCKS_PER_CU=bpc))
+        settings = [dict(ICP_NN_V1=1), dict(ICP_NN_CULL=0)]
+        for C, bpc, seeded in itertools.product((8, 16), (6, 8), (0, 1)):
+            settings.append(dict(ICP_NN_CULL=1, ICP_NN_CHUNK=C, ICP_NN_BLOCKS_PER_CU=bpc, SWEEP_SEEDED=seeded))
         for env in settings:
             r = run(name, env)
             if "error" in r:
