@@ -3,5 +3,6 @@ ICP_point_to_point / ICP_point_to_plane path).  The product is csrc/ -> libicp_m
 gfx950 HIP kernels behind the C ABI of include/icp_mi355x.h); this package is the thin host mirror."""
 from . import _capi as capi  # noqa: F401
 from . import datasets  # noqa: F401
+from . import distributed  # noqa: F401
 from ._capi import ICP_F32, ICP_F64, ICP_NMOM, ICP_POINT_TO_PLANE, ICP_POINT_TO_POINT, IcpError, load  # noqa: F401
 from .engine import Context, Result, eigh3, shard_range, solve_point_to_plane, solve_point_to_point  # noqa: F401

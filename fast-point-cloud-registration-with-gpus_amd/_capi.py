@@ -74,6 +74,11 @@ SIGNATURES = {
     "icp_loop_indices": (_i, [_vp, _vp]),
     "icp_solve_point_to_point": (_i, [_pd, _pd, _pd]),
     "icp_solve_point_to_plane": (_i, [_pd, _pd, _pd, _pd]),
+    "icp_host_loop_create": (_i, [C.POINTER(icp_params), C.POINTER(_vp)]),
+    "icp_host_loop_destroy": (None, [_vp]),
+    "icp_host_loop_advance": (_i, [_vp, _pd, _pi, _pd, _pd]),
+    "icp_host_loop_note_applied": (_i, [_vp]),
+    "icp_host_loop_state": (_i, [_vp, _pi, _pi, _pd, _i, _pd]),
     "icp_shard_range": (_i, [C.c_int64, _i, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "icp_eigh3": (_i, [_pd, _pd, _pd]),
     "icp_synthetic_grid_f32": (_i, [_i, C.c_float, C.c_float, _vp]),

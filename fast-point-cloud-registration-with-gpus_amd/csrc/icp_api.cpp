@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/icp_mi355x.h"
+#include "icp_host_loop.h"
 #include "icp_host_math.h"
 #include "icp_kernels.h"
 
@@ -70,18 +71,10 @@ struct DevBuf {
 
 struct LoopState {
     bool active = false;
-    bool done = false;
     bool pending = false;   // an enqueue awaits its complete
-    bool have_rt = false;   // R, t of the last completed pass are ready to be applied
-    icp_params prm{};
-    int applied = 0;        // transforms applied so far (= index k of the error being produced)
-    int iterations = 0;     // the reference's loop counter at exit
+    icp::HostLoop H;        // error series, stop rule, minimisation, transform composition (host only)
     int applied_idx = 0;    // idx buffer used by the last applied transform
     int mom_blocks = 0, err_blocks = 0;
-    double n_total = 0.0;
-    double R[9], t[3];
-    double T[16];
-    std::vector<double> err;
     double seconds_nn = 0.0;
     int nn_launches = 0;
     bool timed_nn = false;
@@ -551,10 +544,8 @@ int icp_loop_begin(icp_ctx* c, const icp_params* prm)
     if (int rc = ensure_work_buffers(c)) return rc;
     LoopState& L = c->loop;
     L = LoopState();
+    if (int rc = L.H.begin(*prm)) return fail(rc, "bad loop parameters");
     L.active = true;
-    L.prm = *prm;
-    L.err.assign((size_t)prm->max_iter + 1, 0.0);
-    for (int i = 0; i < 16; ++i) L.T[i] = (i % 5 == 0) ? 1.0 : 0.0;
     return ICP_OK;
 }
 
@@ -562,42 +553,27 @@ int icp_loop_enqueue(icp_ctx* c)
 {
     if (int rc = use(c)) return rc;
     LoopState& L = c->loop;
-    if (!L.active || L.done || L.pending) return fail(ICP_ERR_STATE, "enqueue: loop not ready");
+    if (!L.active || L.H.done || L.pending) return fail(ICP_ERR_STATE, "enqueue: loop not ready");
     const auto tr0 = std::chrono::steady_clock::now();
     const icp::NNPlan& pl = c->plan;
     L.err_blocks = 0;
     L.mom_blocks = 0;
     const bool host_reduce = c->host_reduce();
     double* mom_rows = host_reduce ? c->h_mom_partials : (double*)c->mom_partials.p;
-    double* err_rows = host_reduce ? c->h_err_partials : (double*)c->err_partials.p;
-    const bool apply = L.have_rt;
-    const bool final_only = L.applied + (apply ? 1 : 0) >= L.prm.max_iter;  // the loop ends after this error
+    double* err_rows = (double*)c->err_partials.p;  // device: the moments kernel folds them into its rows
+    const bool apply = L.H.have_rt;
+    const bool final_only = L.H.next_is_final();  // the loop ends after this error whatever it is
     // the transform of the previous pass rides in the front of the matching kernel when that kernel
     // supports it; otherwise (fp64, or nothing left to match) it is its own launch
     const bool fused = apply && !final_only && icp::nn_can_fuse_transform(pl);
     if (apply) {
-        if (!fused)
-            HIP_TRY(icp::launch_transform_error(c->prec, c->P.p, c->n, pl.n_pad, L.R, L.t, c->Q.p, pl.m_pad,
-                                                (const int32_t*)c->idx[c->cur].p, err_rows, &L.err_blocks, c->stream));
-        // compose with the values that were actually applied (rounded to the storage precision)
-        double Tk[16] = {0};
-        for (int a = 0; a < 3; ++a) {
-            for (int b = 0; b < 3; ++b)
-                Tk[a * 4 + b] = c->prec == ICP_F64 ? L.R[a * 3 + b] : (double)(float)L.R[a * 3 + b];
-            Tk[a * 4 + 3] = c->prec == ICP_F64 ? L.t[a] : (double)(float)L.t[a];
-        }
-        Tk[15] = 1.0;
-        double Tn[16];
-        for (int a = 0; a < 4; ++a)
-            for (int b = 0; b < 4; ++b) {
-                double s = 0;
-                for (int k = 0; k < 4; ++k) s += Tk[a * 4 + k] * L.T[k * 4 + b];
-                Tn[a * 4 + b] = s;
-            }
-        std::memcpy(L.T, Tn, sizeof Tn);
+        if (!fused)  // with nothing left to match, the last pass's rows go straight to the host
+            HIP_TRY(icp::launch_transform_error(c->prec, c->P.p, c->n, pl.n_pad, L.H.R, L.H.t, c->Q.p, pl.m_pad,
+                                                (const int32_t*)c->idx[c->cur].p,
+                                                (final_only && host_reduce) ? c->h_err_partials : err_rows,
+                                                &L.err_blocks, c->stream));
         L.applied_idx = c->cur;
-        L.applied += 1;
-        L.have_rt = false;
+        L.H.note_applied();
     }
     L.timed_nn = false;
     if (!final_only) {
@@ -610,7 +586,7 @@ int icp_loop_enqueue(icp_ctx* c)
         const bool time_this = c->profile_stride > 0 && (c->nn_launch_count++ % (uint64_t)c->profile_stride) == 0;
         if (time_this) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); }
         if (fused) {
-            icp::NNFusedTransform ft{L.R, L.t, (const int32_t*)c->idx[L.applied_idx].p, c->P2.p, err_rows};
+            icp::NNFusedTransform ft{L.H.R, L.H.t, (const int32_t*)c->idx[L.applied_idx].p, c->P2.p, err_rows};
             HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, c->stream));
             std::swap(c->P, c->P2);  // the moved cloud is the current one from here on
             L.err_blocks = pl.blocks_x;
@@ -618,9 +594,10 @@ int icp_loop_enqueue(icp_ctx* c)
             HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, c->stream));
         }
         if (time_this) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); L.timed_nn = true; }
-        HIP_TRY(icp::launch_moments(pl, L.prm.metric, c->P.p, c->Q.p, c->Nrm.p, c->part_d.p,
+        HIP_TRY(icp::launch_moments(pl, L.H.prm.metric, c->P.p, c->Q.p, c->Nrm.p, c->part_d.p,
                                     (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, mom_rows,
-                                    &L.mom_blocks, (double)(++c->tag_seq), c->stream));
+                                    &L.mom_blocks, (double)(++c->tag_seq), err_rows, L.err_blocks, c->stream));
+        if (host_reduce) L.err_blocks = 0;  // already inside the moment rows
     }
     if (!host_reduce)
         HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
@@ -681,7 +658,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
         for (int b = 0; b < L.err_blocks; ++b) mom[ICP_MOM_ERR] += c->h_err_partials[b];
         for (int b = 0; b < L.mom_blocks; ++b) {
             const double* row = c->h_mom_partials + (size_t)b * ICP_NMOM;
-            for (int k = 1; k < ICP_NMOM; ++k) mom[k] += row[k];
+            for (int k = 0; k < ICP_NMOM - 1; ++k) mom[k] += row[k];  // the last slot is the completion tag
         }
     } else {
         HIP_TRY(hipMemcpyAsync(c->h_mom, c->mom_dev, ICP_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -696,31 +673,10 @@ int icp_loop_complete(icp_ctx* c, int* done)
         L.seconds_nn += 1e-3 * ms;
         L.nn_launches += 1;
     }
-    const double* mom = c->h_mom;
-    if (mom[ICP_MOM_CNT] > 0) L.n_total = mom[ICP_MOM_CNT];
-    const int k = L.applied;
-    if (k >= 1) {
-        // E[k] = || q[idx_{k-1}] - p_k ||_2 / sqrt(N)   (src/ICP_CPU.c:266)
-        L.err[k] = std::sqrt(mom[ICP_MOM_ERR]) / std::sqrt(L.n_total);
-        const bool stop = !L.prm.fixed_iterations &&
-                          ((L.err[k] < L.prm.tol) || (std::fabs(L.err[k] - L.err[k - 1]) < L.prm.tol));
-        if (stop) {
-            L.iterations = k - 1;  // break before the counter is incremented (src/ICP_CPU.c:267)
-            L.done = true;
-        } else {
-            L.iterations = k;
-            if (k > L.prm.max_iter - 1) L.done = true;  // src/ICP_CPU.c:268-269
-        }
-    }
-    if (!L.done) {
-        const int rc = L.prm.metric == ICP_POINT_TO_PLANE ? icp::solve_point_to_plane(mom, L.R, L.t, nullptr)
-                                                          : icp::solve_point_to_point(mom, L.R, L.t);
-        if (rc != ICP_OK) {
-            L.done = true;
-            if (done) *done = 1;
-            return fail(rc, "minimisation failed (degenerate correspondences)");
-        }
-        L.have_rt = true;
+    const int adv = L.H.advance(c->h_mom);
+    if (adv != ICP_OK) {
+        if (done) *done = 1;
+        return fail(adv, "minimisation failed (degenerate correspondences)");
     }
     if (c->trace) {
         const auto tr3 = std::chrono::steady_clock::now();
@@ -729,7 +685,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
         c->tr_solve += std::chrono::duration<double>(tr3 - tr2).count();
         c->tr_n += 1;
     }
-    if (done) *done = L.done ? 1 : 0;
+    if (done) *done = L.H.done ? 1 : 0;
     return ICP_OK;
 }
 
@@ -738,13 +694,13 @@ int icp_loop_state(icp_ctx* c, int* iterations, int* passes, double* err, int er
     if (!c) return fail(ICP_ERR_INVALID, "null context");
     const LoopState& L = c->loop;
     if (!L.active) return fail(ICP_ERR_STATE, "no loop");
-    if (iterations) *iterations = L.iterations;
-    if (passes) *passes = L.applied;
+    if (iterations) *iterations = L.H.iterations;
+    if (passes) *passes = L.H.applied;
     if (err) {
-        const int cnt = (int)L.err.size() < err_cap ? (int)L.err.size() : err_cap;
-        for (int i = 0; i < cnt; ++i) err[i] = L.err[i];
+        const int cnt = (int)L.H.err.size() < err_cap ? (int)L.H.err.size() : err_cap;
+        for (int i = 0; i < cnt; ++i) err[i] = L.H.err[i];
     }
-    if (T16) std::memcpy(T16, L.T, sizeof L.T);
+    if (T16) std::memcpy(T16, L.H.T, sizeof L.H.T);
     return ICP_OK;
 }
 
@@ -761,7 +717,7 @@ int icp_loop_indices(icp_ctx* c, int32_t* out)
 {
     if (int rc = use(c)) return rc;
     if (!c->loop.active) return fail(ICP_ERR_STATE, "no loop");
-    return download_idx(c, c->loop.applied > 0 ? c->loop.applied_idx : c->cur, out);
+    return download_idx(c, c->loop.H.applied > 0 ? c->loop.applied_idx : c->cur, out);
 }
 
 static int run_loop(icp_ctx* c, const icp_params* prm, icp_result* out)
@@ -776,13 +732,13 @@ static int run_loop(icp_ctx* c, const icp_params* prm, icp_result* out)
     const auto t1 = std::chrono::steady_clock::now();
     const LoopState& L = c->loop;
     if (out) {
-        std::memcpy(out->T, L.T, sizeof L.T);
-        out->iterations = L.iterations;
-        out->passes = L.applied;
+        std::memcpy(out->T, L.H.T, sizeof L.H.T);
+        out->iterations = L.H.iterations;
+        out->passes = L.H.applied;
         out->seconds_total = std::chrono::duration<double>(t1 - t0).count();
         out->seconds_nn = L.seconds_nn;
         if (out->err)
-            for (size_t i = 0; i < L.err.size(); ++i) out->err[i] = L.err[i];
+            for (size_t i = 0; i < L.H.err.size(); ++i) out->err[i] = L.H.err[i];
         if (out->idx)
             if (int rc = icp_loop_indices(c, out->idx)) return rc;
         if (out->moved)

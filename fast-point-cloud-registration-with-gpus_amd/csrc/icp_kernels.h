@@ -75,6 +75,7 @@ constexpr int MOM_MAX_BLOCKS = 1024;
 hipError_t launch_moments(const NNPlan& pl, int metric, const void* P_soa, const void* Q_soa, const void* N_soa,
                           const void* part_d, const int32_t* part_idx, int32_t* idx, double* partials, int* blocks,
                           double tag /* stored in slot ICP_NMOM-1 of every row once the row is complete */,
+                          const double* err_rows /* device */, int err_count /* folded into slot ICP_MOM_ERR */,
                           hipStream_t st);
 // p <- R p + t in place (storage precision, separately rounded mul/add), and
 // sum |p_new - q[idx]|^2 in fp64 -> err_partials[block]

@@ -542,10 +542,18 @@ __device__ __forceinline__ int merge_partials(const F* __restrict__ part_d, cons
         for (int u = 0; u < 8; ++u)
             if (d[u] < best) { best = d[u]; bi = j[u]; }
     }
-    for (; s < S; ++s) {
-        const F d = part_d[(size_t)s * n_pad + i];
-        const int j = part_idx[(size_t)s * n_pad + i];
-        if (d < best) { best = d; bi = j; }
+    if (s < S) {  // tail: same 16 loads in flight, out-of-range slots replaced by +inf
+        F d[8];
+        int j[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ss = s + u < S ? s + u : S - 1;
+            d[u] = part_d[(size_t)ss * n_pad + i];
+            j[u] = part_idx[(size_t)ss * n_pad + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s + u < S && d[u] < best) { best = d[u]; bi = j[u]; }
     }
     return bi;
 }
@@ -573,7 +581,8 @@ __global__ __launch_bounds__(MOM_BLOCK) void moments_kernel(const F* __restrict_
                                                             const F* __restrict__ part_d,
                                                             const int32_t* __restrict__ part_idx, int S,
                                                             int32_t* __restrict__ idx_out,
-                                                            double* __restrict__ partials, double tag)
+                                                            double* __restrict__ partials, double tag,
+                                                            const double* __restrict__ err_rows, int err_count)
 {
     constexpr int NACC = (METRIC == ICP_POINT_TO_POINT) ? 18 : 28;
     double acc[NACC];
@@ -614,6 +623,13 @@ __global__ __launch_bounds__(MOM_BLOCK) void moments_kernel(const F* __restrict_
     }
     // slot 0 of the moment vector is the error of the preceding transform (written by finalize)
     block_sum_store<NACC, MOM_BLOCK>(acc, partials + (size_t)blockIdx.x * ICP_NMOM + 1);
+    // slot 0: this block's share of the error rows the preceding transform (fused into the matching
+    // kernel, or its own launch) left in device memory -- fixed assignment, fixed order
+    if (threadIdx.x == 0) {
+        double e = 0.0;
+        for (int r = blockIdx.x; r < err_count; r += gridDim.x) e += err_rows[r];
+        partials[(size_t)blockIdx.x * ICP_NMOM + ICP_MOM_ERR] = e;
+    }
     // completion tag for a host that polls the (pinned, mapped) rows instead of synchronising the
     // stream: the row's data is released to system scope before the tag becomes visible
     static_assert(MOM_BLOCK == 64, "the tag protocol assumes one wave per block");
@@ -912,7 +928,10 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
 #define ICP_LAUNCH_NN2(TT, CC, CU)                                                                                  \
     hipLaunchKernelGGL((nn_match_f32_v2<TT, CC, CU>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,        \
                        (const float*)Qscan, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse)
-    const bool cull = pl.cull && Qscan != Q;
+    // measured (profiles/r1/03_nn_sweep_cull.txt): without a seed the early-out variant loses to the plain
+    // packed kernel on every cloud (its bound starts at +inf), with one it wins on every cloud
+    const bool cull = pl.cull && Qscan != Q && fuse.seed_idx != nullptr;
+    if (!cull) { Qscan = Q; fuse.seed_idx = nullptr; }
     if (pl.pts_per_thread == 4) {
         if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8, false); else ICP_LAUNCH_NN2(4, 16, false);
     } else if (cull) {
@@ -951,7 +970,7 @@ hipError_t launch_merge(const NNPlan& pl, const void* part_d, const int32_t* par
 
 hipError_t launch_moments(const NNPlan& pl, int metric, const void* P, const void* Q, const void* Nrm,
                           const void* part_d, const int32_t* part_idx, int32_t* idx, double* partials, int* blocks,
-                          double tag, hipStream_t st)
+                          double tag, const double* err_rows, int err_count, hipStream_t st)
 {
     int nb = (pl.n + MOM_BLOCK - 1) / MOM_BLOCK;
     if (nb > MOM_MAX_BLOCKS) nb = MOM_MAX_BLOCKS;
@@ -959,7 +978,7 @@ hipError_t launch_moments(const NNPlan& pl, int metric, const void* P, const voi
     if (nb <= 0) return hipSuccess;
 #define ICP_LAUNCH_MOM(F, MET)                                                                                     \
     hipLaunchKernelGGL((moments_kernel<F, MET>), dim3(nb), dim3(MOM_BLOCK), 0, st, (const F*)P, pl.n, pl.n_pad,      \
-                       (const F*)Q, pl.m, pl.m_pad, (const F*)Nrm, (const F*)part_d, part_idx, pl.splits, idx, partials, tag)
+                       (const F*)Q, pl.m, pl.m_pad, (const F*)Nrm, (const F*)part_d, part_idx, pl.splits, idx, partials, tag, err_rows, err_count)
     if (pl.precision == ICP_F64) {
         if (metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_MOM(double, ICP_POINT_TO_PLANE);
         else ICP_LAUNCH_MOM(double, ICP_POINT_TO_POINT);

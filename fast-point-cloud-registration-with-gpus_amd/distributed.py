@@ -1,0 +1,113 @@
+"""Multi-GPU driver of the ICP loop: one process per GPU, the MOVING cloud sharded into contiguous ranges
+(`icp_shard_range`), the model replicated, and exactly one collective per iteration -- an in-place SUM
+all-reduce of the ICP_NMOM-double moment vector (RCCL when the tensors live on MI355X, gloo in the CPU
+tests).  Every rank then solves the same 3x3 / 6x6 problem from bit-identical inputs, so R, t and the stop
+decision agree without a broadcast.  The reference has no multi-GPU path: this is new design.
+
+`run_sharded` is the device driver (used by bench.py for N > 1).  `HostLoop` + `drive` are the same loop over
+abstract shard operations; the CPU test-suite runs them with oracle-backed shards over gloo to check the
+partitioning, the vector layout and the stop logic by construction.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from .engine import shard_range
+
+
+class HostLoop:
+    """`icp_host_loop_*`: the host half of the loop (error series, stop rule, R/t solve, composed transform)."""
+
+    def __init__(self, metric=capi.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6, fixed_iterations=False, precision=capi.ICP_F32):
+        self._lib = capi.load()
+        self._max_iter = int(max_iter)
+        prm = capi.icp_params(int(max_iter), float(tol), 1 if fixed_iterations else 0, int(precision), int(metric))
+        h = C.c_void_p()
+        capi.check(self._lib.icp_host_loop_create(C.byref(prm), C.byref(h)), "icp_host_loop_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.icp_host_loop_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def advance(self, mom):
+        mom = np.ascontiguousarray(mom, dtype=np.float64)
+        assert mom.size == capi.ICP_NMOM
+        done = C.c_int(0)
+        R, t = np.zeros(9), np.zeros(3)
+        pd = C.POINTER(C.c_double)
+        capi.check(self._lib.icp_host_loop_advance(self._h, mom.ctypes.data_as(pd), C.byref(done), R.ctypes.data_as(pd),
+                                                   t.ctypes.data_as(pd)), "icp_host_loop_advance")
+        return bool(done.value), R.reshape(3, 3), t
+
+    def note_applied(self):
+        capi.check(self._lib.icp_host_loop_note_applied(self._h), "icp_host_loop_note_applied")
+
+    def state(self):
+        it, ps = C.c_int(0), C.c_int(0)
+        err = np.zeros(self._max_iter + 1)
+        T = np.zeros(16)
+        pd = C.POINTER(C.c_double)
+        capi.check(self._lib.icp_host_loop_state(self._h, C.byref(it), C.byref(ps), err.ctypes.data_as(pd), err.size,
+                                                 T.ctypes.data_as(pd)), "icp_host_loop_state")
+        return dict(iterations=it.value, passes=ps.value, err=err[: ps.value + 1].copy(), T=T.reshape(4, 4))
+
+
+def shard(P, rank, world):
+    """this rank's contiguous slice of the moving cloud"""
+    b, c = shard_range(len(P), rank, world)
+    return P[b:b + c], b
+
+
+def drive(shard_ops, host_loop, allreduce):
+    """The loop over abstract shard operations.
+    shard_ops.moments() -> local ICP_NMOM vector of the current pass (slot 0 = squared error of the motion
+    applied last); shard_ops.apply(R, t) moves the local shard.  allreduce(vec) sums in place over ranks."""
+    while True:
+        mom = np.ascontiguousarray(shard_ops.moments(), dtype=np.float64)
+        allreduce(mom)
+        done, R, t = host_loop.advance(mom)
+        if done:
+            return host_loop.state()
+        shard_ops.apply(R, t)
+        host_loop.note_applied()
+
+
+def run_sharded(ctx, P_shard, Q, dist, metric=capi.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6, fixed_iterations=False,
+                normals=None):
+    """Device driver.  `ctx` is this rank's Context, `dist` an initialised torch.distributed (backend nccl ==
+    RCCL).  The loop's 32-double vector lives in a torch tensor and the context runs on torch's current stream,
+    so the all-reduce is stream-ordered behind the finalize kernel; the host waits once per iteration."""
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    mom = torch.zeros(capi.ICP_NMOM, dtype=torch.float64, device=dev)
+    ctx.set_model(Q)
+    if metric == capi.ICP_POINT_TO_PLANE:
+        if normals is not None:
+            ctx.set_model_normals(normals)
+        else:
+            ctx.estimate_normals()
+    ctx.set_moving(P_shard)
+    torch.cuda.synchronize()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.loop_set_moments_dev(mom.data_ptr())
+    try:
+        ctx.loop_begin(metric, max_iter=max_iter, tol=tol, fixed_iterations=fixed_iterations)
+        while True:
+            ctx.loop_enqueue()
+            dist.all_reduce(mom)
+            if ctx.loop_complete():
+                break
+        st = ctx.loop_state()
+        st["idx"] = ctx.loop_indices()
+        st["moved"] = ctx.get_moving()
+        return st
+    finally:
+        ctx.loop_set_moments_dev(0)
+        ctx.set_stream(0)

@@ -167,6 +167,16 @@ int icp_solve_point_to_point(const double* mom /*ICP_NMOM*/, double* R9, double*
  * and LAPACKE_ssysv (CPU_ICP_point_to-plane.cpp:371); x = (alpha,beta,gamma,tx,ty,tz), then the
  * full (non-linearised) R = Rz(gamma) Ry(beta) Rx(alpha) (src/ICP_point_to_plane.cu:585-593). */
 int icp_solve_point_to_plane(const double* mom /*ICP_NMOM*/, double* R9, double* t3, double* x6);
+/* The host half of the loops above as a device-free state machine (the device loop runs this very
+ * code): feed it the rank-reduced ICP_NMOM vector of each pass, it returns the stop decision and the
+ * next R, t; tell it when that motion has been applied.  Sequence per pass:
+ *   advance(mom_k) -> [done?] -> apply R,t to the shard -> note_applied() -> (next pass' moments) ... */
+typedef struct icp_host_loop icp_host_loop;
+int icp_host_loop_create(const icp_params* prm, icp_host_loop** out);
+void icp_host_loop_destroy(icp_host_loop* h);
+int icp_host_loop_advance(icp_host_loop* h, const double* mom /*ICP_NMOM*/, int* done, double* R9, double* t3);
+int icp_host_loop_note_applied(icp_host_loop* h);
+int icp_host_loop_state(icp_host_loop* h, int* iterations, int* passes, double* err, int err_cap, double* T16);
 /* contiguous shard [begin, begin+count) of n moving points for `rank` of `world` */
 int icp_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t* count);
 /* symmetric 3x3 eigen-solve used for the normals (upper triangle of row-major A read);

@@ -1,0 +1,135 @@
+"""CPU, world_size 2 over gloo: the multi-GPU path by construction.  The shard arithmetic on each rank is done
+by the oracle (there is no GPU here); what is under test is the product's partitioning (icp_shard_range), the
+moment-vector layout, the single all-reduce per iteration and the host loop (icp_host_loop_* -- the code the
+device loop runs), which must give every rank the same R, t, stop decision and composed transform as one rank
+holding the whole cloud."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleShard:
+    """oracle-backed shard operations in the product's precision design: fp32 matching/transform arithmetic,
+    fp64 moments"""
+
+    def __init__(self, orc, P_shard, Q):
+        self.orc, self.P, self.Q = orc, np.array(P_shard, dtype=np.float32), np.asarray(Q, dtype=np.float32)
+        self.prev_idx = None
+
+    def moments(self):
+        mom = np.zeros(32)
+        P64, Q64 = self.P.astype(np.float64), self.Q.astype(np.float64)
+        if self.prev_idx is not None:                      # error of the motion applied last, old matches
+            mom[0] = ((Q64[self.prev_idx] - P64) ** 2).sum()
+        if len(self.P):
+            idx = self.orc.nn(self.P, self.Q)
+            Qi = Q64[idx]
+            mom[1] = len(self.P)
+            mom[2:5] = P64.sum(0)
+            mom[5:8] = Qi.sum(0)
+            mom[8:17] = (Qi.T @ P64).reshape(9)
+            mom[17] = (P64 * P64).sum()
+            mom[18] = (Qi * Qi).sum()
+            self.prev_idx = idx
+        return mom
+
+    def apply(self, R, t):
+        if len(self.P):
+            self.P = self.orc.transform(self.P, R.astype(np.float32), t.astype(np.float32))
+
+
+def _worker(rank, world, port, n_pts, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import oracle_lib
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    orc = oracle_lib.Oracle()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W = int(round(n_pts ** 0.5))
+    D = pkg.datasets.synthetic_grid(W, np.float32)[:n_pts]
+    M = pkg.datasets.make_model_gpu(pkg.datasets.synthetic_grid(W, np.float32), *pkg.datasets.P2P_GPU)
+    Ps, begin = pkg.distributed.shard(D, rank, world)
+
+    def allreduce(vec):
+        tvec = torch.from_numpy(vec)
+        dist.all_reduce(tvec)              # in place, SUM: the one collective of an iteration
+
+    ops = OracleShard(orc, Ps, M)
+    hl = pkg.distributed.HostLoop(pkg.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6, precision=pkg.ICP_F32)
+    st = pkg.distributed.drive(ops, hl, allreduce)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), T=st["T"], err=st["err"], iterations=st["iterations"], begin=begin,
+             moved=ops.P, idx=ops.prev_idx if ops.prev_idx is not None else np.zeros(0, np.int32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pts", [32 * 32, 31 * 31 - 5])   # even split and a ragged one
+def test_two_ranks_equal_one_rank(tmp_path, pkg, orc, n_pts):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, n_pts, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # every rank reaches the same decision and the same transform, bit for bit
+    assert int(r0["iterations"]) == int(r1["iterations"])
+    assert np.array_equal(r0["T"], r1["T"]) and np.array_equal(r0["err"], r1["err"])
+    assert int(r0["begin"]) == 0 and int(r1["begin"]) == len(r0["moved"])
+
+    # one rank holding the whole cloud: same driver, no communication
+    W = int(round(n_pts ** 0.5))
+    D = pkg.datasets.synthetic_grid(W, np.float32)[:n_pts]
+    M = pkg.datasets.make_model_gpu(pkg.datasets.synthetic_grid(W, np.float32), *pkg.datasets.P2P_GPU)
+    ops = OracleShard(orc, D, M)
+    hl = pkg.distributed.HostLoop(pkg.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6, precision=pkg.ICP_F32)
+    one = pkg.distributed.drive(ops, hl, lambda v: None)
+    assert one["iterations"] == int(r0["iterations"])
+    assert np.abs(one["T"] - r0["T"]).max() < 1e-9 and np.abs(one["err"] - r0["err"]).max() < 1e-9
+    assert np.array_equal(np.concatenate([r0["idx"], r1["idx"]]), ops.prev_idx)   # global idx = concatenation
+
+    # and the oracle's own loop (fp32 matching, fp64 minimisation) agrees
+    want = orc.icp_p2p_f32x(D, M, 40, 1e-6)
+    assert want["iterations"] == one["iterations"]
+    assert np.abs(want["T"] - one["T"]).max() < 1e-9
+    assert np.abs(want["err"] - one["err"]).max() < 1e-9
+
+
+def test_host_loop_stop_rule_and_limits(pkg):
+    """the reference's exit conditions (src/ICP_CPU.c:267-269) on synthetic moment vectors"""
+    HL = pkg.distributed.HostLoop
+
+    def mom(err_sumsq, n=100.0):
+        v = np.zeros(32)
+        v[0], v[1] = err_sumsq, n
+        v[8], v[12], v[16] = 1.0, 1.0, 1.0     # cross-covariance = identity -> R = I
+        return v
+
+    hl = HL(max_iter=5, tol=1e-3)
+    done, R, t = hl.advance(mom(0.0))
+    assert not done and np.allclose(R, np.eye(3))
+    hl.note_applied()
+    done, _, _ = hl.advance(mom(100.0 * 0.5 ** 2))          # E[1] = 0.5
+    assert not done
+    hl.note_applied()
+    done, _, _ = hl.advance(mom(100.0 * 0.4995 ** 2))       # |dE| = 5e-4 < tol -> stop, counter not incremented
+    st = hl.state()
+    assert done and st["iterations"] == 1 and st["passes"] == 2 and abs(st["err"][2] - 0.4995) < 1e-12
+
+    hl = HL(max_iter=3, tol=0.0, fixed_iterations=True)      # runs exactly max_iter passes
+    k = 0
+    done, _, _ = hl.advance(mom(0.0))
+    while not done:
+        hl.note_applied()
+        k += 1
+        done, _, _ = hl.advance(mom(1.0))
+    assert k == 3 and hl.state()["iterations"] == 3
+    with pytest.raises(pkg.IcpError):
+        HL(max_iter=0)
