@@ -286,7 +286,8 @@ __device__ __forceinline__ void apply_rt(const RT<F>& rt, F x, F y, F z, F& ox, 
 // optional fused front end of the matching kernel: the transform of the PREVIOUS pass
 struct NNFuse {
     int apply;               // 0: match P as it is
-    int n;                   // real moving points (the error skips the padding)
+    int n;                   // real moving points (the error and the seeds skip the padding)
+    int m;                   // real model points (seed validation)
     const int32_t* idx_prev; // correspondences the applied (R, t) came from
     float* P_out;            // transformed cloud (written by the grid.y == 0 blocks only)
     double* err_rows;        // [gridDim.x] sum |p_new - q[idx_prev]|^2 per block
@@ -366,11 +367,16 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
             for (int t = 0; t < T; ++t) {
                 const int u = t >> 1;
                 const float x = (t & 1) ? px[u].y : px[u].x, y = (t & 1) ? py[u].y : py[u].x, z = (t & 1) ? pz[u].y : pz[u].x;
-                const int j = fuse.seed_idx[ibase + t * 64];
+                // padding lanes (i >= n) have no previous match, and a seed is trusted only if it is a
+                // real model index: anything else simply starts unbounded
+                const int i = ibase + t * 64;
+                int j = (i < fuse.n) ? fuse.seed_idx[i] : -1;
+                const bool ok = (unsigned)j < (unsigned)fuse.m;
+                j = ok ? j : 0;
                 const float* Qg = fuse.Q_gather;
                 const float d = dist2<float>(x, y, z, Qg[j], Qg[(size_t)m_pad + j], Qg[2 * (size_t)m_pad + j]);
                 // next float above d (d >= 0, finite): bit pattern + 1; inf stays inf
-                best[t] = (d < inf_<float>()) ? __uint_as_float(__float_as_uint(d) + 1u) : d;
+                best[t] = (ok && d < inf_<float>()) ? __uint_as_float(__float_as_uint(d) + 1u) : inf_<float>();
             }
         }
     }
@@ -735,9 +741,11 @@ __global__ __launch_bounds__(NN_BLOCK) void knn4_kernel(const F* __restrict__ Q,
                 // insert keeping (d, j) ascending; equal d keeps the earlier (lower) j first
                 F cd = d;
                 int cj = j;
+                bool shifting = false;  // once the new entry is placed, everything below moves down one slot
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
-                    const bool sw = cd < bd[r];
+                    const bool sw = shifting || (cd < bd[r]);
+                    shifting = sw;
                     const F td = bd[r];
                     const int tj = bj[r];
                     bd[r] = sw ? cd : td;
@@ -910,6 +918,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     dim3 grid(pl.blocks_x, pl.splits);
     RT<float> rt{};
     NNFuse fuse{};
+    fuse.n = pl.n;
+    fuse.m = pl.m;
     fuse.Q_gather = (const float*)Q;
     const void* Qscan = Q;
     if (pl.cull && opt && opt->Q_scan) {
