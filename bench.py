@@ -6,7 +6,7 @@
 Workload (BASELINE.json `metric`, configs[2]): point-to-point ICP on the hall LiDAR scan, 16 384 moving x
 16 384 model points, fp32, clouds resident in HBM.  A *step* is one full ICP iteration of the loop in
 libicp_mi355x.so: [transform + error of the previous pass] -> brute-force matching -> fused
-gather/moments -> finalize -> 256-byte D2H -> host 3x3 SVD.  The tolerance test is disabled
+gather/moments (rows into pinned host memory) -> host: tag poll, fixed-order row sum, 3x3 SVD.  The tolerance test is disabled
 (fixed-iteration mode, like src/ICP_standard.cu) so that exactly K steps run.
 
 N > 1 (weak scaling): every rank holds a hall-sized shard of the moving cloud (the global moving cloud is
@@ -140,6 +140,17 @@ def main():
         alg_bytes = 12.0 * n + 12.0 * m + 4.0 * n            # read P, read Q, write idx (fp32)
         # back-to-back launches of the same kernel, no other work between (cross-check, not the headline)
         b2b_ms = ctx.nn_match_bench(50) / 50.0
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r1", "04_pmc_hbm_traffic.json")
+        if world == 1 and os.path.exists(pmc):
+            # HBM bytes per launch of the seeded matching kernel from the committed rocprofv3 PMC passes of THIS
+            # command (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units, FETCH doubled: gfx950 correction)
+            rec = json.load(open(pmc)).get("void icp::nn_match_f32_v2<2, 8, true>")
+            if rec:
+                traffic = rec["hbm_bytes_corrected"]
+                traffic_src = ("profiles/r1/04_pmc_hbm_traffic.json: FETCH_SIZE %.0f B raw (x2 corrected) + WRITE_SIZE %.0f B; "
+                               "the excess over the algorithmic bytes is the per-segment (d, idx) partials" %
+                               (rec["fetch_bytes_raw"], rec["write_bytes"]))
         out = {
             "metric": "ICP iterations/sec + NN HBM GB/s (% roofline), hall cloud",
             "value": world * K / t_max,
@@ -156,12 +167,13 @@ def main():
                        "model_points": m, "global_moving_points": n * world, "fixed_iterations": True,
                        "collective": "1 all-reduce of 32 doubles per iteration" if world > 1 else "none"},
             "roofline": {
-                "kernel": "nn_match_kernel<float>", "bound": "valu",
+                "kernel": "nn_match_f32_v2<2,8,true> (packed fp32, seeded early-out; transform of the previous pass fused in)",
+                "bound": "valu",
                 "bound_note": "brute-force NN is 4681 flop/B on this cloud (ridge ~20): VALU-bound, not HBM-bound; "
                               "fp32 vector peak == fp32 MFMA peak on gfx950. Exact (non-FMA) arithmetic caps frac at 0.5.",
                 "achieved": flops / nn_avg_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / nn_avg_s / 1e12 / FP32_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": flops, "avg_launch_us": 1e6 * nn_avg_s, "launches_timed": nn_launches,
                 "back_to_back_us": 1e3 * b2b_ms, "pairs_per_s": n * m / nn_avg_s,
                 "launch": info,
