@@ -90,6 +90,7 @@ SIGNATURES = {
     "icp_read_os1_ranges": (_i, [C.c_char_p, _vp, _i, _pu32]),
     "icp_read_os1_intrinsics": (_i, [C.c_char_p, _pf, _pf]),
     "icp_os1_to_cartesian": (_i, [_vp, _vp, _i, C.c_uint32, _pf, _pf, _vp]),
+    "icp_os1_packets_to_cartesian": (_i, [_vp, _vp, _i, _pf, _pf, _vp, _vp]),
 }
 
 _lib = None

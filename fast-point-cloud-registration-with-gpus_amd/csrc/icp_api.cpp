@@ -780,6 +780,34 @@ int icp_point_to_plane(icp_ctx* c, const void* data, int n, const void* model, i
     return run_loop(c, &p, out);
 }
 
+int icp_os1_packets_to_cartesian(icp_ctx* c, const uint8_t* packets, int n_packets, const float alt16[16],
+                                 const float az16[16], float* xyz_out, uint32_t* ranges_out)
+{
+    if (int rc = use(c)) return rc;
+    if (n_packets < 0 || (n_packets > 0 && (!packets || !xyz_out)) || !alt16 || !az16) return fail(ICP_ERR_INVALID, "bad arguments");
+    if (n_packets == 0) return ICP_OK;
+    const size_t n = (size_t)n_packets * 256, bytes = (size_t)n_packets * 12608;
+    DevBuf d_pk, d_ang, d_r, d_xyz;
+    auto body = [&]() -> int {
+        HIP_TRY(d_pk.ensure(bytes));
+        HIP_TRY(d_ang.ensure(32 * sizeof(float)));
+        HIP_TRY(d_r.ensure(n * sizeof(uint32_t)));
+        HIP_TRY(d_xyz.ensure(3 * n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(d_pk.p, packets, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_ang.p, alt16, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync((float*)d_ang.p + 16, az16, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(icp::launch_os1_packets((const uint8_t*)d_pk.p, n_packets, (const float*)d_ang.p, (const float*)d_ang.p + 16,
+                                        (uint32_t*)d_r.p, (float*)d_xyz.p, c->stream));
+        HIP_TRY(hipMemcpyAsync(xyz_out, d_xyz.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (ranges_out) HIP_TRY(hipMemcpyAsync(ranges_out, d_r.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return ICP_OK;
+    };
+    const int rc = body();
+    d_pk.release(); d_ang.release(); d_r.release(); d_xyz.release();
+    return rc;
+}
+
 int icp_os1_to_cartesian(icp_ctx* c, const uint32_t* ranges, int n, uint32_t encoder0, const float alt16[16],
                          const float az16[16], float* xyz_out)
 {

@@ -93,6 +93,8 @@ hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, v
 hipError_t launch_knn4(const NNPlan& pl, const void* Q_soa, int32_t* nbr /*[m][4]*/, hipStream_t st);
 hipError_t launch_normal_cov(int precision, const void* Q_soa, int m, int m_pad, const int32_t* nbr,
                              float* cov6 /*[m][6] upper triangle*/, hipStream_t st);
+hipError_t launch_os1_packets(const uint8_t* packets, int n_packets, const float* alt16, const float* az16,
+                              uint32_t* ranges, float* xyz_aos, hipStream_t st);
 hipError_t launch_os1_conversion(const uint32_t* ranges, int n, uint32_t encoder0, const float* alt16,
                                  const float* az16, float* xyz_aos, hipStream_t st);
 

@@ -813,6 +813,33 @@ __global__ void os1_conversion_kernel(const uint32_t* __restrict__ r, int n, uin
     xyz[3 * (size_t)i + 2] = rr * sp;
 }
 
+// raw OS1-16 packets (12 608 B each: 16 azimuth blocks x [16 B header | 64 channels x 12 B | 4 B status]) ->
+// ranges [mm] + Cartesian points [mm] in one pass; one lane per (packet, block, beam).  Replaces the host
+// parse loop + H2D + Conversion of src/CUDA/GPU_point_to_point_real.cu:457-487,538-563.  Byte-granular reads
+// (the 20-bit range sits at an arbitrary byte offset); 3 bytes per lane, ~0.8 MB for the hall dump.
+__global__ void os1_packets_kernel(const uint8_t* __restrict__ packets, int n_packets, const float* __restrict__ altitude,
+                                   const float* __restrict__ azimuth, uint32_t* __restrict__ ranges,
+                                   float* __restrict__ xyz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_packets * 256) return;
+    const int packet = i / 256, blk = (i / 16) % 16, beam = i % 16;
+    const int ch = 2 + 4 * beam;  // the 16 lasers of an OS1-16 sit in channels 2, 6, ..., 62
+    const size_t w = (size_t)packet * 12608 + (size_t)blk * 788 + 16 + 12 * (size_t)ch;
+    const uint32_t r = (uint32_t)packets[w] | ((uint32_t)packets[w + 1] << 8) | (((uint32_t)packets[w + 2] & 0xFu) << 16);
+    const uint32_t encoder0 = (uint32_t)packets[12] | ((uint32_t)packets[13] << 8);  // first block of the first packet
+    ranges[i] = r;
+    const int azimuth_block = i / 16;
+    const unsigned long long counter = ((unsigned long long)encoder0 + (unsigned long long)azimuth_block * 88ull) % 90112ull;
+    const float theta = (float)(2.0 * M_PI * ((double)counter / 90112.0 + (double)azimuth[beam] / 360.0));
+    const float phi = (float)(2.0 * M_PI * (double)altitude[beam] / 360.0);
+    const float rr = (float)r;
+    const float ct = cosf(theta), st = sinf(theta), cp = cosf(phi), sp = sinf(phi);
+    xyz[3 * (size_t)i + 0] = rr * ct * cp;
+    xyz[3 * (size_t)i + 1] = -rr * st * cp;
+    xyz[3 * (size_t)i + 2] = rr * sp;
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch geometry + launchers
 // ------------------------------------------------------------------------------------------------
@@ -1082,6 +1109,16 @@ hipError_t launch_normal_cov(int precision, const void* Q, int m, int m_pad, con
     else
         hipLaunchKernelGGL((normal_cov_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)Q, m, m_pad, nbr,
                            cov6);
+    return hipGetLastError();
+}
+
+hipError_t launch_os1_packets(const uint8_t* packets, int n_packets, const float* alt16, const float* az16,
+                              uint32_t* ranges, float* xyz_aos, hipStream_t st)
+{
+    if (n_packets <= 0) return hipSuccess;
+    const int n = n_packets * 256;
+    hipLaunchKernelGGL(os1_packets_kernel, dim3((n + 255) / 256), dim3(256), 0, st, packets, n_packets, alt16, az16, ranges,
+                       xyz_aos);
     return hipGetLastError();
 }
 

@@ -29,7 +29,32 @@ int main(int argc, char** argv)
     icp_result res{};
     res.err = err.data();
     ICP_CHECK(icp_set_profiling(ctx, 1));
-    ICP_CHECK(icp_point_to_point(ctx, D.data(), n, M.data(), n, &prm, &res));
+    if (a.trace.empty()) {
+        ICP_CHECK(icp_point_to_point(ctx, D.data(), n, M.data(), n, &prm, &res));
+    } else {
+        // step-wise so that the cloud of every iteration can be captured (pt_total of src/ICP_CPU.c:197-201,254)
+        std::vector<std::vector<float>> pt_total;
+        ICP_CHECK(icp_set_moving(ctx, D.data(), n, ICP_F32));
+        ICP_CHECK(icp_loop_begin(ctx, &prm));
+        const auto l0 = std::chrono::steady_clock::now();
+        int done = 0, passes = 0, seen = 0;
+        while (!done) {
+            ICP_CHECK(icp_loop_enqueue(ctx));
+            ICP_CHECK(icp_loop_complete(ctx, &done));
+            ICP_CHECK(icp_loop_state(ctx, &res.iterations, &passes, err.data(), (int)err.size(), res.T));
+            if (passes > seen) {
+                pt_total.emplace_back(3 * (size_t)n);
+                ICP_CHECK(icp_get_moving(ctx, pt_total.back().data()));
+                seen = passes;
+            }
+        }
+        res.passes = passes;
+        res.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - l0).count();
+        double nn_s = 0.0;
+        ICP_CHECK(icp_loop_timing(ctx, &nn_s, nullptr));
+        res.seconds_nn = nn_s;
+        if (!write_trace(a.trace, D, M, pt_total, err.data(), n)) { std::perror("trace file"); return -1; }
+    }
 
     std::printf("Error:\n");
     print_sarray(err.data(), res.iterations + 1);

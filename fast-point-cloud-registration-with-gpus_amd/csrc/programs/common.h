@@ -32,6 +32,7 @@ struct Args {
     int max_iter = 0;
     bool f64 = false;
     bool dump_T = false;
+    std::string trace;  // --trace file: per-iteration clouds in the layout of print_all (src/ICP_CPU.c:409-448)
 };
 
 inline bool parse_args(int argc, char** argv, Args& a, const char* prog)
@@ -44,10 +45,11 @@ inline bool parse_args(int argc, char** argv, Args& a, const char* prog)
         else if (s == "--max-iter" && i + 1 < argc) a.max_iter = std::atoi(argv[++i]);
         else if (s == "--f64") a.f64 = true;
         else if (s == "--transform") a.dump_T = true;
+        else if (s == "--trace" && i + 1 < argc) a.trace = argv[++i];
         else {
             std::fprintf(stderr,
                          "usage: %s [--width W] [--bunny file.csv] [--hall packets.csv beam_intrinsics.csv]\n"
-                         "          [--max-iter K] [--transform]\n"
+                         "          [--max-iter K] [--transform] [--trace file]\n"
                          "  no arguments = the reference program's built-in synthetic input\n", prog);
             return false;
         }
@@ -59,6 +61,31 @@ inline void print_transform(const double* T)
 {
     std::printf("Transform (row-major 4x4, moving -> model):\n");
     for (int r = 0; r < 4; ++r) std::printf("% .9f % .9f % .9f % .9f\n", T[4 * r], T[4 * r + 1], T[4 * r + 2], T[4 * r + 3]);
+}
+
+// print_all of the reference (src/ICP_CPU.c:409-448, never called there): one row per point, '|'-separated,
+// data | model | the transformed data cloud after every iteration, then the error series.  Clouds are AoS here.
+inline bool write_trace(const std::string& path, const std::vector<float>& D, const std::vector<float>& M,
+                        const std::vector<std::vector<float>>& pt_total, const double* E, int num_points)
+{
+    FILE* document = std::fopen(path.c_str(), "w");
+    if (!document) return false;
+    const int num_iterations = (int)pt_total.size();
+    std::fprintf(document, "x_data|y_data|z_data|x_model|y_model|z_model");
+    for (int i = 0; i < num_iterations; i++) std::fprintf(document, "|TDx_%d|TDy_%d|TDz_%d", i + 1, i + 1, i + 1);
+    std::fprintf(document, "\n");
+    for (int i = 0; i < num_points; i++) {
+        for (int k = 0; k < 3; k++) std::fprintf(document, "%- 7.3f| ", D[3 * (size_t)i + k]);
+        for (int k = 0; k < 3; k++) std::fprintf(document, "%- 7.3f| ", M[3 * (size_t)i + k]);
+        for (int j = 0; j < num_iterations; j++)
+            for (int k = 0; k < 3; k++) std::fprintf(document, "%- 7.3f| ", pt_total[j][3 * (size_t)i + k]);
+        std::fprintf(document, "\n");
+    }
+    std::fprintf(document, "\nError|");
+    for (int i = 0; i < num_iterations; i++) std::fprintf(document, "%.3f|", E[i]);
+    std::fprintf(document, "\n");
+    std::fclose(document);
+    return true;
 }
 
 // Build the (data, model) pair the way the reference programs do for each input kind (fp32 AoS).

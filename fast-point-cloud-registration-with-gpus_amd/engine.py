@@ -228,6 +228,21 @@ class Context:
         return out
 
 
+    def os1_packets_to_cartesian(self, packets, altitude16, azimuth16):
+        """raw packet bytes (uint8, n_packets * 12608) -> (xyz [mm] (N,3) float32, ranges (N,) uint32), decoded on the device"""
+        pk = np.ascontiguousarray(packets, dtype=np.uint8).reshape(-1)
+        assert pk.size % 12608 == 0
+        npk = pk.size // 12608
+        alt = np.ascontiguousarray(altitude16, dtype=np.float32)
+        az = np.ascontiguousarray(azimuth16, dtype=np.float32)
+        xyz = np.empty((npk * 256, 3), dtype=np.float32)
+        rng = np.empty(npk * 256, dtype=np.uint32)
+        pf = C.POINTER(C.c_float)
+        capi.check(self._lib.icp_os1_packets_to_cartesian(self._h, pk.ctypes.data, npk, alt.ctypes.data_as(pf), az.ctypes.data_as(pf),
+                                                          xyz.ctypes.data, rng.ctypes.data), "icp_os1_packets_to_cartesian")
+        return xyz, rng
+
+
 # ---- host-only helpers (no device) -------------------------------------------------------------
 def solve_point_to_point(mom):
     lib = capi.load()

@@ -210,6 +210,12 @@ int icp_read_os1_intrinsics(const char* path, float altitude16[16], float azimut
 int icp_os1_to_cartesian(icp_ctx* ctx, const uint32_t* ranges, int n, uint32_t encoder_count0,
                          const float altitude16[16], const float azimuth16[16], float* xyz_aos_mm);
 
+/* raw OS1-16 packets (n_packets x 12608 bytes, as captured from the sensor) -> ranges + Cartesian points in one
+ * device pass: replaces the host parse loop + H2D + Conversion<<<>>> of
+ * src/CUDA/GPU_point_to_point_real.cu:457-487,538-563.  256 points per packet; ranges_out may be NULL. */
+int icp_os1_packets_to_cartesian(icp_ctx* ctx, const uint8_t* packets, int n_packets, const float altitude16[16],
+                                 const float azimuth16[16], float* xyz_aos_mm, uint32_t* ranges_out);
+
 #ifdef __cplusplus
 }
 #endif

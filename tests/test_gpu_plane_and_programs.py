@@ -200,3 +200,58 @@ def test_icp_point_to_plane_program(pkg):
     assert "ICP converged successfully!" in r.stdout
     T = _transform(r.stdout)
     assert np.abs(T[:3, 3] - np.array([0.8, -0.3, 0.2])).max() < 0.05          # the motion baked into the model
+
+
+# ---------------------------------------------------------------------------------------------------
+# hall packets decoded on the device, the sweep program, the per-iteration trace dump
+# ---------------------------------------------------------------------------------------------------
+def _hall_packets(golden):
+    ranges = np.fromfile(os.path.join(golden, "hall_ranges_u32.bin"), dtype=np.uint32)
+    enc = json.load(open(os.path.join(golden, "hall_meta.json")))["encoder_count0"]
+    pk = np.zeros(64 * 12608, dtype=np.uint8)
+    pk[12], pk[13] = enc & 0xFF, (enc >> 8) & 0xFF
+    idx = np.arange(ranges.size)
+    w = (idx // 256) * 12608 + ((idx // 16) % 16) * 788 + 16 + 12 * (2 + 4 * (idx % 16))
+    pk[w], pk[w + 1], pk[w + 2] = ranges & 0xFF, (ranges >> 8) & 0xFF, (ranges >> 16) & 0x0F
+    return pk, ranges, enc
+
+
+def test_os1_packets_decoded_on_device(ctx, pkg, orc, golden):
+    pk, ranges, enc = _hall_packets(golden)
+    alt, az = pkg.datasets.read_os1_intrinsics(os.path.join(golden, "beam_intrinsics.csv"))
+    xyz, rng = ctx.os1_packets_to_cartesian(pk, alt, az)
+    assert np.array_equal(rng, ranges)                                   # 20-bit ranges, bit-exact
+    assert np.array_equal(xyz, ctx.os1_to_cartesian(ranges, enc, alt, az))   # same arithmetic as the two-step path
+    want = orc.os1_conversion(ranges.astype(np.float32), enc, alt, az)   # the reference's Conversion, restated
+    assert np.abs(xyz - want).max() < 2e-5 * np.abs(want).max()
+    # the first two packets of the real dump, as text -> bytes
+    vals = np.array([int(x) for x in open(os.path.join(golden, "os1_two_packets.csv")).read().split()], dtype=np.uint8)
+    xyz2, rng2 = ctx.os1_packets_to_cartesian(vals, alt, az)
+    assert np.array_equal(rng2, ranges[:512]) and np.array_equal(xyz2, xyz[:512])
+
+
+def test_time_complexity_program(tmp_path):
+    for flags, name, header in (([], "p2p.csv", "NUM_POINTS,TIME"), (["--plane"], "plane.csv", "NUM_POINTS,TIME"),
+                                (["--matching"], "match.csv", "#POINTS,TIME")):
+        out = tmp_path / name
+        r = subprocess.run([os.path.join(BIN, "ICP_time_complexity"), "--max-width", "12", "--out", str(out)] + flags,
+                           capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stderr
+        lines = open(out).read().split()
+        assert lines[0] == header
+        rows = [ln.split(",") for ln in lines[1:]]
+        assert [int(a) for a, _ in rows][-1] == 144 and all(float(b) > 0 for _, b in rows)
+        assert len(rows) >= 9
+
+
+def test_trace_dump_layout(tmp_path):
+    out = tmp_path / "Test_icp"
+    r = subprocess.run([os.path.join(BIN, "ICP_point_to_point"), "--width", "8", "--trace", str(out)], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = open(out).read().splitlines()
+    head = lines[0].split("|")
+    assert head[:6] == ["x_data", "y_data", "z_data", "x_model", "y_model", "z_model"] and head[6] == "TDx_1"   # src/ICP_CPU.c:416-417
+    n_it = (len(head) - 6) // 3
+    assert n_it >= 2 and len(lines[1].split("|")) == 6 + 3 * n_it + 1
+    assert lines[1 + 64] == "" and lines[2 + 64].startswith("Error|")
