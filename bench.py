@@ -78,8 +78,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     dist = None
-    if world > 1:
+    # ICP_BENCH_FORCE_DIST=1 drives the multi-GPU code path (RCCL all-reduce, torch stream, device finalize)
+    # with a single rank, so that it can be rehearsed on a one-GPU box
+    use_dist = world > 1 or os.environ.get("ICP_BENCH_FORCE_DIST") == "1"
+    saved_stdout = None
+    if use_dist:
+        # RCCL prints a version banner on STDOUT when its first communicator is created; the contract is ONE JSON
+        # line on stdout, so fd 1 points at stderr until the result is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
@@ -93,22 +103,28 @@ def main():
     ctx.set_model(Q)
     ctx.set_moving(P)
     mom = None
-    if world > 1:
-        # the loop writes its moment vector straight into a torch tensor and runs on torch's stream, so
-        # the RCCL all-reduce is ordered behind the finalize kernel without any host synchronisation
+    stream_ctx = None
+    if use_dist:
+        # The loop writes its moment vector straight into a torch tensor and runs on a torch-owned (non-default)
+        # stream that is also torch's CURRENT stream while the loop runs, so the RCCL all-reduce is ordered behind
+        # the finalize kernel, and the D2H behind the all-reduce, without any host synchronisation in between.
+        torch.cuda.set_device(local_rank)
         mom = torch.zeros(pkg.ICP_NMOM, dtype=torch.float64, device=f"cuda:{local_rank}")
         torch.cuda.synchronize()
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        side = torch.cuda.Stream(device=local_rank)
+        stream_ctx = torch.cuda.stream(side)
+        stream_ctx.__enter__()
+        ctx.set_stream(side.cuda_stream)
         ctx.loop_set_moments_dev(mom.data_ptr())
 
     def step():
         ctx.loop_enqueue()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(mom)
         return ctx.loop_complete()
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -127,11 +143,15 @@ def main():
     st = ctx.loop_state()
 
     t_max = dt
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_max = float(tt.item())
 
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         info = ctx.nn_launch_info()
         nn_launches = max(1, cnt1 - cnt0)
@@ -165,7 +185,7 @@ def main():
                     "Donut_1024x16.csv; polar->Cartesian by the device kernel)",
             "config": {"workload": "hall LiDAR scan point-to-point ICP (BASELINE configs[2])", "moving_points_per_gpu": n,
                        "model_points": m, "global_moving_points": n * world, "fixed_iterations": True,
-                       "collective": "1 all-reduce of 32 doubles per iteration" if world > 1 else "none"},
+                       "collective": "1 all-reduce of 32 doubles per iteration" if use_dist else "none"},
             "roofline": {
                 "kernel": "nn_match_f32_v2<2,8,true> (packed fp32, seeded early-out; transform of the previous pass fused in)",
                 "bound": "valu",
@@ -185,8 +205,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, Q)
         print(json.dumps(out), flush=True)
+    if stream_ctx is not None:
+        ctx.loop_set_moments_dev(0)
+        ctx.set_stream(0)
+        stream_ctx.__exit__(None, None, None)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -101,7 +101,7 @@ struct icp_ctx {
     DevBuf part_d, part_idx, idx[2];
     int cur = 0;  // idx buffer written by the most recent matching pass
     bool idx_valid = false;  // idx[cur] holds matches of the resident clouds
-    DevBuf mom_partials, err_partials, mom_own, nbr, cov;
+    DevBuf mom_partials, err_partials, mom_own, nbr;
     double* mom_dev = nullptr;
     double* h_mom = nullptr;  // pinned: the reduced ICP_NMOM vector as the host solve reads it
     // single-GPU fast path: the moments / transform kernels store their per-block partial rows straight
@@ -305,7 +305,7 @@ void icp_destroy(icp_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->P, &c->P2, &c->Q, &c->Qs, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
-                      &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->cov};
+                      &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
     if (c->h_mom_partials) (void)hipHostFree(c->h_mom_partials);
@@ -501,33 +501,21 @@ int icp_estimate_normals(icp_ctx* c, void* nxyz_out, int32_t* nbr_out)
     if (m < 5) return fail(ICP_ERR_INVALID, "normals need at least 5 model points (k = 4 neighbours + self)");
     icp::NNPlan pl = icp::nn_plan(m, m, c->prec, c->num_cus);
     HIP_TRY(c->nbr.ensure((size_t)m * 4 * sizeof(int32_t)));
-    HIP_TRY(c->cov.ensure((size_t)m * 6 * sizeof(float)));
+    const size_t es = icp::elem_size(c->prec);
+    HIP_TRY(c->Nrm.ensure(3 * (size_t)pl.m_pad * es));
     HIP_TRY(icp::launch_knn4(pl, c->Q.p, (int32_t*)c->nbr.p, c->stream));
-    HIP_TRY(icp::launch_normal_cov(c->prec, c->Q.p, m, pl.m_pad, (const int32_t*)c->nbr.p, (float*)c->cov.p, c->stream));
-    std::vector<float> cov((size_t)m * 6);
-    HIP_TRY(hipMemcpyAsync(cov.data(), c->cov.p, cov.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    // covariance + eigen-solve on the device, straight into the resident (padded SoA) normal cloud
+    HIP_TRY(icp::launch_normals(c->prec, c->Q.p, m, pl.m_pad, (const int32_t*)c->nbr.p, c->Nrm.p, c->stream));
+    if (nxyz_out) {
+        HIP_TRY(c->stage.ensure(3 * (size_t)m * es));
+        HIP_TRY(icp::launch_soa_to_aos(c->prec, c->Nrm.p, m, pl.m_pad, c->stage.p, c->stream));
+        HIP_TRY(hipMemcpyAsync(nxyz_out, c->stage.p, 3 * (size_t)m * es, hipMemcpyDeviceToHost, c->stream));
+    }
     if (nbr_out)
         HIP_TRY(hipMemcpyAsync(nbr_out, c->nbr.p, (size_t)m * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    // eigenvector of the eigenvalue of smallest magnitude (cblas_isamin over ssyev's ascending w,
-    // src/ICP_point_to_plane.cu:435-437); fp64 Jacobi on the fp32 covariance
-    const size_t es = icp::elem_size(c->prec);
-    std::vector<unsigned char> nrm(3 * (size_t)m * es);
-    for (int i = 0; i < m; ++i) {
-        const float* a = &cov[(size_t)i * 6];
-        const double A[9] = {a[0], a[1], a[2], 0, a[3], a[4], 0, 0, a[5]};
-        double w[3], Z[9];
-        icp::eigh3(A, w, Z);
-        int k = 0;
-        for (int e = 1; e < 3; ++e)
-            if (std::fabs((float)w[e]) < std::fabs((float)w[k])) k = e;
-        for (int j = 0; j < 3; ++j) {
-            if (c->prec == ICP_F64) ((double*)nrm.data())[3 * (size_t)i + j] = Z[j * 3 + k];
-            else ((float*)nrm.data())[3 * (size_t)i + j] = (float)Z[j * 3 + k];
-        }
-    }
-    if (nxyz_out) std::memcpy(nxyz_out, nrm.data(), nrm.size());
-    return icp_set_model_normals(c, nrm.data(), m);
+    c->have_normals = true;
+    return ICP_OK;
 }
 
 // ---- the loop ----------------------------------------------------------------------------------

@@ -89,10 +89,11 @@ hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_
 hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st);
 hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, void* aos, hipStream_t st);
 
-// model-on-model 4 nearest neighbours (self / rank 0 dropped) + covariance of the neighbours
+// model-on-model 4 nearest neighbours (self / rank 0 dropped)
 hipError_t launch_knn4(const NNPlan& pl, const void* Q_soa, int32_t* nbr /*[m][4]*/, hipStream_t st);
-hipError_t launch_normal_cov(int precision, const void* Q_soa, int m, int m_pad, const int32_t* nbr,
-                             float* cov6 /*[m][6] upper triangle*/, hipStream_t st);
+// covariance of the 4 neighbours + fp64 Jacobi eigen-solve per lane -> padded SoA normals on the device
+hipError_t launch_normals(int precision, const void* Q_soa, int m, int m_pad, const int32_t* nbr, void* Nrm_soa,
+                          hipStream_t st);
 hipError_t launch_os1_packets(const uint8_t* packets, int n_packets, const float* alt16, const float* az16,
                               uint32_t* ranges, float* xyz_aos, hipStream_t st);
 hipError_t launch_os1_conversion(const uint32_t* ranges, int n, uint32_t encoder0, const float* alt16,

@@ -8,7 +8,7 @@
 //                          src/CUDA/GPU_point_to_plane_real.cu:246-288,532-549
 //   transform_error_kernel RyT + Scopy + Scopy/Saxpy/Snrm2  src/ICP_point_to_point.cu:81-88,403-416
 //   finalize_kernel        (the reductions hidden inside cuBLAS)
-//   knn4_kernel/normal_cov knn + Normals  src/CUDA/GPU_point_to_plane_real.cu:54-128
+//   knn4_kernel/normals    knn + Normals + host ssyev loop  src/CUDA/GPU_point_to_plane_real.cu:54-188,413-423
 //   os1_conversion_kernel  Conversion     src/CUDA/GPU_point_to_point_real.cu:20-36
 //
 // Numerics contract of the matching kernels: the squared distance is evaluated exactly as the CPU
@@ -762,26 +762,30 @@ __global__ __launch_bounds__(NN_BLOCK) void knn4_kernel(const F* __restrict__ Q,
     }
 }
 
-// covariance (upper triangle, not divided by k) of the 4 neighbours, float arithmetic in the
-// order of src/CUDA/CPU_ICP_point_to-plane.cpp:217-246: bar = (sum) * 0.25f, A += (x-bar)(y-bar).
+// PCA normal of every model point from its 4 neighbours, entirely on the device: float covariance in the
+// order of src/CUDA/CPU_ICP_point_to-plane.cpp:217-246 (bar = sum * 0.25f, A += (x-bar)(y-bar), not divided by
+// k), then a cyclic-Jacobi eigen-solve in fp64 registers (stands in for the reference's HOST loop of
+// LAPACKE_ssyev, src/ICP_point_to_plane.cu:429-438) and the eigenvector of the eigenvalue of smallest magnitude
+// (cblas_isamin over the ascending eigenvalues, first on ties).  Writes the padded SoA normal cloud directly.
 template <typename F>
-__global__ void normal_cov_kernel(const F* __restrict__ Q, int m, int m_pad, const int32_t* __restrict__ nbr,
-                                  float* __restrict__ cov6)
+__global__ void normals_kernel(const F* __restrict__ Q, int m, int m_pad, const int32_t* __restrict__ nbr,
+                               F* __restrict__ Nrm)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+    if (i >= m_pad) return;
+    const int src = i < m ? i : m - 1;  // padding replicates the last point's normal (never referenced)
     float x[4], y[4], z[4];
     float bx = 0.f, by = 0.f, bz = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int s = nbr[(size_t)i * 4 + j];
+        const int s = nbr[(size_t)src * 4 + j];
         x[j] = (float)Q[s];
         y[j] = (float)Q[(size_t)m_pad + s];
         z[j] = (float)Q[2 * (size_t)m_pad + s];
         bx += x[j]; by += y[j]; bz += z[j];
     }
-    const float a = 1.0f / 4.0f;
-    bx *= a; by *= a; bz *= a;
+    const float qa = 1.0f / 4.0f;
+    bx *= qa; by *= qa; bz *= qa;
     float A[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -789,8 +793,69 @@ __global__ void normal_cov_kernel(const F* __restrict__ Q, int m, int m_pad, con
         A[0] += dx * dx; A[1] += dx * dy; A[2] += dx * dz;
         A[3] += dy * dy; A[4] += dy * dz; A[5] += dz * dz;
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) cov6[(size_t)i * 6 + k] = A[k];
+    // symmetric 3x3 in named scalars (no runtime-indexed arrays -> no scratch)
+    double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
+    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = a01 * a01 + a02 * a02 + a12 * a12;
+        const double dia = a00 * a00 + a11 * a11 + a22 * a22;
+        if (off <= 1e-34 * dia || off == 0.0) break;
+        // rotation (p,q) = (0,1): r = 2
+        if (a01 != 0.0) {
+            const double th = (a11 - a00) / (2.0 * a01);
+            const double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            a00 -= t * a01; a11 += t * a01; a01 = 0.0;
+            const double rp = a02, rq = a12;
+            a02 = c * rp - s * rq; a12 = s * rp + c * rq;
+            double p, q;
+            p = v00; q = v01; v00 = c * p - s * q; v01 = s * p + c * q;
+            p = v10; q = v11; v10 = c * p - s * q; v11 = s * p + c * q;
+            p = v20; q = v21; v20 = c * p - s * q; v21 = s * p + c * q;
+        }
+        // (0,2): r = 1
+        if (a02 != 0.0) {
+            const double th = (a22 - a00) / (2.0 * a02);
+            const double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            a00 -= t * a02; a22 += t * a02; a02 = 0.0;
+            const double rp = a01, rq = a12;
+            a01 = c * rp - s * rq; a12 = s * rp + c * rq;
+            double p, q;
+            p = v00; q = v02; v00 = c * p - s * q; v02 = s * p + c * q;
+            p = v10; q = v12; v10 = c * p - s * q; v12 = s * p + c * q;
+            p = v20; q = v22; v20 = c * p - s * q; v22 = s * p + c * q;
+        }
+        // (1,2): r = 0
+        if (a12 != 0.0) {
+            const double th = (a22 - a11) / (2.0 * a12);
+            const double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            a11 -= t * a12; a22 += t * a12; a12 = 0.0;
+            const double rp = a01, rq = a02;
+            a01 = c * rp - s * rq; a02 = s * rp + c * rq;
+            double p, q;
+            p = v01; q = v02; v01 = c * p - s * q; v02 = s * p + c * q;
+            p = v11; q = v12; v11 = c * p - s * q; v12 = s * p + c * q;
+            p = v21; q = v22; v21 = c * p - s * q; v22 = s * p + c * q;
+        }
+    }
+    // ascending eigenvalues (stable w.r.t. the original slot), then the first of smallest |w| as floats
+    double w0 = a00, w1 = a11, w2 = a22;
+    double e0x = v00, e0y = v10, e0z = v20, e1x = v01, e1y = v11, e1z = v21, e2x = v02, e2y = v12, e2z = v22;
+#define ICP_SWAP_EIG(wa, ax, ay, az, wb, bx_, by_, bz_) \
+    if (wb < wa) { double tw = wa; wa = wb; wb = tw; double tx = ax; ax = bx_; bx_ = tx; double ty = ay; ay = by_; by_ = ty; double tz = az; az = bz_; bz_ = tz; }
+    ICP_SWAP_EIG(w0, e0x, e0y, e0z, w1, e1x, e1y, e1z)
+    ICP_SWAP_EIG(w0, e0x, e0y, e0z, w2, e2x, e2y, e2z)
+    ICP_SWAP_EIG(w1, e1x, e1y, e1z, w2, e2x, e2y, e2z)
+#undef ICP_SWAP_EIG
+    double nx = e0x, ny = e0y, nz = e0z;
+    float wm = fabsf((float)w0);
+    if (fabsf((float)w1) < wm) { wm = fabsf((float)w1); nx = e1x; ny = e1y; nz = e1z; }
+    if (fabsf((float)w2) < wm) { nx = e2x; ny = e2y; nz = e2z; }
+    Nrm[i] = (F)nx;
+    Nrm[(size_t)m_pad + i] = (F)ny;
+    Nrm[2 * (size_t)m_pad + i] = (F)nz;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1098,17 +1163,17 @@ hipError_t launch_knn4(const NNPlan& pl, const void* Q, int32_t* nbr, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_normal_cov(int precision, const void* Q, int m, int m_pad, const int32_t* nbr, float* cov6,
-                             hipStream_t st)
+hipError_t launch_normals(int precision, const void* Q, int m, int m_pad, const int32_t* nbr, void* Nrm_soa,
+                          hipStream_t st)
 {
     if (m <= 0) return hipSuccess;
-    const int blocks = (m + 255) / 256;
+    const int blocks = (m_pad + 127) / 128;
     if (precision == ICP_F64)
-        hipLaunchKernelGGL((normal_cov_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)Q, m, m_pad, nbr,
-                           cov6);
+        hipLaunchKernelGGL((normals_kernel<double>), dim3(blocks), dim3(128), 0, st, (const double*)Q, m, m_pad, nbr,
+                           (double*)Nrm_soa);
     else
-        hipLaunchKernelGGL((normal_cov_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)Q, m, m_pad, nbr,
-                           cov6);
+        hipLaunchKernelGGL((normals_kernel<float>), dim3(blocks), dim3(128), 0, st, (const float*)Q, m, m_pad, nbr,
+                           (float*)Nrm_soa);
     return hipGetLastError();
 }
 

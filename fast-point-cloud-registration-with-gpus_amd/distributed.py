@@ -95,18 +95,24 @@ def run_sharded(ctx, P_shard, Q, dist, metric=capi.ICP_POINT_TO_POINT, max_iter=
             ctx.estimate_normals()
     ctx.set_moving(P_shard)
     torch.cuda.synchronize()
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # a torch-owned NON-default stream, made torch's current stream for the duration of the loop: the context
+    # launches on it and torch orders the collective against it.  (Handle 0 = the legacy default stream would be
+    # taken by icp_set_stream as "use your own stream", and torch would then order the all-reduce against the
+    # wrong stream.)
+    side = torch.cuda.Stream(device=dev)
+    ctx.set_stream(side.cuda_stream)
     ctx.loop_set_moments_dev(mom.data_ptr())
     try:
-        ctx.loop_begin(metric, max_iter=max_iter, tol=tol, fixed_iterations=fixed_iterations)
-        while True:
-            ctx.loop_enqueue()
-            dist.all_reduce(mom)
-            if ctx.loop_complete():
-                break
-        st = ctx.loop_state()
-        st["idx"] = ctx.loop_indices()
-        st["moved"] = ctx.get_moving()
+        with torch.cuda.stream(side):
+            ctx.loop_begin(metric, max_iter=max_iter, tol=tol, fixed_iterations=fixed_iterations)
+            while True:
+                ctx.loop_enqueue()
+                dist.all_reduce(mom)
+                if ctx.loop_complete():
+                    break
+            st = ctx.loop_state()
+            st["idx"] = ctx.loop_indices()
+            st["moved"] = ctx.get_moving()
         return st
     finally:
         ctx.loop_set_moments_dev(0)

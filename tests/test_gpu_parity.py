@@ -265,20 +265,43 @@ def test_external_moments_buffer_and_stream(ctx, pkg):
     torch.cuda.synchronize()
     ctx.set_model(M)
     ctx.set_moving(D)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    side = torch.cuda.Stream()
+    ctx.set_stream(side.cuda_stream)
     ctx.loop_set_moments_dev(mom.data_ptr())
     try:
-        ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=12, tol=1e-6)
-        seen_counts = []
-        while True:
-            ctx.loop_enqueue()
-            seen_counts.append(float(mom[1].item()))     # ordered behind the finalize kernel on torch's stream
-            if ctx.loop_complete():
-                break
-        st = ctx.loop_state()
+        with torch.cuda.stream(side):
+            ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=12, tol=1e-6)
+            seen_counts = []
+            while True:
+                ctx.loop_enqueue()
+                seen_counts.append(float(mom[1].item()))     # ordered behind the finalize kernel on torch's stream
+                if ctx.loop_complete():
+                    break
+            st = ctx.loop_state()
     finally:
         ctx.loop_set_moments_dev(0)
         ctx.set_stream(0)
     assert st["iterations"] == want.iterations
     assert rel(st["T"], want.T) < 1e-12 and np.abs(st["err"] - want.err).max() < 1e-12
     assert seen_counts[0] == D.shape[0]
+
+
+def test_run_sharded_single_rank_rccl(ctx, pkg, orc):
+    """the multi-GPU driver end to end with world_size 1 over the nccl (= RCCL) backend: communicator set-up,
+    all-reduce on the loop's stream, device finalize, D2H behind the collective"""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        D = pkg.datasets.synthetic_grid(64, np.float32)
+        M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+        Ps, begin = pkg.distributed.shard(D, 0, 1)
+        st = pkg.distributed.run_sharded(ctx, Ps, M, dist, max_iter=40, tol=1e-6)
+    finally:
+        dist.destroy_process_group()
+    want = orc.icp_p2p_f32x(D, M, 40, 1e-6)
+    assert begin == 0 and st["iterations"] == want["iterations"]
+    assert rel(st["T"], want["T"]) < TOL_T and np.abs(st["err"] - want["err"]).max() < TOL_E
+    assert np.array_equal(st["idx"], want["idx"])
