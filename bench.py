@@ -104,7 +104,17 @@ def main():
     ctx.set_moving(P)
     mom = None
     stream_ctx = None
-    if use_dist:
+    native_comm = False
+    if use_dist and os.environ.get("ICP_BENCH_COMM", "rccl") != "torch":
+        # preferred: the library issues the all-reduce itself (RCCL bound at run time, icp_comm_init); torch only
+        # broadcasts the 128-byte communicator id.  Any failure falls back to the torch.distributed collective.
+        try:
+            torch.cuda.set_device(local_rank)
+            pkg.distributed.attach_native_comm(ctx, dist)
+            native_comm = True
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] native RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+    if use_dist and not native_comm:
         # The loop writes its moment vector straight into a torch tensor and runs on a torch-owned (non-default)
         # stream that is also torch's CURRENT stream while the loop runs, so the RCCL all-reduce is ordered behind
         # the finalize kernel, and the D2H behind the all-reduce, without any host synchronisation in between.
@@ -118,8 +128,8 @@ def main():
         ctx.loop_set_moments_dev(mom.data_ptr())
 
     def step():
-        ctx.loop_enqueue()
-        if use_dist:
+        ctx.loop_enqueue()          # native_comm: finalize kernel + ncclAllReduce on the loop's stream
+        if use_dist and not native_comm:
             dist.all_reduce(mom)
         return ctx.loop_complete()
 
@@ -130,13 +140,21 @@ def main():
 
     ctx.set_profiling(8)   # HIP events around every 8th matching launch of the timed region
     ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=W + K + 2, tol=0.0, fixed_iterations=True)
-    for _ in range(W):
-        step()
+    in_library = not (use_dist and not native_comm)   # nothing Python has to do between the steps
+
+    def steps(count):
+        if in_library:
+            done_steps, _ = ctx.loop_run(count)      # count x (enqueue + complete) inside libicp_mi355x
+            assert done_steps == count
+        else:
+            for _ in range(count):
+                step()
+
+    steps(W)
     sec0, cnt0 = ctx.loop_timing()
     sync()
     t0 = time.perf_counter()
-    for _ in range(K):
-        step()
+    steps(K)
     sync()
     dt = time.perf_counter() - t0
     sec1, cnt1 = ctx.loop_timing()
@@ -185,7 +203,8 @@ def main():
                     "Donut_1024x16.csv; polar->Cartesian by the device kernel)",
             "config": {"workload": "hall LiDAR scan point-to-point ICP (BASELINE configs[2])", "moving_points_per_gpu": n,
                        "model_points": m, "global_moving_points": n * world, "fixed_iterations": True,
-                       "collective": "1 all-reduce of 32 doubles per iteration" if use_dist else "none"},
+                       "collective": ("1 RCCL all-reduce of 32 doubles per iteration, issued by "
+                                      + ("libicp_mi355x on the loop's stream" if native_comm else "torch.distributed")) if use_dist else "none"},
             "roofline": {
                 "kernel": "nn_match_f32_v2<2,8,true> (packed fp32, seeded early-out; transform of the previous pass fused in)",
                 "bound": "valu",
@@ -209,6 +228,8 @@ def main():
         ctx.loop_set_moments_dev(0)
         ctx.set_stream(0)
         stream_ctx.__exit__(None, None, None)
+    if native_comm:
+        ctx.comm_destroy()
     ctx.close()
     if use_dist:
         dist.barrier()

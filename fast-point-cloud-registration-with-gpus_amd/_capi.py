@@ -69,9 +69,13 @@ SIGNATURES = {
     "icp_loop_moments_dev": (_vp, [_vp]),
     "icp_loop_set_moments_dev": (_i, [_vp, _vp]),
     "icp_loop_complete": (_i, [_vp, _pi]),
+    "icp_loop_run": (_i, [_vp, _i, _pi, _pi]),
     "icp_loop_state": (_i, [_vp, _pi, _pi, _pd, _i, _pd]),
     "icp_loop_timing": (_i, [_vp, _pd, _pi]),
     "icp_loop_indices": (_i, [_vp, _vp]),
+    "icp_comm_unique_id": (_i, [_vp]),
+    "icp_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "icp_comm_destroy": (_i, [_vp]),
     "icp_solve_point_to_point": (_i, [_pd, _pd, _pd]),
     "icp_solve_point_to_plane": (_i, [_pd, _pd, _pd, _pd]),
     "icp_host_loop_create": (_i, [C.POINTER(icp_params), C.POINTER(_vp)]),

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/icp_mi355x.h"
+#include "icp_comm.h"
 #include "icp_host_loop.h"
 #include "icp_host_math.h"
 #include "icp_kernels.h"
@@ -117,8 +118,9 @@ struct icp_ctx {
     bool trace = false;
     double tr_enqueue = 0, tr_wait = 0, tr_reduce = 0, tr_solve = 0;
     uint64_t tr_n = 0;
+    void* comm = nullptr;              // RCCL communicator (icp_comm_init): the loop all-reduces its vector itself
     bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
-    bool host_reduce() const { return mom_dev == (double*)mom_own.p && h_mom_partials != nullptr; }
+    bool host_reduce() const { return !comm && mom_dev == (double*)mom_own.p && h_mom_partials != nullptr; }
     icp::NNPlan plan{};
     LoopState loop;
 };
@@ -304,6 +306,7 @@ void icp_destroy(icp_ctx* c)
                      1e6 * c->tr_reduce / c->tr_n, 1e6 * c->tr_solve / c->tr_n);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
     DevBuf* bufs[] = {&c->P, &c->P2, &c->Q, &c->Qs, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr};
     for (DevBuf* b : bufs) b->release();
@@ -314,6 +317,36 @@ void icp_destroy(icp_ctx* c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+int icp_comm_unique_id(void* out_bytes)
+{
+    if (!out_bytes) return fail(ICP_ERR_INVALID, "out == NULL");
+    std::string err;
+    const int rc = icp::comm_unique_id(out_bytes, err);
+    return rc == ICP_OK ? ICP_OK : fail(rc, err);
+}
+
+int icp_comm_init(icp_ctx* c, const void* id_bytes, int rank, int world)
+{
+    if (int rc = use(c)) return rc;
+    if (!id_bytes || world < 1 || rank < 0 || rank >= world) return fail(ICP_ERR_INVALID, "bad communicator arguments");
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
+    HIP_TRY(c->mom_own.ensure(ICP_NMOM * sizeof(double)));
+    if (!c->mom_dev) c->mom_dev = (double*)c->mom_own.p;
+    std::string err;
+    const int rc = icp::comm_init(id_bytes, rank, world, &c->comm, err);
+    return rc == ICP_OK ? ICP_OK : fail(rc, err);
+}
+
+int icp_comm_destroy(icp_ctx* c)
+{
+    if (int rc = use(c)) return rc;
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
+    return ICP_OK;
 }
 
 int icp_set_stream(icp_ctx* c, void* hip_stream)
@@ -587,9 +620,14 @@ int icp_loop_enqueue(icp_ctx* c)
                                     &L.mom_blocks, (double)(++c->tag_seq), err_rows, L.err_blocks, c->stream));
         if (host_reduce) L.err_blocks = 0;  // already inside the moment rows
     }
-    if (!host_reduce)
+    if (!host_reduce) {
         HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
                                      (const double*)c->err_partials.p, L.err_blocks, c->stream));
+        if (c->comm) {  // the iteration's one collective: 32 doubles, in place, on the loop's stream
+            std::string err;
+            if (int rc = icp::comm_allreduce_sum_f64(c->comm, c->mom_dev, ICP_NMOM, c->stream, err)) return fail(rc, err);
+        }
+    }
     L.host_reduce = host_reduce;
     L.pending = true;
     if (c->trace) c->tr_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
@@ -674,6 +712,20 @@ int icp_loop_complete(icp_ctx* c, int* done)
         c->tr_n += 1;
     }
     if (done) *done = L.H.done ? 1 : 0;
+    return ICP_OK;
+}
+
+int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
+{
+    if (max_steps < 0) return fail(ICP_ERR_INVALID, "max_steps < 0");
+    int d = c && c->loop.active && c->loop.H.done ? 1 : 0, k = 0;
+    while (!d && k < max_steps) {
+        if (int rc = icp_loop_enqueue(c)) return rc;
+        if (int rc = icp_loop_complete(c, &d)) return rc;
+        ++k;
+    }
+    if (steps_done) *steps_done = k;
+    if (done) *done = d;
     return ICP_OK;
 }
 

@@ -78,6 +78,40 @@ def drive(shard_ops, host_loop, allreduce):
         host_loop.note_applied()
 
 
+def attach_native_comm(ctx, dist):
+    """Give `ctx` its own RCCL communicator (icp_comm_init): rank 0 draws the id, torch.distributed only carries
+    those 128 bytes.  Afterwards icp_loop_enqueue issues the all-reduce itself."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(box[0], rank, world)
+
+
+def run_sharded_native(ctx, P_shard, Q, dist, metric=capi.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6,
+                       fixed_iterations=False, normals=None):
+    """Device driver with the collective issued by the library (no Python between the kernels and RCCL)."""
+    ctx.set_model(Q)
+    if metric == capi.ICP_POINT_TO_PLANE:
+        if normals is not None:
+            ctx.set_model_normals(normals)
+        else:
+            ctx.estimate_normals()
+    ctx.set_moving(P_shard)
+    attach_native_comm(ctx, dist)
+    try:
+        ctx.loop_begin(metric, max_iter=max_iter, tol=tol, fixed_iterations=fixed_iterations)
+        while True:
+            ctx.loop_enqueue()
+            if ctx.loop_complete():
+                break
+        st = ctx.loop_state()
+        st["idx"] = ctx.loop_indices()
+        st["moved"] = ctx.get_moving()
+        return st
+    finally:
+        ctx.comm_destroy()
+
+
 def run_sharded(ctx, P_shard, Q, dist, metric=capi.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6, fixed_iterations=False,
                 normals=None):
     """Device driver.  `ctx` is this rank's Context, `dist` an initialised torch.distributed (backend nccl ==

@@ -83,6 +83,20 @@ class Context:
         """time every n-th matching launch of the loop with HIP events (0 / False = off)"""
         capi.check(self._lib.icp_set_profiling(self._h, int(every_nth)), "icp_set_profiling")
 
+    # ---- multi-GPU: library-issued RCCL all-reduce ----------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_ubyte * 128)()
+        capi.check(capi.load().icp_comm_unique_id(buf), "icp_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, id_bytes, rank, world):
+        buf = (C.c_ubyte * 128).from_buffer_copy(id_bytes)
+        capi.check(self._lib.icp_comm_init(self._h, buf, int(rank), int(world)), "icp_comm_init")
+
+    def comm_destroy(self):
+        capi.check(self._lib.icp_comm_destroy(self._h), "icp_comm_destroy")
+
     # ---- matching seam -------------------------------------------------------------------------
     def Matching(self, P, Q):
         """idx[i] = argmin_j |P_i - Q_j|^2, lowest j on ties (reference `Matching` kernel)."""
@@ -196,6 +210,12 @@ class Context:
         done = C.c_int(0)
         capi.check(self._lib.icp_loop_complete(self._h, C.byref(done)), "icp_loop_complete")
         return bool(done.value)
+
+    def loop_run(self, max_steps):
+        """up to max_steps iterations inside the library; returns (steps_done, done)"""
+        k, d = C.c_int(0), C.c_int(0)
+        capi.check(self._lib.icp_loop_run(self._h, int(max_steps), C.byref(k), C.byref(d)), "icp_loop_run")
+        return k.value, bool(d.value)
 
     def loop_state(self):
         it, ps = C.c_int(0), C.c_int(0)

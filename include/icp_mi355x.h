@@ -150,6 +150,9 @@ int icp_loop_set_moments_dev(icp_ctx* ctx, void* dev_ptr_32_doubles);
 /* copy the (reduced) vector back, evaluate the stop rule, solve R,t for the next pass.
  * *done != 0 when the loop has ended. */
 int icp_loop_complete(icp_ctx* ctx, int* done);
+/* up to max_steps x (enqueue + complete) without returning to the caller in between (single GPU, or a
+ * communicator attached with icp_comm_init); stops early when the loop ends */
+int icp_loop_run(icp_ctx* ctx, int max_steps, int* steps_done, int* done);
 /* current state: iterations so far, error series (count doubles), composed transform */
 int icp_loop_state(icp_ctx* ctx, int* iterations, int* passes, double* err, int err_cap, double* T16);
 /* with icp_set_profiling(ctx, 1): summed hipEvent time of the matching kernel launches of this loop
@@ -157,6 +160,17 @@ int icp_loop_state(icp_ctx* ctx, int* iterations, int* passes, double* err, int 
 int icp_loop_timing(icp_ctx* ctx, double* seconds_nn, int* nn_launches);
 /* correspondences of the last pass that contributed to T (ping-pong buffer), n int32 */
 int icp_loop_indices(icp_ctx* ctx, int32_t* idx_out);
+
+/* ---- multi-GPU: the loop's single collective issued by the library (RCCL over xGMI, bound at run time) ----
+ * One process per GPU.  Rank 0 obtains an id (icp_comm_unique_id), the host application distributes those
+ * ICP_COMM_ID_BYTES bytes by any means (MPI, a torch.distributed broadcast, a file), every rank calls
+ * icp_comm_init on its context.  From then on icp_loop_enqueue all-reduces (sum, in place) the ICP_NMOM vector
+ * right behind the finalize kernel on the loop's stream; icp_loop_complete sees the global sums.  Shard the
+ * MOVING cloud with icp_shard_range and give every rank the full model. */
+#define ICP_COMM_ID_BYTES 128
+int icp_comm_unique_id(void* out_id_bytes);
+int icp_comm_init(icp_ctx* ctx, const void* id_bytes, int rank, int world);
+int icp_comm_destroy(icp_ctx* ctx);
 
 /* ---- host-only pieces (no device needed; exercised by the CPU test-suite) ------------------- */
 /* 3x3 cross-covariance solve from raw moments: replaces cublasSgemm + cusolverDnSgesvd + 2 gemm

@@ -305,3 +305,24 @@ def test_run_sharded_single_rank_rccl(ctx, pkg, orc):
     assert begin == 0 and st["iterations"] == want["iterations"]
     assert rel(st["T"], want["T"]) < TOL_T and np.abs(st["err"] - want["err"]).max() < TOL_E
     assert np.array_equal(st["idx"], want["idx"])
+
+
+def test_run_sharded_native_comm_single_rank(ctx, pkg, orc):
+    """library-issued RCCL all-reduce (icp_comm_*), world_size 1: id exchange, communicator, collective on the
+    loop's own stream, device finalize"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29547"
+    dist.init_process_group("gloo", rank=0, world_size=1)      # only carries the 128-byte id
+    try:
+        D = pkg.datasets.synthetic_grid(64, np.float32)
+        M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+        st = pkg.distributed.run_sharded_native(ctx, D, M, dist, max_iter=40, tol=1e-6)
+    finally:
+        dist.destroy_process_group()
+    want = orc.icp_p2p_f32x(D, M, 40, 1e-6)
+    assert st["iterations"] == want["iterations"] and rel(st["T"], want["T"]) < TOL_T
+    assert np.array_equal(st["idx"], want["idx"])
+    # and the context is back on its single-GPU fast path afterwards
+    res = ctx.point_to_point(D, M, max_iter=40, tol=1e-6)
+    assert res.iterations == want["iterations"] and rel(res.T, st["T"]) < 1e-12
