@@ -536,7 +536,18 @@ int icp_estimate_normals(icp_ctx* c, void* nxyz_out, int32_t* nbr_out)
     HIP_TRY(c->nbr.ensure((size_t)m * 4 * sizeof(int32_t)));
     const size_t es = icp::elem_size(c->prec);
     HIP_TRY(c->Nrm.ensure(3 * (size_t)pl.m_pad * es));
-    HIP_TRY(icp::launch_knn4(pl, c->Q.p, (int32_t*)c->nbr.p, c->stream));
+    static const bool knn_v1 = std::getenv("ICP_KNN_V1") && std::getenv("ICP_KNN_V1")[0] == '1';
+    if (c->prec == ICP_F32 && !knn_v1) {
+        int n_pad, bx, S, seg;
+        icp::knn4_v2_geometry(m, c->num_cus, &n_pad, &bx, &S, &seg);
+        // the per-segment top-5 lists reuse the matching partial buffers
+        HIP_TRY(c->part_d.ensure((size_t)S * n_pad * 5 * sizeof(float)));
+        HIP_TRY(c->part_idx.ensure((size_t)S * n_pad * 5 * sizeof(int32_t)));
+        HIP_TRY(icp::launch_knn4_v2(c->Q.p, m, c->num_cus, (float*)c->part_d.p, (int32_t*)c->part_idx.p, (int32_t*)c->nbr.p,
+                                    c->stream));
+    } else {
+        HIP_TRY(icp::launch_knn4(pl, c->Q.p, (int32_t*)c->nbr.p, c->stream));
+    }
     // covariance + eigen-solve on the device, straight into the resident (padded SoA) normal cloud
     HIP_TRY(icp::launch_normals(c->prec, c->Q.p, m, pl.m_pad, (const int32_t*)c->nbr.p, c->Nrm.p, c->stream));
     if (nxyz_out) {

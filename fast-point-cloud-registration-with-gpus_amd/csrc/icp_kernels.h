@@ -91,6 +91,10 @@ hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, v
 
 // model-on-model 4 nearest neighbours (self / rank 0 dropped)
 hipError_t launch_knn4(const NNPlan& pl, const void* Q_soa, int32_t* nbr /*[m][4]*/, hipStream_t st);
+// fp32: packed, wave-/segment-split top-5 kernel + merge.  part_* hold splits * n_pad * 5 entries.
+void knn4_v2_geometry(int m, int num_cus, int* n_pad, int* blocks_x, int* splits, int* seg_len);
+hipError_t launch_knn4_v2(const void* Q_soa, int m, int num_cus, float* part_d, int32_t* part_j, int32_t* nbr,
+                          hipStream_t st);
 // covariance of the 4 neighbours + fp64 Jacobi eigen-solve per lane -> padded SoA normals on the device
 hipError_t launch_normals(int precision, const void* Q_soa, int m, int m_pad, const int32_t* nbr, void* Nrm_soa,
                           hipStream_t st);

@@ -762,6 +762,179 @@ __global__ __launch_bounds__(NN_BLOCK) void knn4_kernel(const F* __restrict__ Q,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// kNN(4), fp32, v2: the matching kernel's machinery (packed distances over two query points per lane, four
+// waves splitting the block's model segment, grid.y segments, 8-point chunks with a wave-uniform early-out)
+// carrying a sorted (d, j) top-5 per query instead of a single minimum.  A chunk is examined element-wise only
+// when some lane's chunk minimum beats that lane's threshold = min(5th best so far, seeded bound).  The seeded
+// bound is the largest distance to five DISTINCT model points around the query's own index, bumped one ulp: at
+// least five points lie strictly under it, so the exact top-5 survives; the seed only prunes work.
+// Per-wave lists are merged through LDS (ties -> the lower wave = lower indices), per-segment lists by
+// knn4_merge_kernel (ties -> the lower segment).  Rank 0 (self or an equal-distance lower index) is dropped there.
+// ------------------------------------------------------------------------------------------------
+struct Top5 {
+    float d[5];
+    int j[5];
+};
+
+__device__ __forceinline__ void top5_insert(Top5& L, float d, int j)
+{
+    float cd = d;
+    int cj = j;
+    bool shifting = false;  // once placed, everything below moves down one slot (keeps equal-d entries index-ordered)
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const bool sw = shifting || (cd < L.d[r]);
+        shifting = sw;
+        const float td = L.d[r];
+        const int tj = L.j[r];
+        L.d[r] = sw ? cd : td;
+        L.j[r] = sw ? cj : tj;
+        cd = sw ? td : cd;
+        cj = sw ? tj : cj;
+    }
+}
+
+constexpr int KNN_C = 8;
+
+__global__ __launch_bounds__(NN_BLOCK, 4) void knn4_f32_v2(const float* __restrict__ Q, int m, int m_pad, int n_pad,
+                                                           int seg_len, float* __restrict__ part_d,
+                                                           int32_t* __restrict__ part_j)
+{
+    constexpr int C = KNN_C;
+    __shared__ __attribute__((aligned(16))) float sq[4][3][NN2_TQW];
+    __shared__ float ld[4][128][5];
+    __shared__ int lj[4][128][5];
+
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int wseg = seg_len >> 2;
+    const int q0 = blockIdx.y * seg_len;
+    const int my0 = q0 + w * wseg;
+    const int my1 = min(my0 + wseg, m_pad);
+    const int ibase = blockIdx.x * 128 + lane;
+    const int i0 = min(ibase, m - 1), i1 = min(ibase + 64, m - 1);  // queries are model points; padding lanes repeat the last
+
+    const f2 px = f2{Q[i0], Q[i1]}, py = f2{Q[(size_t)m_pad + i0], Q[(size_t)m_pad + i1]},
+             pz = f2{Q[2 * (size_t)m_pad + i0], Q[2 * (size_t)m_pad + i1]};
+    Top5 L[2];
+    float bound[2], thr[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { L[t].d[r] = inf_<float>(); L[t].j[r] = 0x7fffffff; }
+        const int i = t ? i1 : i0;
+        const float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
+        const int lo = max(0, min(i - 2, m - 5));  // five distinct indices around the query's own
+        float mx = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int j = lo + k;
+            mx = fmaxf(mx, dist2<float>(x, y, z, Q[j], Q[(size_t)m_pad + j], Q[2 * (size_t)m_pad + j]));
+        }
+        bound[t] = (mx < inf_<float>()) ? __uint_as_float(__float_as_uint(mx) + 1u) : mx;
+        thr[t] = bound[t];
+    }
+
+    const int ntile = (wseg + NN2_TQW - 1) / NN2_TQW;
+    for (int k = 0; k < ntile; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int v = threadIdx.x + r * NN_BLOCK;
+            const int ww = v / 192, rem = v % 192;
+            const int a = rem / 64, e = (rem % 64) * 4;
+            const int off = k * NN2_TQW + e;
+            const int src = q0 + ww * wseg + off;
+            if (off < wseg && src < m_pad)
+                *reinterpret_cast<float4*>(&sq[ww][a][e]) = *reinterpret_cast<const float4*>(&Q[(size_t)a * m_pad + src]);
+        }
+        __syncthreads();
+        const int tile0 = my0 + k * NN2_TQW;
+        const int len = min(NN2_TQW, my1 - tile0);
+        for (int c = 0; c < len; c += C) {
+            f2 dd[C];
+            float cmin0 = inf_<float>(), cmin1 = inf_<float>();
+#pragma unroll
+            for (int kk = 0; kk < C; kk += 4) {
+                const float4 qx4 = *reinterpret_cast<const float4*>(&sq[w][0][c + kk]);
+                const float4 qy4 = *reinterpret_cast<const float4*>(&sq[w][1][c + kk]);
+                const float4 qz4 = *reinterpret_cast<const float4*>(&sq[w][2][c + kk]);
+                const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+                const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+                const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+                dd[kk + 0] = pk_dist2<0>(qxa, qya, qza, px, py, pz);
+                dd[kk + 1] = pk_dist2<1>(qxa, qya, qza, px, py, pz);
+                dd[kk + 2] = pk_dist2<0>(qxb, qyb, qzb, px, py, pz);
+                dd[kk + 3] = pk_dist2<1>(qxb, qyb, qzb, px, py, pz);
+                cmin0 = fmin_(fmin_(cmin0, dd[kk].x), dd[kk + 1].x);
+                cmin0 = fmin_(fmin_(cmin0, dd[kk + 2].x), dd[kk + 3].x);
+                cmin1 = fmin_(fmin_(cmin1, dd[kk].y), dd[kk + 1].y);
+                cmin1 = fmin_(fmin_(cmin1, dd[kk + 2].y), dd[kk + 3].y);
+            }
+            const bool need = (cmin0 < thr[0]) | (cmin1 < thr[1]);
+            if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+#pragma unroll
+            for (int kk = 0; kk < C; ++kk) {
+                const int j = tile0 + c + kk;
+                const bool real = j < m;  // padded duplicates of the last point must not enter a top-k
+                if (real && dd[kk].x < thr[0]) { top5_insert(L[0], dd[kk].x, j); thr[0] = fmin_(bound[0], L[0].d[4]); }
+                if (real && dd[kk].y < thr[1]) { top5_insert(L[1], dd[kk].y, j); thr[1] = fmin_(bound[1], L[1].d[4]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            ld[w][lane + t * 64][r] = L[t].d[r];
+            lj[w][lane + t * 64][r] = L[t].j[r];
+        }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        // 4-way merge of sorted lists; on equal d the lower wave (lower indices) goes first
+        int h[4] = {0, 0, 0, 0};
+        const size_t o = ((size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * 128 + threadIdx.x) * 5;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            float bd = inf_<float>();
+            int bw = 0;
+#pragma unroll
+            for (int ww = 3; ww >= 0; --ww) {
+                const float d = h[ww] < 5 ? ld[ww][threadIdx.x][h[ww]] : inf_<float>();
+                if (d <= bd) { bd = d; bw = ww; }   // descending ww with <= : the lowest wave wins ties
+            }
+            const int hj = h[bw] < 5 ? lj[bw][threadIdx.x][h[bw]] : 0x7fffffff;
+            part_d[o + r] = bd;
+            part_j[o + r] = bd < inf_<float>() ? hj : 0x7fffffff;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) h[ww] += (ww == bw) ? 1 : 0;
+        }
+    }
+}
+
+// merge the S per-segment top-5 lists of every query (ascending segments, earlier segment first on equal d),
+// drop rank 0, store the 4 neighbour indices
+__global__ void knn4_merge_kernel(const float* __restrict__ part_d, const int32_t* __restrict__ part_j, int S, int n_pad,
+                                  int m, int32_t* __restrict__ nbr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Top5 L;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) { L.d[r] = part_d[(size_t)i * 5 + r]; L.j[r] = part_j[(size_t)i * 5 + r]; }
+    for (int s = 1; s < S; ++s) {
+        const size_t o = ((size_t)s * n_pad + i) * 5;
+        for (int r = 0; r < 5; ++r) {
+            const float d = part_d[o + r];
+            if (!(d < L.d[4])) break;  // lists are sorted: nothing further in this segment can enter
+            top5_insert(L, d, part_j[o + r]);
+        }
+    }
+#pragma unroll
+    for (int r = 1; r < 5; ++r) nbr[(size_t)i * 4 + (r - 1)] = L.j[r];
+}
+
 // PCA normal of every model point from its 4 neighbours, entirely on the device: float covariance in the
 // order of src/CUDA/CPU_ICP_point_to-plane.cpp:217-246 (bar = sum * 0.25f, A += (x-bar)(y-bar), not divided by
 // k), then a cyclic-Jacobi eigen-solve in fp64 registers (stands in for the reference's HOST loop of
@@ -1147,6 +1320,35 @@ hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, v
     else
         hipLaunchKernelGGL((soa_to_aos_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)soa, n, n_pad,
                            (float*)aos);
+    return hipGetLastError();
+}
+
+void knn4_v2_geometry(int m, int num_cus, int* n_pad, int* blocks_x, int* splits, int* seg_len)
+{
+    const int m_pad = pad_model(m);
+    *n_pad = round_up(m, 128);
+    *blocks_x = *n_pad / 128;
+    if (num_cus <= 0) num_cus = 256;
+    int S = (num_cus * 4 + *blocks_x - 1) / *blocks_x;        // 4 blocks (16 waves) per CU
+    const int max_S = (m_pad + 511) / 512;
+    if (S > max_S) S = max_S;
+    if (S < 1) S = 1;
+    int seg = round_up((m_pad + S - 1) / S, 4 * KNN_C);
+    *splits = (m_pad + seg - 1) / seg;
+    *seg_len = seg;
+}
+
+hipError_t launch_knn4_v2(const void* Q, int m, int num_cus, float* part_d, int32_t* part_j, int32_t* nbr, hipStream_t st)
+{
+    if (m <= 0) return hipSuccess;
+    int n_pad, bx, S, seg;
+    knn4_v2_geometry(m, num_cus, &n_pad, &bx, &S, &seg);
+    hipLaunchKernelGGL(knn4_f32_v2, dim3(bx, S), dim3(NN_BLOCK), 0, st, (const float*)Q, m, pad_model(m), n_pad, seg, part_d,
+                       part_j);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(knn4_merge_kernel, dim3((m + 255) / 256), dim3(256), 0, st, (const float*)part_d,
+                       (const int32_t*)part_j, S, n_pad, m, nbr);
     return hipGetLastError();
 }
 

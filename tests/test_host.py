@@ -44,7 +44,8 @@ def test_matching_isa_has_no_fused_multiply_add():
     for name, body in kernels:
         hits = bad.findall(body)
         assert not hits, f"{name}: {hits[:3]}"
-        assert re.search(r"v_(?:pk_)?mul_f(32|64)", body) and re.search(r"v_(?:pk_)?add_f(32|64)", body)
+        if "merge" not in name:   # the merge kernels only compare
+            assert re.search(r"v_(?:pk_)?mul_f(32|64)", body) and re.search(r"v_(?:pk_)?add_f(32|64)", body)
 
 
 def test_no_device_is_loud(pkg):
