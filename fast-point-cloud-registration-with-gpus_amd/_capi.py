@@ -55,6 +55,7 @@ SIGNATURES = {
     "icp_set_model": (_i, [_vp, _vp, _i, _i]),
     "icp_set_moving": (_i, [_vp, _vp, _i, _i]),
     "icp_set_model_normals": (_i, [_vp, _vp, _i]),
+    "icp_reset_moving": (_i, [_vp]),
     "icp_get_moving": (_i, [_vp, _vp]),
     "icp_get_indices": (_i, [_vp, _vp]),
     "icp_nn_match_resident": (_i, [_vp, _pf]),

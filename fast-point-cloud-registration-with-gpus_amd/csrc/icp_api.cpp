@@ -96,6 +96,7 @@ struct icp_ctx {
     int prec = -1;  // precision of the resident clouds (model and moving must agree)
     int n = 0, m = 0;
     bool have_model = false, have_moving = false, have_normals = false;
+    DevBuf P0;  // pristine copy of the moving cloud as uploaded (icp_reset_moving)
     DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
     bool have_scan_copy = false;
     int voided = 0;  // P2: ping-pong target of the transform fused into the matching kernel
@@ -114,6 +115,8 @@ struct icp_ctx {
     uint64_t tag_seq = 0;              // completion tag of the most recent moments launch (exact in a double)
     int profile_stride = 0;            // time every n-th matching launch (0 = never)
     uint64_t nn_launch_count = 0;
+    double prof_seconds_nn = 0.0;      // cumulative over loops since icp_set_profiling
+    int prof_nn_launches = 0;
     // ICP_TRACE=1: host-side time split of the loop, printed by icp_destroy
     bool trace = false;
     double tr_enqueue = 0, tr_wait = 0, tr_reduce = 0, tr_solve = 0;
@@ -307,7 +310,7 @@ void icp_destroy(icp_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
-    DevBuf* bufs[] = {&c->P, &c->P2, &c->Q, &c->Qs, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -362,6 +365,8 @@ int icp_set_profiling(icp_ctx* c, int enable)
     if (!c) return fail(ICP_ERR_INVALID, "null context");
     c->profiling = enable != 0;
     c->profile_stride = enable > 0 ? enable : 0;
+    c->prof_seconds_nn = 0.0;
+    c->prof_nn_launches = 0;
     return ICP_OK;
 }
 
@@ -403,7 +408,26 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
     c->loop.active = false;
     c->idx_valid = false;
     if (int rc = upload_cloud(c, xyz, n, icp::pad_moving(n), precision, c->P)) return rc;
+    if (n > 0) {
+        const size_t bytes = 3 * (size_t)icp::pad_moving(n) * icp::elem_size(precision);
+        HIP_TRY(c->P0.ensure(bytes));
+        HIP_TRY(hipMemcpyAsync(c->P0.p, c->P.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
     c->have_moving = true;
+    return ICP_OK;
+}
+
+int icp_reset_moving(icp_ctx* c)
+{
+    if (int rc = use(c)) return rc;
+    if (!c->have_moving) return fail(ICP_ERR_STATE, "no moving cloud resident");
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    if (c->n > 0) {
+        const size_t bytes = 3 * (size_t)icp::pad_moving(c->n) * icp::elem_size(c->prec);
+        HIP_TRY(hipMemcpyAsync(c->P.p, c->P0.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->loop.active = false;
+    c->idx_valid = false;
     return ICP_OK;
 }
 
@@ -709,6 +733,8 @@ int icp_loop_complete(icp_ctx* c, int* done)
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         L.seconds_nn += 1e-3 * ms;
         L.nn_launches += 1;
+        c->prof_seconds_nn += 1e-3 * ms;
+        c->prof_nn_launches += 1;
     }
     const int adv = L.H.advance(c->h_mom);
     if (adv != ICP_OK) {
@@ -758,9 +784,8 @@ int icp_loop_state(icp_ctx* c, int* iterations, int* passes, double* err, int er
 int icp_loop_timing(icp_ctx* c, double* seconds_nn, int* nn_launches)
 {
     if (!c) return fail(ICP_ERR_INVALID, "null context");
-    if (!c->loop.active) return fail(ICP_ERR_STATE, "no loop");
-    if (seconds_nn) *seconds_nn = c->loop.seconds_nn;
-    if (nn_launches) *nn_launches = c->loop.nn_launches;
+    if (seconds_nn) *seconds_nn = c->prof_seconds_nn;
+    if (nn_launches) *nn_launches = c->prof_nn_launches;
     return ICP_OK;
 }
 

@@ -125,6 +125,9 @@ class Context:
         Nrm = _as_cloud(Nrm, self._dtype)
         capi.check(self._lib.icp_set_model_normals(self._h, Nrm.ctypes.data, Nrm.shape[0]), "icp_set_model_normals")
 
+    def reset_moving(self):
+        capi.check(self._lib.icp_reset_moving(self._h), "icp_reset_moving")
+
     def get_moving(self):
         out = np.empty((self._n, 3), dtype=self._dtype)
         capi.check(self._lib.icp_get_moving(self._h, out.ctypes.data), "icp_get_moving")

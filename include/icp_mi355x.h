@@ -108,6 +108,9 @@ int icp_set_model(icp_ctx* ctx, const void* xyz_aos, int m, int precision);
 int icp_set_moving(icp_ctx* ctx, const void* xyz_aos, int n, int precision);
 /* unit normals of the model points, AoS, same precision as the model (point-to-plane) */
 int icp_set_model_normals(icp_ctx* ctx, const void* nxyz_aos, int m);
+/* put the moving cloud back to the state icp_set_moving uploaded (device-to-device copy of a resident pristine
+ * copy): lets a caller register the same pair repeatedly without touching PCIe */
+int icp_reset_moving(icp_ctx* ctx);
 int icp_get_moving(icp_ctx* ctx, void* xyz_aos_out);        /* 3n values, precision of the cloud */
 int icp_get_indices(icp_ctx* ctx, int32_t* idx_out);        /* n int32: the most recent matching pass */
 /* one matching pass over the resident clouds; indices stay on the device.  kernel_ms (optional)
@@ -155,8 +158,8 @@ int icp_loop_complete(icp_ctx* ctx, int* done);
 int icp_loop_run(icp_ctx* ctx, int max_steps, int* steps_done, int* done);
 /* current state: iterations so far, error series (count doubles), composed transform */
 int icp_loop_state(icp_ctx* ctx, int* iterations, int* passes, double* err, int err_cap, double* T16);
-/* with icp_set_profiling(ctx, 1): summed hipEvent time of the matching kernel launches of this loop
- * and their count (the bench's roofline leg reads the timed region through this) */
+/* summed hipEvent time and count of the matching-kernel launches timed since icp_set_profiling was last called
+ * (cumulative over loops; the bench's roofline leg reads the timed region through this) */
 int icp_loop_timing(icp_ctx* ctx, double* seconds_nn, int* nn_launches);
 /* correspondences of the last pass that contributed to T (ping-pong buffer), n int32 */
 int icp_loop_indices(icp_ctx* ctx, int32_t* idx_out);
