@@ -195,15 +195,15 @@ def main():
         # back-to-back launches of the same kernel, no other work between (cross-check, not the headline)
         b2b_ms = ctx.nn_match_bench(50) / 50.0
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1", "04_pmc_hbm_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r1", "06_pmc_hbm_traffic_fused_tail.json")
         if world == 1 and os.path.exists(pmc):
             # HBM bytes per launch of the seeded matching kernel from the committed rocprofv3 PMC passes of THIS
             # command (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units, FETCH doubled: gfx950 correction)
-            rec = json.load(open(pmc)).get("void icp::nn_match_f32_v2<2, 8, true>")
+            rec = json.load(open(pmc)).get("void icp::nn_match_f32_v2<2, 8, true, 1>")
             if rec:
                 traffic = rec["hbm_bytes_corrected"]
-                traffic_src = ("profiles/r1/04_pmc_hbm_traffic.json: FETCH_SIZE %.0f B raw (x2 corrected) + WRITE_SIZE %.0f B; "
-                               "the excess over the algorithmic bytes is the per-segment (d, idx) partials" %
+                traffic_src = ("profiles/r1/06_pmc_hbm_traffic_fused_tail.json: FETCH_SIZE %.0f B raw (x2 corrected) + WRITE_SIZE %.0f B "
+                               "(atomic key updates count as writes)" %
                                (rec["fetch_bytes_raw"], rec["write_bytes"]))
         out = {
             "metric": "ICP iterations/sec + NN HBM GB/s (% roofline), hall cloud",
@@ -226,8 +226,9 @@ def main():
                        "collective": ("1 RCCL all-reduce of 32 doubles per iteration, issued by "
                                       + ("libicp_mi355x on the loop's stream" if native_comm else "torch.distributed")) if use_dist else "none"},
             "roofline": {
-                "kernel": "nn_match_f32_v2<2,8,*> (packed fp32; cold first pass without, later passes with the seeded early-out; "
-                          "transform of the previous pass fused in) -- average over the timed registrations",
+                "kernel": "nn_match_f32_v2<2,8,*,1>: ONE launch per iteration = [transform + error of the previous pass] + brute-force "
+                          "matching (packed fp32; cold first pass without, later passes with the seeded early-out) + segment merge "
+                          "(atomic keys) + gather/moment rows by each row's last block -- average over the timed registrations",
                 "bound": "valu",
                 "bound_note": "brute-force NN is 4681 flop/B on this cloud (ridge ~20): VALU-bound, not HBM-bound; "
                               "fp32 vector peak == fp32 MFMA peak on gfx950. Exact (non-FMA) arithmetic caps frac at 0.5.",
@@ -235,7 +236,11 @@ def main():
                 "frac": flops / nn_avg_s / 1e12 / FP32_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": flops, "avg_launch_us": 1e6 * nn_avg_s, "launches_timed": nn_launches,
-                "back_to_back_us": 1e3 * b2b_ms, "pairs_per_s": n * m / nn_avg_s,
+                "pairs_per_s": n * m / nn_avg_s,
+                "matching_only": {"what": "the same matching kernel WITHOUT the fused transform/tail (icp_nn_match_bench_ex: 50 back-to-back "
+                                          "seeded launches), i.e. the part the 8*N*M flop belong to",
+                                  "avg_launch_us": 1e3 * b2b_ms, "achieved": flops / (1e-3 * b2b_ms) / 1e12,
+                                  "frac": flops / (1e-3 * b2b_ms) / 1e12 / FP32_PEAK_TFLOPS},
                 "launch": info,
                 "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / nn_avg_s / 1e9,
                         "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes / nn_avg_s / 1e9 / HBM_PEAK_GBPS},

@@ -81,6 +81,7 @@ struct LoopState {
     bool timed_nn = false;
     bool host_reduce = false;  // how the pending enqueue's partial rows are being reduced
     bool matched = false;      // a matching pass of THIS loop has filled idx[cur]
+    bool rows_have_err = false; // slot 0 of the pending moment rows carries the error shares (fused tail)
 };
 
 }  // namespace
@@ -104,6 +105,9 @@ struct icp_ctx {
     int cur = 0;  // idx buffer written by the most recent matching pass
     bool idx_valid = false;  // idx[cur] holds matches of the resident clouds
     DevBuf mom_partials, err_partials, mom_own, nbr;
+    DevBuf keys, tickets;              // fused tail of the matching kernel: (d, idx) keys per moving point, row tickets
+    size_t rows_cap = 0;               // rows available in mom_partials / h_mom_partials
+    bool fused_tail = true;            // ICP_FUSED_TAIL=0 keeps matching and moments as two kernels
     double* mom_dev = nullptr;
     double* h_mom = nullptr;  // pinned: the reduced ICP_NMOM vector as the host solve reads it
     // single-GPU fast path: the moments / transform kernels store their per-block partial rows straight
@@ -148,7 +152,26 @@ int ensure_work_buffers(icp_ctx* c)
     HIP_TRY(c->idx[0].ensure((size_t)pl.n_pad * sizeof(int32_t)));
     HIP_TRY(c->idx[1].ensure((size_t)pl.n_pad * sizeof(int32_t)));
     const bool fresh = c->mom_partials.cap == 0;
-    HIP_TRY(c->mom_partials.ensure((size_t)icp::MOM_MAX_BLOCKS * ICP_NMOM * sizeof(double)));
+    size_t rows = (size_t)icp::MOM_MAX_BLOCKS;
+    if ((size_t)pl.blocks_x > rows) rows = (size_t)pl.blocks_x;
+    if (rows > c->rows_cap) {
+        if (c->h_mom_partials) { (void)hipHostFree(c->h_mom_partials); c->h_mom_partials = nullptr; }
+        HIP_TRY(hipHostMalloc((void**)&c->h_mom_partials, rows * ICP_NMOM * sizeof(double), hipHostMallocMapped));
+        std::memset(c->h_mom_partials, 0, rows * ICP_NMOM * sizeof(double));
+        c->rows_cap = rows;
+    }
+    HIP_TRY(c->mom_partials.ensure(rows * ICP_NMOM * sizeof(double)));
+    if (icp::nn_can_fuse_tail(pl)) {
+        const size_t kb = (size_t)pl.n_pad * sizeof(unsigned long long), tb = (size_t)pl.blocks_x * sizeof(unsigned int);
+        if (kb > c->keys.cap) {
+            HIP_TRY(c->keys.ensure(kb));
+            HIP_TRY(hipMemsetAsync(c->keys.p, 0xFF, c->keys.cap, c->stream));   // "no candidate yet"
+        }
+        if (tb > c->tickets.cap) {
+            HIP_TRY(c->tickets.ensure(tb));
+            HIP_TRY(hipMemsetAsync(c->tickets.p, 0, c->tickets.cap, c->stream));
+        }
+    }
     // one error row per matching block row (fused transform) or per transform block
     size_t err_rows = (size_t)icp::MOM_MAX_BLOCKS;
     if ((size_t)pl.blocks_x > err_rows) err_rows = (size_t)pl.blocks_x;
@@ -284,10 +307,7 @@ int icp_create(int device, icp_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mom, ICP_NMOM * sizeof(double), hipHostMallocDefault);
-    if (e == hipSuccess)
-        e = hipHostMalloc((void**)&c->h_mom_partials, (size_t)icp::MOM_MAX_BLOCKS * ICP_NMOM * sizeof(double),
-                          hipHostMallocMapped);
-    if (e == hipSuccess) std::memset(c->h_mom_partials, 0, (size_t)icp::MOM_MAX_BLOCKS * ICP_NMOM * sizeof(double));
+
     if (e != hipSuccess) {
         const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
         icp_destroy(c);
@@ -296,6 +316,7 @@ int icp_create(int device, icp_ctx** out)
     c->stream = c->own_stream;
     if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
     if (const char* v = std::getenv("ICP_TRACE")) c->trace = v[0] == '1';
+    if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
     *out = c;
     return ICP_OK;
 }
@@ -311,7 +332,7 @@ void icp_destroy(icp_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
     DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
-                      &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr};
+                      &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
     if (c->h_mom_partials) (void)hipHostFree(c->h_mom_partials);
@@ -485,7 +506,7 @@ int icp_nn_match_resident(icp_ctx* c, float* kernel_ms)
     if (int rc = ensure_work_buffers(c)) return rc;
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
     const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr, nullptr};
-    HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, c->stream));
+    HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(icp::launch_merge(c->plan, c->part_d.p, (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -507,7 +528,7 @@ int icp_nn_match_bench_ex(icp_ctx* c, int reps, int seeded, float* total_ms)
     const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
                                  (seeded && c->idx_valid) ? (const int32_t*)c->idx[c->cur].p : nullptr};
     for (int r = 0; r < reps; ++r)
-        HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, c->stream));
+        HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventElapsedTime(total_ms, c->ev0, c->ev1));
@@ -614,6 +635,7 @@ int icp_loop_enqueue(icp_ctx* c)
     const icp::NNPlan& pl = c->plan;
     L.err_blocks = 0;
     L.mom_blocks = 0;
+    L.rows_have_err = false;
     const bool host_reduce = c->host_reduce();
     double* mom_rows = host_reduce ? c->h_mom_partials : (double*)c->mom_partials.p;
     double* err_rows = (double*)c->err_partials.p;  // device: the moments kernel folds them into its rows
@@ -641,23 +663,43 @@ int icp_loop_enqueue(icp_ctx* c)
         c->idx_valid = true;
         const bool time_this = c->profile_stride > 0 && (c->nn_launch_count++ % (uint64_t)c->profile_stride) == 0;
         if (time_this) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); }
+        // fused tail: the matching kernel itself merges the segments (atomic keys), stores idx and produces the
+        // moment rows -- no partial arrays, no second launch.  ICP_FUSED_TAIL=0 keeps the two-kernel form.
+        const bool tail = c->fused_tail && icp::nn_can_fuse_tail(pl);
+        icp::NNTailArgs ta{};
+        if (tail) {
+            ta.metric = L.H.prm.metric;
+            ta.keys = (unsigned long long*)c->keys.p;
+            ta.tickets = (unsigned int*)c->tickets.p;
+            ta.err_tile = (double*)c->err_partials.p;
+            ta.idx_out = (int32_t*)c->idx[c->cur].p;
+            ta.Nrm_soa = c->Nrm.p;
+            ta.rows = mom_rows;
+            ta.tag = (double)(++c->tag_seq);
+        }
         if (fused) {
             icp::NNFusedTransform ft{L.H.R, L.H.t, (const int32_t*)c->idx[L.applied_idx].p, c->P2.p, err_rows};
-            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, c->stream));
+            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, tail ? &ta : nullptr, c->stream));
             std::swap(c->P, c->P2);  // the moved cloud is the current one from here on
             L.err_blocks = pl.blocks_x;
         } else {
-            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, c->stream));
+            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, tail ? &ta : nullptr, c->stream));
         }
         if (time_this) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); L.timed_nn = true; }
-        HIP_TRY(icp::launch_moments(pl, L.H.prm.metric, c->P.p, c->Q.p, c->Nrm.p, c->part_d.p,
-                                    (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, mom_rows,
-                                    &L.mom_blocks, (double)(++c->tag_seq), err_rows, L.err_blocks, c->stream));
-        if (host_reduce) L.err_blocks = 0;  // already inside the moment rows
+        if (tail) {
+            L.mom_blocks = pl.blocks_x;   // one row per row of matching blocks, error share in slot 0
+            L.err_blocks = 0;
+            L.rows_have_err = true;
+        } else {
+            HIP_TRY(icp::launch_moments(pl, L.H.prm.metric, c->P.p, c->Q.p, c->Nrm.p, c->part_d.p,
+                                        (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, mom_rows,
+                                        &L.mom_blocks, (double)(++c->tag_seq), err_rows, L.err_blocks, c->stream));
+            if (host_reduce) L.err_blocks = 0;  // already inside the moment rows
+        }
     }
     if (!host_reduce) {
         HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
-                                     (const double*)c->err_partials.p, L.err_blocks, c->stream));
+                                     (const double*)c->err_partials.p, L.err_blocks, L.rows_have_err ? 1 : 0, c->stream));
         if (c->comm) {  // the iteration's one collective: 32 doubles, in place, on the loop's stream
             std::string err;
             if (int rc = icp::comm_allreduce_sum_f64(c->comm, c->mom_dev, ICP_NMOM, c->stream, err)) return fail(rc, err);

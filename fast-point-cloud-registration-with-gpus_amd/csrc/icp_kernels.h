@@ -59,10 +59,25 @@ struct NNCullInputs {
     const int32_t* seed_idx;
 };
 
+// fused tail of the packed kernel: atomic (d, idx) keys + row tickets, the row's last block produces idx and the
+// moment row (see NNTail in icp_kernels.hip).  keys must be all-ones and tickets zero before the first launch;
+// the kernel leaves them that way.
+struct NNTailArgs {
+    int metric;                 // ICP_POINT_TO_POINT / ICP_POINT_TO_PLANE
+    unsigned long long* keys;   // [n_pad]
+    unsigned int* tickets;      // [blocks_x]
+    double* err_tile;           // [blocks_x] device
+    int32_t* idx_out;           // [n_pad]
+    const void* Nrm_soa;        // normals (plane)
+    double* rows;               // [blocks_x][ICP_NMOM], pinned host or device
+    double tag;
+};
+bool nn_can_fuse_tail(const NNPlan& pl);
+
 // matching: per (segment, point) partial minimum + index.  `ft` (optional) = fused transform,
-// `opt` (optional) = early-out inputs.
+// `opt` (optional) = early-out inputs, `ta` (optional) = fused tail (then no partials are written).
 hipError_t launch_nn(const NNPlan& pl, const void* P_soa, const void* Q_soa, void* part_d, int32_t* part_idx,
-                     const NNFusedTransform* ft, const NNCullInputs* opt, hipStream_t st);
+                     const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st);
 // void the exact duplicates of a padded SoA model (host side, O(m) hash); returns how many were voided
 int void_duplicate_points_f32(const float* Q_soa_host, int m, int m_pad, float* out_soa_host);
 // stand-alone merge of the segment partials into idx (icp_nn_match_* only; the ICP loop merges
@@ -84,7 +99,7 @@ hipError_t launch_transform_error(int precision, void* P_soa, int n, int n_pad, 
                                   int* blocks, hipStream_t st);
 // deterministic fixed-order reduction of the per-block partials into the ICP_NMOM-vector
 hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_blocks, const double* err_partials,
-                           int err_blocks, hipStream_t st);
+                           int err_blocks, int rows_have_err /* slot 0 of the rows carries error shares */, hipStream_t st);
 
 hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st);
 hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, void* aos, hipStream_t st);

@@ -263,6 +263,25 @@ __device__ __forceinline__ f2 pk_dist2(f2 qx, f2 qy, f2 qz, f2 px, f2 py, f2 pz)
 
 constexpr int NN2_TQW = 256;  // model points per wave per LDS tile step
 
+// Optional fused TAIL of the matching kernel (TAIL = 1 point-to-point, 2 point-to-plane): instead of leaving
+// per-segment (d, idx) partials for a second kernel, every block folds its result into one 64-bit key per moving
+// point with a device-scope atomic min -- key = (float bits of d) << 32 | idx, so the integer order IS the
+// lexicographic (d, idx) order the tie rule needs -- then draws a ticket for its row of moving points.  The block
+// that draws the last ticket of a row (all S segment blocks have contributed) reads the final keys, stores idx,
+// gathers q (and the normal) and produces the row's moment sums: the work of moments_kernel without a second
+// launch, a dependent dispatch or the partial arrays.  Protocol (agent scope, placement independent): the payload
+// is written ONLY by agent-scope atomics; every wave drains them (s_waitcnt vmcnt(0)) and the block barriers
+// before one lane adds the ticket; the last arriver reads the keys back with agent-scope atomic loads.
+struct NNTail {
+    unsigned long long* keys;  // [n_pad], all ones between launches (the last block of a row resets them)
+    unsigned int* tickets;     // [gridDim.x], zero between launches (reset by the last block)
+    double* err_tile;          // [gridDim.x] device: error of the fused transform, from the grid.y == 0 block
+    int32_t* idx_out;          // [n_pad]
+    const float* Nrm;          // model normals (SoA, m_pad) for TAIL == 2
+    double* rows;              // [gridDim.x][ICP_NMOM]: pinned host (single GPU) or device (finalize follows)
+    double tag;                // completion tag stored in slot ICP_NMOM-1 of the row
+};
+
 // rigid motion applied to the moving cloud; travels by value in the kernel-argument segment
 template <typename F> struct RT { F r[9]; F t[3]; };
 
@@ -296,17 +315,23 @@ struct NNFuse {
     const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
 };
 
-template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/, bool CULL /*seeded bound + xy early-out*/>
+template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/, bool CULL /*seeded bound + xy early-out*/, int TAIL = 0>
 __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(const float* __restrict__ P, int n_pad,
                                                                const float* __restrict__ Q, int m_pad, int seg_len,
                                                                float* __restrict__ part_d,
                                                                int32_t* __restrict__ part_idx, RT<float> rt,
-                                                               NNFuse fuse)
+                                                               NNFuse fuse, NNTail tail)
 {
     constexpr int TP = T / 2;  // packed pairs of moving points per lane
-    __shared__ __attribute__((aligned(16))) float sq[4][3][NN2_TQW];
-    __shared__ float md[4][64 * T];
-    __shared__ int mi[4][64 * T];
+    // one raw LDS block, carved by hand: the tail's transpose buffer overlays the tile + merge scratch
+    constexpr int SQ_BYTES = 4 * 3 * NN2_TQW * 4, MD_BYTES = 4 * 64 * T * 4;
+    constexpr int TR_BYTES = TAIL ? (TAIL == 2 ? 28 : 18) * 65 * 8 : 0;
+    constexpr int LDS_BYTES = (SQ_BYTES + 2 * MD_BYTES + 16) > TR_BYTES ? (SQ_BYTES + 2 * MD_BYTES + 16) : TR_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    float (*sq)[3][NN2_TQW] = reinterpret_cast<float (*)[3][NN2_TQW]>(lds_raw);
+    float (*md)[64 * T] = reinterpret_cast<float (*)[64 * T]>(lds_raw + SQ_BYTES);
+    int (*mi)[64 * T] = reinterpret_cast<int (*)[64 * T]>(lds_raw + SQ_BYTES + MD_BYTES);
+    int* s_flag = reinterpret_cast<int*>(lds_raw + SQ_BYTES + 2 * MD_BYTES);
 
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -353,7 +378,12 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
         }
         if (blockIdx.y == 0 && w == 0) {
             err = wave_sum(err);
-            if (lane == 0) fuse.err_rows[blockIdx.x] = err;
+            if (lane == 0) {
+                if constexpr (TAIL != 0)  // read by whichever block closes this row: agent-scope store, drained before our ticket
+                    __hip_atomic_store(&tail.err_tile[blockIdx.x], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    fuse.err_rows[blockIdx.x] = err;
+            }
         }
     }
 #pragma unroll
@@ -521,9 +551,91 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
             const int j = mi[ww][threadIdx.x];
             if (d < b) { b = d; bi = j; }
         }
-        const size_t o = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * (64 * T) + threadIdx.x;
-        part_d[o] = b;
-        part_idx[o] = bi;
+        if constexpr (TAIL == 0) {
+            const size_t o = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * (64 * T) + threadIdx.x;
+            part_d[o] = b;
+            part_idx[o] = bi;
+        } else {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(b) << 32) | (unsigned int)bi;
+            __hip_atomic_fetch_min(&tail.keys[(size_t)blockIdx.x * (64 * T) + threadIdx.x], key, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (TAIL != 0) {
+        static_assert(TAIL == 0 || T == 2, "the fused tail is written for two moving points per lane");
+        // every wave drains its atomics, the block meets, one lane draws the row's ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int ticket = __hip_atomic_fetch_add(&tail.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_flag = (ticket == gridDim.y - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*s_flag == 0 || w != 0) return;  // only wave 0 of the row's last block goes on (the LDS is all its own now)
+
+        constexpr int NACC = TAIL == 2 ? 28 : 18;
+        double acc[NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+        const float* Qg = fuse.Q_gather;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = ibase + t * 64;
+            const unsigned long long key = __hip_atomic_load(&tail.keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail.keys[i] = ~0ull;  // ready for the next launch (nobody touches this row again in this one)
+            int j = (int)(unsigned int)(key & 0xffffffffull);
+            j = ((unsigned)j < (unsigned)fuse.m) ? j : fuse.m - 1;  // unreachable clamp, keeps idx in range by construction
+            if (i < fuse.n) {
+                tail.idx_out[i] = j;
+                const double ppx = (double)(t ? px[0].y : px[0].x), ppy = (double)(t ? py[0].y : py[0].x),
+                             ppz = (double)(t ? pz[0].y : pz[0].x);
+                const double qx = (double)Qg[j], qy = (double)Qg[(size_t)m_pad + j], qz = (double)Qg[2 * (size_t)m_pad + j];
+                acc[0] += 1.0;
+                if constexpr (TAIL == 1) {
+                    acc[1] += ppx; acc[2] += ppy; acc[3] += ppz;
+                    acc[4] += qx; acc[5] += qy; acc[6] += qz;
+                    acc[7] += qx * ppx; acc[8] += qx * ppy; acc[9] += qx * ppz;
+                    acc[10] += qy * ppx; acc[11] += qy * ppy; acc[12] += qy * ppz;
+                    acc[13] += qz * ppx; acc[14] += qz * ppy; acc[15] += qz * ppz;
+                    acc[16] += ppx * ppx + ppy * ppy + ppz * ppz;
+                    acc[17] += qx * qx + qy * qy + qz * qz;
+                } else {
+                    const double nx = (double)tail.Nrm[j], ny = (double)tail.Nrm[(size_t)m_pad + j],
+                                 nz = (double)tail.Nrm[2 * (size_t)m_pad + j];
+                    double cn[6];
+                    cn[0] = ppy * nz - ppz * ny;
+                    cn[1] = ppz * nx - ppx * nz;
+                    cn[2] = ppx * ny - ppy * nx;
+                    cn[3] = nx; cn[4] = ny; cn[5] = nz;
+                    const double bb = (ppx - qx) * nx + (ppy - qy) * ny + (ppz - qz) * nz;
+                    int o = 1;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int c2 = a; c2 < 6; ++c2) acc[o++] += cn[a] * cn[c2];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) acc[22 + a] -= cn[a] * bb;
+                }
+            }
+        }
+        // one wave: transpose through LDS (rows padded to 65 doubles), lane k adds slot k in lane order
+        double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // same wave: DS ops are in order; this pins the compiler
+        double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
+        if (lane < NACC) {
+            double sum = 0.0;
+#pragma unroll 8
+            for (int l = 0; l < 64; ++l) sum += tr[lane][l];
+            row[1 + lane] = sum;
+        }
+        if (lane == 0) {
+            row[ICP_MOM_ERR] = fuse.apply ? __hip_atomic_load(&tail.err_tile[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            tail.tickets[blockIdx.x] = 0u;
+        }
+        __threadfence_system();  // the row is visible to a polling host before its tag
+        if (lane == 0) row[ICP_NMOM - 1] = tail.tag;
     }
 }
 
@@ -681,13 +793,17 @@ __global__ __launch_bounds__(TR_BLOCK) void transform_error_kernel(F* __restrict
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void finalize_kernel(double* __restrict__ mom, const double* __restrict__ mom_partials,
                                                        int mom_blocks, const double* __restrict__ err_partials,
-                                                       int err_blocks)
+                                                       int err_blocks, int rows_have_err)
 {
     __shared__ double red[8][ICP_NMOM];
     const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
     double s = 0.0;
     if (k == 0) {
         for (int b = part; b < err_blocks; b += 8) s += err_partials[b];
+        if (rows_have_err)
+            for (int b = part; b < mom_blocks; b += 8) s += mom_partials[(size_t)b * ICP_NMOM];
+    } else if (k == ICP_NMOM - 1) {
+        s = 0.0;  // the rows' completion-tag slot is not a moment
     } else {
         for (int b = part; b < mom_blocks; b += 8) s += mom_partials[(size_t)b * ICP_NMOM + k];
     }
@@ -1177,8 +1293,10 @@ static hipError_t launch_nn_t(const NNPlan& pl, const void* P, const void* Q, vo
     return hipGetLastError();
 }
 
+bool nn_can_fuse_tail(const NNPlan& pl) { return pl.version == 2 && pl.pts_per_thread == 2 && pl.chunk == 8 && pl.n > 0 && pl.m > 0; }
+
 static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
-                               const NNFusedTransform* ft, const NNCullInputs* opt, hipStream_t st)
+                               const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st)
 {
     dim3 grid(pl.blocks_x, pl.splits);
     RT<float> rt{};
@@ -1200,14 +1318,32 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         fuse.P_out = (float*)ft->P_out;
         fuse.err_rows = ft->err_rows;
     }
+    NNTail tail{};
+    if (ta) {
+        if (!nn_can_fuse_tail(pl)) return hipErrorInvalidValue;
+        tail.keys = ta->keys;
+        tail.tickets = ta->tickets;
+        tail.err_tile = ta->err_tile;
+        tail.idx_out = ta->idx_out;
+        tail.Nrm = (const float*)ta->Nrm_soa;
+        tail.rows = ta->rows;
+        tail.tag = ta->tag;
+    }
+#define ICP_LAUNCH_NN2T(CU, TL)                                                                                     \
+    hipLaunchKernelGGL((nn_match_f32_v2<2, 8, CU, TL>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,      \
+                       (const float*)Qscan, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse, tail)
 #define ICP_LAUNCH_NN2(TT, CC, CU)                                                                                  \
-    hipLaunchKernelGGL((nn_match_f32_v2<TT, CC, CU>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,        \
-                       (const float*)Qscan, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse)
+    hipLaunchKernelGGL((nn_match_f32_v2<TT, CC, CU, 0>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,     \
+                       (const float*)Qscan, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse, tail)
     // measured (profiles/r1/03_nn_sweep_cull.txt): without a seed the early-out variant loses to the plain
     // packed kernel on every cloud (its bound starts at +inf), with one it wins on every cloud
     const bool cull = pl.cull && Qscan != Q && fuse.seed_idx != nullptr;
     if (!cull) { Qscan = Q; fuse.seed_idx = nullptr; }
-    if (pl.pts_per_thread == 4) {
+    if (ta) {
+        const bool plane = ta->metric == ICP_POINT_TO_PLANE;
+        if (cull) { if (plane) ICP_LAUNCH_NN2T(true, 2); else ICP_LAUNCH_NN2T(true, 1); }
+        else { if (plane) ICP_LAUNCH_NN2T(false, 2); else ICP_LAUNCH_NN2T(false, 1); }
+    } else if (pl.pts_per_thread == 4) {
         if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8, false); else ICP_LAUNCH_NN2(4, 16, false);
     } else if (cull) {
         if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, true); else ICP_LAUNCH_NN2(2, 16, true);
@@ -1215,17 +1351,18 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, false); else ICP_LAUNCH_NN2(2, 16, false);
     }
 #undef ICP_LAUNCH_NN2
+#undef ICP_LAUNCH_NN2T
     return hipGetLastError();
 }
 
 bool nn_can_fuse_transform(const NNPlan& pl) { return pl.version == 2 && pl.n > 0 && pl.m > 0; }
 
 hipError_t launch_nn(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
-                     const NNFusedTransform* ft, const NNCullInputs* opt, hipStream_t st)
+                     const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st)
 {
     if (pl.n <= 0 || pl.m <= 0) return hipSuccess;
-    if (pl.version == 2) return launch_nn_v2(pl, P, Q, part_d, part_idx, ft, opt, st);
-    if (ft) return hipErrorInvalidValue;  // only the packed fp32 kernel carries the fused front end
+    if (pl.version == 2) return launch_nn_v2(pl, P, Q, part_d, part_idx, ft, opt, ta, st);
+    if (ft || ta) return hipErrorInvalidValue;  // only the packed fp32 kernel carries the fused front end
     return pl.precision == ICP_F64 ? launch_nn_t<double>(pl, P, Q, part_d, part_idx, st)
                                    : launch_nn_t<float>(pl, P, Q, part_d, part_idx, st);
 }
@@ -1290,10 +1427,10 @@ hipError_t launch_transform_error(int precision, void* P, int n, int n_pad, cons
 }
 
 hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_blocks, const double* err_partials,
-                           int err_blocks, hipStream_t st)
+                           int err_blocks, int rows_have_err, hipStream_t st)
 {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, mom_out, mom_partials, mom_blocks, err_partials,
-                       err_blocks);
+                       err_blocks, rows_have_err);
     return hipGetLastError();
 }
 
