@@ -12,6 +12,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 TOL_T = 1e-5      # relative, composed 4x4 transform (BASELINE.json north_star)
 TOL_E = 1e-5      # absolute, RMS error series
 
@@ -326,3 +328,51 @@ def test_run_sharded_native_comm_single_rank(ctx, pkg, orc):
     # and the context is back on its single-GPU fast path afterwards
     res = ctx.point_to_point(D, M, max_iter=40, tol=1e-6)
     assert res.iterations == want["iterations"] and rel(res.T, st["T"]) < 1e-12
+
+
+def test_reset_moving_and_loop_run(ctx, pkg, orc):
+    """icp_reset_moving restores the uploaded cloud on the device; icp_loop_run(k) == k x (enqueue + complete)"""
+    D = pkg.datasets.synthetic_grid(48, np.float32)
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    ctx.set_model(M)
+    ctx.set_moving(D)
+    runs = []
+    for _ in range(2):
+        ctx.reset_moving()
+        assert np.array_equal(ctx.get_moving(), D)
+        ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6)
+        k1, done = ctx.loop_run(3)
+        assert k1 == 3 and not done
+        k2, done = ctx.loop_run(1000)
+        assert done
+        st = ctx.loop_state()
+        assert st["passes"] == k1 + k2 - 1            # the last step only evaluated the stop rule
+        runs.append((st, ctx.get_moving(), ctx.loop_indices()))
+    (a, pa, ia), (b, pb, ib) = runs
+    assert np.array_equal(a["T"], b["T"]) and np.array_equal(pa, pb) and np.array_equal(ia, ib)
+    want = orc.icp_p2p_f32x(D, M, 40, 1e-6)
+    assert a["iterations"] == want["iterations"] and rel(a["T"], want["T"]) < TOL_T and np.array_equal(ia, want["idx"])
+
+
+@pytest.mark.parametrize("tail", ["1", "0"])
+def test_fused_and_two_kernel_forms_agree(pkg, orc, golden, tail):
+    """ICP_FUSED_TAIL=0/1 (read at context creation): same indices, same transform to the last bits of the sums"""
+    import subprocess, sys, json
+    code = (
+        "import sys, os, json, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))\n"
+        "from __graft_entry__ import load_package\n"
+        "import oracle_lib\n"
+        "pkg = load_package(); orc = oracle_lib.Oracle()\n"
+        f"P, Q = orc.hall_clouds({golden!r})\n"
+        "with pkg.Context(0) as ctx:\n"
+        "    r = ctx.point_to_point(P, Q, max_iter=100, tol=1e-6)\n"
+        "print(json.dumps(dict(it=r.iterations, T=r.T.tolist(), err=r.err.tolist(), idx=int(np.bitwise_xor.reduce(r.idx * np.arange(1, r.idx.size + 1, dtype=np.int64))))))\n")
+    env = dict(os.environ, ICP_FUSED_TAIL=tail)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    P, Q = orc.hall_clouds(golden)
+    want = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
+    assert got["it"] == want["iterations"] and rel(np.array(got["T"]), want["T"]) < TOL_T
+    assert got["idx"] == int(np.bitwise_xor.reduce(want["idx"] * np.arange(1, want["idx"].size + 1, dtype=np.int64)))

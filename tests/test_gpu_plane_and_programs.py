@@ -255,3 +255,19 @@ def test_trace_dump_layout(tmp_path):
     n_it = (len(head) - 6) // 3
     assert n_it >= 2 and len(lines[1].split("|")) == 6 + 3 * n_it + 1
     assert lines[1 + 64] == "" and lines[2 + 64].startswith("Error|")
+
+
+def test_point_to_plane_hall(ctx, pkg, orc, golden):
+    """BASELINE configs[3]: hall LiDAR scan, point-to-plane (6x6 solve), fp32 -- device kNN/normals included"""
+    P, Q = orc.hall_clouds(golden)
+    ctx.set_model(Q)
+    nrm, nbr = ctx.estimate_normals(want_neighbours=True)
+    assert np.array_equal(nbr, orc.knn4(Q))
+    res = ctx.point_to_plane(P, Q, normals=nrm, max_iter=100, tol=1e-6)
+    want = orc.icp_p2plane(P, Q, nrm, 100, 1e-6, accumulate_f64=True)      # same normals on both sides
+    assert abs(res.iterations - want["iterations"]) <= 1
+    k = min(len(res.err), len(want["err"]))
+    assert np.abs(res.err[:k] - want["err"][:k]).max() < 1e-4
+    assert rel(res.T, want["T"]) < 1e-4
+    ang, t_mm = pkg.datasets.HALL_MM
+    assert np.abs(res.T[:3, 3] - np.array(t_mm) / 1000.0).max() < 5e-3 and abs(res.T[1, 0] - np.sin(ang[2])) < 5e-3
