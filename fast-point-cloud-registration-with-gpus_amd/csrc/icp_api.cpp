@@ -98,6 +98,7 @@ struct icp_ctx {
     int n = 0, m = 0;
     bool have_model = false, have_moving = false, have_normals = false;
     DevBuf P0;  // pristine copy of the moving cloud as uploaded (icp_reset_moving)
+    DevBuf Qbox;  // chunk bounding boxes of Qs
     DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
     bool have_scan_copy = false;
     int voided = 0;  // P2: ping-pong target of the transform fused into the matching kernel
@@ -108,6 +109,7 @@ struct icp_ctx {
     DevBuf keys, tickets;              // fused tail of the matching kernel: (d, idx) keys per moving point, row tickets
     size_t rows_cap = 0;               // rows available in mom_partials / h_mom_partials
     bool fused_tail = true;            // ICP_FUSED_TAIL=0 keeps matching and moments as two kernels
+    bool use_boxes = true;             // ICP_NN_BOXES=0 disables the bounding-box level of the early-out
     double* mom_dev = nullptr;
     double* h_mom = nullptr;  // pinned: the reduced ICP_NMOM vector as the host solve reads it
     // single-GPU fast path: the moments / transform kernels store their per-block partial rows straight
@@ -317,6 +319,7 @@ int icp_create(int device, icp_ctx** out)
     if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
     if (const char* v = std::getenv("ICP_TRACE")) c->trace = v[0] == '1';
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
     *out = c;
     return ICP_OK;
 }
@@ -331,7 +334,7 @@ void icp_destroy(icp_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
-    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -411,6 +414,9 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         std::vector<float> scan(3 * (size_t)m_pad);
         c->voided = void_duplicate_points((const float*)xyz, m, m_pad, scan.data());
         if (int rc = upload_cloud(c, scan.data(), m_pad, m_pad, precision, c->Qs)) return rc;
+        // bounding boxes of its 8-point chunks: the first, cheapest level of the early-out
+        HIP_TRY(c->Qbox.ensure((size_t)((m_pad + 7) / 8) * 8 * sizeof(float)));
+        HIP_TRY(icp::launch_model_boxes(c->Qs.p, m_pad, (float*)c->Qbox.p, c->stream));
         c->have_scan_copy = true;
     }
     c->have_model = true;
@@ -505,7 +511,7 @@ int icp_nn_match_resident(icp_ctx* c, float* kernel_ms)
     if (int rc = require_clouds(c)) return rc;
     if (int rc = ensure_work_buffers(c)) return rc;
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr, nullptr};
+    const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr, nullptr, c->use_boxes ? c->Qbox.p : nullptr};
     HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(icp::launch_merge(c->plan, c->part_d.p, (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, c->stream));
@@ -526,7 +532,8 @@ int icp_nn_match_bench_ex(icp_ctx* c, int reps, int seeded, float* total_ms)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     // seeded with the most recent correspondences when there are any: this is how the loop launches it
     const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
-                                 (seeded && c->idx_valid) ? (const int32_t*)c->idx[c->cur].p : nullptr};
+                                 (seeded && c->idx_valid) ? (const int32_t*)c->idx[c->cur].p : nullptr,
+                                 c->use_boxes ? c->Qbox.p : nullptr};
     for (int r = 0; r < reps; ++r)
         HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -657,7 +664,8 @@ int icp_loop_enqueue(icp_ctx* c)
     if (!final_only) {
         // the previous pass's matches seed the early-out bound (any valid index would do)
         const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
-                                     L.matched ? (const int32_t*)c->idx[c->cur].p : nullptr};
+                                     L.matched ? (const int32_t*)c->idx[c->cur].p : nullptr,
+                                     c->use_boxes ? c->Qbox.p : nullptr};
         c->cur ^= 1;
         L.matched = true;
         c->idx_valid = true;

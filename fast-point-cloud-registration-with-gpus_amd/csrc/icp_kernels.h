@@ -57,7 +57,9 @@ bool nn_can_fuse_transform(const NNPlan& pl);
 struct NNCullInputs {
     const void* Q_scan;
     const int32_t* seed_idx;
+    const void* boxes;  // per 8-point chunk of Q_scan: {lo.xyz, hi.xyz, 0, 0} floats (launch_model_boxes), or NULL
 };
+hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st);
 
 // fused tail of the packed kernel: atomic (d, idx) keys + row tickets, the row's last block produces idx and the
 // moment row (see NNTail in icp_kernels.hip).  keys must be all-ones and tickets zero before the first launch;

@@ -313,6 +313,7 @@ struct NNFuse {
     const int32_t* seed_idx; // CULL kernels: any valid model index per moving point (or NULL); it only
                              // tightens the starting bound, the result does not depend on it
     const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
+    const float* boxes;      // CULL kernels: per 8-point chunk of the scan copy {lo.xyz, hi.xyz, -, -} (or NULL)
 };
 
 template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/, bool CULL /*seeded bound + xy early-out*/, int TAIL = 0>
@@ -334,7 +335,9 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
     int* s_flag = reinterpret_cast<int*>(lds_raw + SQ_BYTES + 2 * MD_BYTES);
 
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
+    // the wave id as a SCALAR: everything derived from it (ranges, loop bounds, the box addresses) then lives in
+    // SGPRs, the loops are scalar loops and the per-chunk boxes arrive through the scalar cache
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wseg = seg_len >> 2;              // model points per wave (multiple of C)
     const int q0 = blockIdx.y * seg_len;
     const int my0 = q0 + w * wseg;
@@ -434,6 +437,28 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
 #pragma unroll
             for (int t = 0; t < T; ++t) bo[t] = best[t];
             if constexpr (CULL) {
+                // level 0: the chunk's bounding box (precomputed once per model over the scan copy).  Per axis
+                // gap = max(lo - p, p - hi, 0) <= |q - p| for every q of the chunk, so L = (gx^2 + gy^2) + gz^2 is a
+                // lower bound of every distance in the chunk; shaved by 2^-20 it stays one under the reference's
+                // rounding of those distances.  ~20 VALU ops per chunk and lane pair instead of ~50, wave-uniform skip.
+                if (fuse.boxes) {
+                    const float* bx = fuse.boxes + (size_t)((tile0 + c) / C) * 8;  // scalar address -> s_load
+                    const float lox = bx[0], loy = bx[1], loz = bx[2], hix = bx[3], hiy = bx[4], hiz = bx[5];
+                    bool needb = false;
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) {
+                        const f2 ax = f2{lox, lox} - px[u], bxx = px[u] - f2{hix, hix};
+                        const f2 ay = f2{loy, loy} - py[u], byy = py[u] - f2{hiy, hiy};
+                        const f2 az = f2{loz, loz} - pz[u], bzz = pz[u] - f2{hiz, hiz};
+                        f2 gx = f2{__builtin_fmaxf(__builtin_fmaxf(ax.x, bxx.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ax.y, bxx.y), 0.f)};
+                        f2 gy = f2{__builtin_fmaxf(__builtin_fmaxf(ay.x, byy.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ay.y, byy.y), 0.f)};
+                        f2 gz = f2{__builtin_fmaxf(__builtin_fmaxf(az.x, bzz.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(az.y, bzz.y), 0.f)};
+                        f2 L = (gx * gx + gy * gy) + gz * gz;
+                        L = L * f2{0.99999905f, 0.99999905f};  // 1 - 2^-20
+                        needb |= (L.x < best[2 * u]) | (L.y < best[2 * u + 1]);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(needb) == 0ull) continue;
+                }
                 // phase A: the inner sum of the reference's association, pxy = dx*dx + dy*dy, for the whole
                 // chunk.  d = fl(pxy + dz*dz) >= pxy, so a chunk whose smallest pxy is not below any lane's
                 // running minimum cannot lower it (nor win a tie: ascending order, strict <) -- skip its z half.
@@ -637,6 +662,36 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
         __threadfence_system();  // the row is visible to a polling host before its tag
         if (lane == 0) row[ICP_NMOM - 1] = tail.tag;
     }
+}
+
+// bounding box of every 8-point chunk of the duplicate-voided scan copy (voided = +inf entries are ignored; an
+// all-void chunk gets lo = +inf, hi = -inf and is skipped by construction).  Once per model.
+__global__ void model_boxes_kernel(const float* __restrict__ Qs, int m_pad, float* __restrict__ boxes)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * 8 >= m_pad) return;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = inf_<float>(); hi[a] = -inf_<float>(); }
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = Qs[(size_t)a * m_pad + j];
+            if (v < inf_<float>() && v > -inf_<float>()) { lo[a] = __builtin_fminf(lo[a], v); hi[a] = __builtin_fmaxf(hi[a], v); }
+        }
+    }
+    float* o = boxes + (size_t)c * 8;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+}
+
+hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const int chunks = (m_pad + 7) / 8;
+    hipLaunchKernelGGL(model_boxes_kernel, dim3((chunks + 255) / 256), dim3(256), 0, st, (const float*)Qs_soa, m_pad, boxes);
+    return hipGetLastError();
 }
 
 // lexicographic (d, j) minimum over the S segment partials: segments are ascending model ranges,
@@ -1308,6 +1363,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     if (pl.cull && opt && opt->Q_scan) {
         Qscan = opt->Q_scan;
         fuse.seed_idx = opt->seed_idx;
+        fuse.boxes = pl.chunk == 8 ? (const float*)opt->boxes : nullptr;
     }
     if (ft) {
         for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
@@ -1338,7 +1394,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     // measured (profiles/r1/03_nn_sweep_cull.txt): without a seed the early-out variant loses to the plain
     // packed kernel on every cloud (its bound starts at +inf), with one it wins on every cloud
     const bool cull = pl.cull && Qscan != Q && fuse.seed_idx != nullptr;
-    if (!cull) { Qscan = Q; fuse.seed_idx = nullptr; }
+    if (!cull) { Qscan = Q; fuse.seed_idx = nullptr; fuse.boxes = nullptr; }
     if (ta) {
         const bool plane = ta->metric == ICP_POINT_TO_PLANE;
         if (cull) { if (plane) ICP_LAUNCH_NN2T(true, 2); else ICP_LAUNCH_NN2T(true, 1); }

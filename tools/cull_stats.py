@@ -17,8 +17,9 @@ elif name == "bunny":
 else:
     P = orc.synth_grid_f32(128); Q = orc.gpu_model_f32(P, (0.2, -0.2, 0.05), (0.8, -0.3, 0.2))
 # after convergence the clouds nearly coincide: use the registered pose (P moved onto Q) as the steady state
-r = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
-P = r["moved"]
+if "--initial" not in sys.argv:
+    r = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
+    P = r["moved"]
 n, m = len(P), len(Q)
 # void exact duplicates like the product does
 _, first = np.unique(Q, axis=0, return_index=True)
@@ -46,3 +47,22 @@ tot = nw * nc
 print(name, "waves", nw, "chunks", nc)
 for k in tests:
     print(f"  bound {k:3s}: {100.0 * skip[k] / tot:6.2f}% of (wave, chunk) pairs skippable")
+
+# ---- interval (per-chunk bounding box) lower bounds: gap = max(lo - p, p - hi, 0) per axis --------------------
+Qc = np.where(np.isinf(Qs), np.nan, Qs).reshape(nc, C, 3)
+lo = np.nanmin(Qc, axis=1); hi = np.nanmax(Qc, axis=1)          # (nc, 3); all-void chunks -> nan -> always skippable
+lo = np.where(np.isnan(lo), np.inf, lo); hi = np.where(np.isnan(hi), -np.inf, hi)
+skipb = {k: 0 for k in tests}
+for wv in range(nw):
+    p = P[wv * W:(wv + 1) * W]
+    b = best[wv * W:(wv + 1) * W][:, None]
+    gap = np.maximum(np.maximum(lo[None, :, :] - p[:, None, :], p[:, None, :] - hi[None, :, :]), 0.0)   # (128, nc, 3)
+    g2 = gap * gap
+    for k, (a, bb, c) in tests.items():
+        L = a * g2[:, :, 0] + bb * g2[:, :, 1] + c * g2[:, :, 2]
+        L = np.where(np.isnan(L), np.inf, L)
+        need = (L < b).any(0)
+        skipb[k] += int((~need).sum())
+print("  interval (chunk AABB) bounds:")
+for k in tests:
+    print(f"  box   {k:3s}: {100.0 * skipb[k] / tot:6.2f}% skippable")
