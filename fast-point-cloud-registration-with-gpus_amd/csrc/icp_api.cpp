@@ -50,6 +50,8 @@ int fail(int code, const std::string& msg)
             return fail(ICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
     } while (0)
 
+static constexpr size_t kPhaseSlots = 512 * 1024;  // ICP_NN_PHASES: 10 stamps per wave
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -99,6 +101,9 @@ struct icp_ctx {
     bool have_model = false, have_moving = false, have_normals = false;
     DevBuf P0;  // pristine copy of the moving cloud as uploaded (icp_reset_moving)
     DevBuf Qbox;  // chunk bounding boxes of Qs
+    DevBuf Qsamp; // one point per chunk of Qs
+    DevBuf phase_log;        // ICP_NN_PHASES diagnostic
+    std::string phase_path;
     DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
     bool have_scan_copy = false;
     int voided = 0;  // P2: ping-pong target of the transform fused into the matching kernel
@@ -320,6 +325,15 @@ int icp_create(int device, icp_ctx** out)
     if (const char* v = std::getenv("ICP_TRACE")) c->trace = v[0] == '1';
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_NN_PHASES")) {
+        // diagnostic: the matching kernel stamps its phases per wave; the last launch's stamps are written to the
+        // named file (raw int64) when the context is destroyed -- tools/phase_report.py reads it
+        if (v[0] && c->phase_log.ensure(kPhaseSlots * sizeof(long long)) == hipSuccess &&
+            hipMemset(c->phase_log.p, 0, kPhaseSlots * sizeof(long long)) == hipSuccess) {
+            c->phase_path = v;
+            icp::set_phase_log((long long*)c->phase_log.p, (long long)kPhaseSlots);
+        }
+    }
     *out = c;
     return ICP_OK;
 }
@@ -334,7 +348,15 @@ void icp_destroy(icp_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
-    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    if (c->phase_log.p && !c->phase_path.empty()) {
+        icp::set_phase_log(nullptr, 0);
+        std::vector<long long> h(kPhaseSlots);
+        if (hipMemcpy(h.data(), c->phase_log.p, kPhaseSlots * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = std::fopen(c->phase_path.c_str(), "wb")) { std::fwrite(h.data(), sizeof(long long), h.size(), f); std::fclose(f); }
+        }
+        c->phase_log.release();
+    }
+    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -417,6 +439,8 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         // bounding boxes of its 8-point chunks: the first, cheapest level of the early-out
         HIP_TRY(c->Qbox.ensure((size_t)((m_pad + 7) / 8) * 8 * sizeof(float)));
         HIP_TRY(icp::launch_model_boxes(c->Qs.p, m_pad, (float*)c->Qbox.p, c->stream));
+        HIP_TRY(c->Qsamp.ensure(icp::model_samples_bytes(m_pad)));
+        HIP_TRY(icp::launch_model_samples(c->Qs.p, m_pad, (float*)c->Qsamp.p, c->stream));
         c->have_scan_copy = true;
     }
     c->have_model = true;
@@ -511,7 +535,7 @@ int icp_nn_match_resident(icp_ctx* c, float* kernel_ms)
     if (int rc = require_clouds(c)) return rc;
     if (int rc = ensure_work_buffers(c)) return rc;
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr, nullptr, c->use_boxes ? c->Qbox.p : nullptr};
+    const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr, nullptr, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(icp::launch_merge(c->plan, c->part_d.p, (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, c->stream));
@@ -533,7 +557,7 @@ int icp_nn_match_bench_ex(icp_ctx* c, int reps, int seeded, float* total_ms)
     // seeded with the most recent correspondences when there are any: this is how the loop launches it
     const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
                                  (seeded && c->idx_valid) ? (const int32_t*)c->idx[c->cur].p : nullptr,
-                                 c->use_boxes ? c->Qbox.p : nullptr};
+                                 c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     for (int r = 0; r < reps; ++r)
         HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -547,7 +571,7 @@ int icp_nn_launch_info(icp_ctx* c, int* splits, int* blocks, int* threads, int* 
     if (!c) return fail(ICP_ERR_INVALID, "null context");
     if (splits) *splits = c->plan.splits;
     if (blocks) *blocks = c->plan.blocks_x * c->plan.splits;
-    if (threads) *threads = icp::NN_BLOCK;
+    if (threads) *threads = icp::nn_block_threads(c->plan);
     if (n_pad) *n_pad = c->plan.n_pad;
     if (m_pad) *m_pad = c->plan.m_pad;
     return ICP_OK;
@@ -665,7 +689,7 @@ int icp_loop_enqueue(icp_ctx* c)
         // the previous pass's matches seed the early-out bound (any valid index would do)
         const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
                                      L.matched ? (const int32_t*)c->idx[c->cur].p : nullptr,
-                                     c->use_boxes ? c->Qbox.p : nullptr};
+                                     c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
         c->cur ^= 1;
         L.matched = true;
         c->idx_valid = true;

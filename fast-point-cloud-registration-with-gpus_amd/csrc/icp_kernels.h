@@ -27,7 +27,9 @@ struct NNPlan {
     int version;        // 1: generic kernel (fp64, A/B), 2: packed fp32 kernel
     int chunk;          // index-tracking chunk of the launched kernel
     int cull;           // the packed kernel may use the seeded-bound / xy early-out variant
+    int sparse;         // the geometry is the sparse kernel's (16-wave blocks of 128 moving points; needs chunk boxes)
 };
+int nn_block_threads(const NNPlan& pl);
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 inline int pad_moving(int n) { return n <= 0 ? 0 : round_up(n, NN_POINT_ALIGN); }
@@ -58,7 +60,13 @@ struct NNCullInputs {
     const void* Q_scan;
     const int32_t* seed_idx;
     const void* boxes;  // per 8-point chunk of Q_scan: {lo.xyz, hi.xyz, 0, 0} floats (launch_model_boxes), or NULL
+    const void* samples = nullptr;  // one point per chunk of Q_scan (launch_model_samples): the sparse kernel's cold start
 };
+size_t model_samples_bytes(int m_pad);
+hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, hipStream_t st);
+// diagnostic: per-wave phase stamps (s_memrealtime, 100 MHz) of the packed matching kernel, 10 slots per wave indexed
+// ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 10 + phase; NULL switches it off (the default)
+void set_phase_log(long long* dev, long long slots);
 hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st);
 
 // fused tail of the packed kernel: atomic (d, idx) keys + row tickets, the row's last block produces idx and the

@@ -261,7 +261,128 @@ __device__ __forceinline__ f2 pk_dist2(f2 qx, f2 qy, f2 qz, f2 px, f2 py, f2 pz)
     return d + dz;
 }
 
+// the same with the model pair held in SGPRs (wave-uniform chunk fetched through the scalar cache)
+template <int HI>
+__device__ __forceinline__ f2 pk_sub_bcast_s(f2 q, f2 p)
+{
+    f2 r;
+    if constexpr (HI == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(q), "v"(p));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(q), "v"(p));
+    return r;
+}
+template <int HI, bool QS>
+__device__ __forceinline__ f2 pk_sub_q(f2 q, f2 p)
+{
+    if constexpr (QS) return pk_sub_bcast_s<HI>(q, p); else return pk_sub_bcast<HI>(q, p);
+}
+
+// wave-wide min / max of a float by DPP (no LDS): row_shr 1,2,4,8 leave each row's result in its lane 15
+// (min/max are idempotent, overlapping windows are harmless), row_bcast15/31 carry it to lane 63.
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax(float v)
+{
+    // written as DPP-fused instructions (the compiler would spend seven per step); s_nop 1 covers the
+    // VALU-write -> DPP-read hazard, lanes without a source keep their value
+#define ICP_DPP_STEP(CTRL)                                                                       \
+    if constexpr (MAX) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL : "+v"(v));   \
+    else asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL : "+v"(v));
+    ICP_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+    ICP_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+    ICP_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+    ICP_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+    ICP_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    ICP_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef ICP_DPP_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 constexpr int NN2_TQW = 256;  // model points per wave per LDS tile step
+
+// One chunk of C model points against the lane's packed moving points, with the xy early-out:
+// phase A forms pxy = dx*dx + dy*dy (the inner sum of the reference's association) for the whole chunk;
+// d = fl(pxy + dz*dz) >= pxy, so a chunk whose smallest pxy is not below any lane's running minimum cannot
+// lower it (nor win a tie: ascending order, strict <) and its z half is skipped; phase B finishes the chunk
+// exactly as the un-culled kernel would have.  QS: the chunk address is wave-uniform and q travels in SGPRs.
+template <int TP, int C, bool QS>
+__device__ __forceinline__ void scan_chunk_xy_cull(const float* qxp, const float* qyp, const float* qzp, const f2 (&px)[TP],
+                                                   const f2 (&py)[TP], const f2 (&pz)[TP], float (&best)[2 * TP])
+{
+    f2 pxy[TP][C];
+    float mxy[2 * TP];
+#pragma unroll
+    for (int t = 0; t < 2 * TP; ++t) mxy[t] = inf_<float>();
+#pragma unroll
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qx4 = *reinterpret_cast<const float4*>(qxp + kk);
+        const float4 qy4 = *reinterpret_cast<const float4*>(qyp + kk);
+        const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+        const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            f2 ax, ay;
+            ax = pk_sub_q<0, QS>(qxa, px[u]); ay = pk_sub_q<0, QS>(qya, py[u]);
+            pxy[u][kk + 0] = ax * ax + ay * ay;
+            ax = pk_sub_q<1, QS>(qxa, px[u]); ay = pk_sub_q<1, QS>(qya, py[u]);
+            pxy[u][kk + 1] = ax * ax + ay * ay;
+            ax = pk_sub_q<0, QS>(qxb, px[u]); ay = pk_sub_q<0, QS>(qyb, py[u]);
+            pxy[u][kk + 2] = ax * ax + ay * ay;
+            ax = pk_sub_q<1, QS>(qxb, px[u]); ay = pk_sub_q<1, QS>(qyb, py[u]);
+            pxy[u][kk + 3] = ax * ax + ay * ay;
+            mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk].x), pxy[u][kk + 1].x);
+            mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk + 2].x), pxy[u][kk + 3].x);
+            mxy[2 * u + 1] = fmin_(fmin_(mxy[2 * u + 1], pxy[u][kk].y), pxy[u][kk + 1].y);
+            mxy[2 * u + 1] = fmin_(fmin_(mxy[2 * u + 1], pxy[u][kk + 2].y), pxy[u][kk + 3].y);
+        }
+    }
+    bool need = false;
+#pragma unroll
+    for (int t = 0; t < 2 * TP; ++t) need |= mxy[t] < best[t];
+    if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;  // wave-uniform early-out
+#pragma unroll
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qz4 = *reinterpret_cast<const float4*>(qzp + kk);
+        const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            f2 az;
+            az = pk_sub_q<0, QS>(qza, pz[u]); const f2 d0 = pxy[u][kk + 0] + az * az;
+            az = pk_sub_q<1, QS>(qza, pz[u]); const f2 d1 = pxy[u][kk + 1] + az * az;
+            az = pk_sub_q<0, QS>(qzb, pz[u]); const f2 d2 = pxy[u][kk + 2] + az * az;
+            az = pk_sub_q<1, QS>(qzb, pz[u]); const f2 d3 = pxy[u][kk + 3] + az * az;
+            best[2 * u] = fmin_(fmin_(best[2 * u], d0.x), d1.x);
+            best[2 * u] = fmin_(fmin_(best[2 * u], d2.x), d3.x);
+            best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d0.y), d1.y);
+            best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d2.y), d3.y);
+        }
+    }
+}
+
+// lower bound of every reference distance between the lane's points and a box: per axis
+// g = max(lo - p, p - hi, 0) <= |q - p| for every q inside, rounding is monotonic, and L uses the reference's own
+// association (gx*gx + gy*gy) + gz*gz, so L <= d operation by operation; the 2^-20 shave is belt and braces.
+template <int TP, bool LE = false /*ties count: the chunks are not visited in ascending order*/>
+__device__ __forceinline__ bool box_may_improve(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                                const f2 (&px)[TP], const f2 (&py)[TP], const f2 (&pz)[TP],
+                                                const float (&best)[2 * TP])
+{
+    bool needb = false;
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        const f2 ax = f2{lox, lox} - px[u], bxx = px[u] - f2{hix, hix};
+        const f2 ay = f2{loy, loy} - py[u], byy = py[u] - f2{hiy, hiy};
+        const f2 az = f2{loz, loz} - pz[u], bzz = pz[u] - f2{hiz, hiz};
+        f2 gx = f2{__builtin_fmaxf(__builtin_fmaxf(ax.x, bxx.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ax.y, bxx.y), 0.f)};
+        f2 gy = f2{__builtin_fmaxf(__builtin_fmaxf(ay.x, byy.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ay.y, byy.y), 0.f)};
+        f2 gz = f2{__builtin_fmaxf(__builtin_fmaxf(az.x, bzz.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(az.y, bzz.y), 0.f)};
+        f2 L = (gx * gx + gy * gy) + gz * gz;
+        L = L * f2{0.99999905f, 0.99999905f};  // 1 - 2^-20
+        if constexpr (LE) needb |= (L.x <= best[2 * u]) | (L.y <= best[2 * u + 1]);
+        else needb |= (L.x < best[2 * u]) | (L.y < best[2 * u + 1]);
+    }
+    return needb;
+}
 
 // Optional fused TAIL of the matching kernel (TAIL = 1 point-to-point, 2 point-to-plane): instead of leaving
 // per-segment (d, idx) partials for a second kernel, every block folds its result into one 64-bit key per moving
@@ -314,9 +435,20 @@ struct NNFuse {
                              // tightens the starting bound, the result does not depend on it
     const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
     const float* boxes;      // CULL kernels: per 8-point chunk of the scan copy {lo.xyz, hi.xyz, -, -} (or NULL)
+    const float* samples;    // sparse kernel: one point per chunk of the scan copy (SoA, round_up(m_pad/8, 8) entries) or NULL
+    long long* tlog;         // diagnostic (ICP_NN_PHASES): per-wave s_memrealtime stamps, 10 slots per wave, or NULL
+    long long tlog_cap;      // slots available
 };
 
-template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/, bool CULL /*seeded bound + xy early-out*/, int TAIL = 0>
+// phase stamp of the diagnostic log: one scalar branch when the log is off
+#define ICP_PHASE(PH)                                                                                              \
+    if (fuse.tlog != nullptr && lane == 0) {                                                                       \
+        const long long slot_ = (((long long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + w) * 10 + (PH);            \
+        if (slot_ < fuse.tlog_cap) fuse.tlog[slot_] = (long long)wall_clock64();                                   \
+    }
+
+template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/, int CULL /*0: plain; 1: seeded bound + box/xy early-out over LDS tiles;
+            2: sparse -- lane-parallel box test picks the chunks, q through the scalar cache, no tile*/, int TAIL = 0>
 __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(const float* __restrict__ P, int n_pad,
                                                                const float* __restrict__ Q, int m_pad, int seg_len,
                                                                float* __restrict__ part_d,
@@ -324,8 +456,9 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
                                                                NNFuse fuse, NNTail tail)
 {
     constexpr int TP = T / 2;  // packed pairs of moving points per lane
+    static_assert(CULL != 2 || (T == 2 && C == 8), "the sparse scan is written for one packed pair per lane and 8-point chunks");
     // one raw LDS block, carved by hand: the tail's transpose buffer overlays the tile + merge scratch
-    constexpr int SQ_BYTES = 4 * 3 * NN2_TQW * 4, MD_BYTES = 4 * 64 * T * 4;
+    constexpr int SQ_BYTES = CULL == 2 ? 0 : 4 * 3 * NN2_TQW * 4, MD_BYTES = 4 * 64 * T * 4;
     constexpr int TR_BYTES = TAIL ? (TAIL == 2 ? 28 : 18) * 65 * 8 : 0;
     constexpr int LDS_BYTES = (SQ_BYTES + 2 * MD_BYTES + 16) > TR_BYTES ? (SQ_BYTES + 2 * MD_BYTES + 16) : TR_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -347,6 +480,7 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
     f2 px[TP], py[TP], pz[TP];
     float best[T];
     int cst[T];
+    ICP_PHASE(0)
 #pragma unroll
     for (int u = 0; u < TP; ++u) {
         const int i0 = ibase + (2 * u) * 64, i1 = i0 + 64;
@@ -389,6 +523,7 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
             }
         }
     }
+    ICP_PHASE(1)
 #pragma unroll
     for (int t = 0; t < T; ++t) { best[t] = inf_<float>(); cst[t] = -1; }
     if constexpr (CULL) {
@@ -410,10 +545,64 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
                 const float d = dist2<float>(x, y, z, Qg[j], Qg[(size_t)m_pad + j], Qg[2 * (size_t)m_pad + j]);
                 // next float above d (d >= 0, finite): bit pattern + 1; inf stays inf
                 best[t] = (ok && d < inf_<float>()) ? __uint_as_float(__float_as_uint(d) + 1u) : inf_<float>();
+                // padding lanes can never improve on a bound of zero: they cost no chunk visits (their result,
+                // "nothing found", is never read)
+                best[t] = (i < fuse.n) ? best[t] : 0.f;
             }
         }
     }
 
+    ICP_PHASE(2)
+    if constexpr (CULL == 2) {
+        // Sparse scan.  The wave's 128 moving points have a bounding box G and a largest running bound B; a chunk
+        // whose box lies at least B away from G cannot lower any lane's minimum.  That test does not involve the
+        // individual points, so it runs LANE-PARALLEL -- lane l tests chunk l, 64 chunks for ~25 VALU ops instead
+        // of 64 x 20 -- and its ballot is the list of chunks worth visiting.  The few survivors go through the
+        // per-point box test and the xy early-out as before; their coordinates arrive through the scalar cache
+        // (wave-uniform address), so this variant has no LDS tile, no fill and no barrier before the merge.
+        float glo[3], ghi[3];
+        glo[0] = wave_minmax<false>(__builtin_fminf(px[0].x, px[0].y)); ghi[0] = wave_minmax<true>(__builtin_fmaxf(px[0].x, px[0].y));
+        glo[1] = wave_minmax<false>(__builtin_fminf(py[0].x, py[0].y)); ghi[1] = wave_minmax<true>(__builtin_fmaxf(py[0].x, py[0].y));
+        glo[2] = wave_minmax<false>(__builtin_fminf(pz[0].x, pz[0].y)); ghi[2] = wave_minmax<true>(__builtin_fmaxf(pz[0].x, pz[0].y));
+        const int cb0 = my0 / C;
+        const int nch = (my1 - my0) / C;  // <= 0 for an empty range
+        for (int cbase = 0; cbase < nch; cbase += 64) {
+            // B only shrinks while the wave works: refreshed once per 64 chunks
+            const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
+            const bool valid = cbase + lane < nch;
+            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cb0 + (valid ? cbase + lane : 0)) * 8);
+            const float4 b0 = bp[0], b1 = bp[1];  // lo.xyz hi.x | hi.yz - -
+            const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - ghi[0], glo[0] - b0.w), 0.f);
+            const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - ghi[1], glo[1] - b1.x), 0.f);
+            const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - ghi[2], glo[2] - b1.y), 0.f);
+            const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(valid && L < B);
+            while (todo != 0ull) {
+                const int bsel = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int ch = cb0 + cbase + bsel;  // wave-uniform
+                const float lox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0.x), bsel));
+                const float loy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0.y), bsel));
+                const float loz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0.z), bsel));
+                const float hix = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0.w), bsel));
+                const float hiy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1.x), bsel));
+                const float hiz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1.y), bsel));
+                if (__builtin_amdgcn_ballot_w64(box_may_improve<TP>(lox, loy, loz, hix, hiy, hiz, px, py, pz, best)) == 0ull) continue;
+                float bo[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) bo[t] = best[t];
+                const float* qc = Q + (size_t)ch * C;
+                scan_chunk_xy_cull<TP, C, true>(qc, qc + m_pad, qc + 2 * (size_t)m_pad, px, py, pz, best);
+                bool any = false;
+#pragma unroll
+                for (int t = 0; t < T; ++t) any |= best[t] < bo[t];
+                if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) cst[t] = (best[t] < bo[t]) ? ch : cst[t];
+                }
+            }
+        }
+    } else {
     const int ntile = (wseg + NN2_TQW - 1) / NN2_TQW;
     for (int k = 0; k < ntile; ++k) {
         __syncthreads();
@@ -437,80 +626,14 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
 #pragma unroll
             for (int t = 0; t < T; ++t) bo[t] = best[t];
             if constexpr (CULL) {
-                // level 0: the chunk's bounding box (precomputed once per model over the scan copy).  Per axis
-                // gap = max(lo - p, p - hi, 0) <= |q - p| for every q of the chunk, so L = (gx^2 + gy^2) + gz^2 is a
-                // lower bound of every distance in the chunk; shaved by 2^-20 it stays one under the reference's
-                // rounding of those distances.  ~20 VALU ops per chunk and lane pair instead of ~50, wave-uniform skip.
+                // level 0: the chunk's bounding box (precomputed once per model over the scan copy): ~20 VALU ops
+                // per chunk and lane pair instead of ~50, wave-uniform skip; then the xy early-out
                 if (fuse.boxes) {
                     const float* bx = fuse.boxes + (size_t)((tile0 + c) / C) * 8;  // scalar address -> s_load
-                    const float lox = bx[0], loy = bx[1], loz = bx[2], hix = bx[3], hiy = bx[4], hiz = bx[5];
-                    bool needb = false;
-#pragma unroll
-                    for (int u = 0; u < TP; ++u) {
-                        const f2 ax = f2{lox, lox} - px[u], bxx = px[u] - f2{hix, hix};
-                        const f2 ay = f2{loy, loy} - py[u], byy = py[u] - f2{hiy, hiy};
-                        const f2 az = f2{loz, loz} - pz[u], bzz = pz[u] - f2{hiz, hiz};
-                        f2 gx = f2{__builtin_fmaxf(__builtin_fmaxf(ax.x, bxx.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ax.y, bxx.y), 0.f)};
-                        f2 gy = f2{__builtin_fmaxf(__builtin_fmaxf(ay.x, byy.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ay.y, byy.y), 0.f)};
-                        f2 gz = f2{__builtin_fmaxf(__builtin_fmaxf(az.x, bzz.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(az.y, bzz.y), 0.f)};
-                        f2 L = (gx * gx + gy * gy) + gz * gz;
-                        L = L * f2{0.99999905f, 0.99999905f};  // 1 - 2^-20
-                        needb |= (L.x < best[2 * u]) | (L.y < best[2 * u + 1]);
-                    }
-                    if (__builtin_amdgcn_ballot_w64(needb) == 0ull) continue;
+                    if (__builtin_amdgcn_ballot_w64(box_may_improve<TP>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], px, py, pz, best)) == 0ull)
+                        continue;
                 }
-                // phase A: the inner sum of the reference's association, pxy = dx*dx + dy*dy, for the whole
-                // chunk.  d = fl(pxy + dz*dz) >= pxy, so a chunk whose smallest pxy is not below any lane's
-                // running minimum cannot lower it (nor win a tie: ascending order, strict <) -- skip its z half.
-                f2 pxy[TP][C];
-                float mxy[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) mxy[t] = inf_<float>();
-#pragma unroll
-                for (int kk = 0; kk < C; kk += 4) {
-                    const float4 qx4 = *reinterpret_cast<const float4*>(&sq[w][0][c + kk]);
-                    const float4 qy4 = *reinterpret_cast<const float4*>(&sq[w][1][c + kk]);
-                    const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
-                    const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
-#pragma unroll
-                    for (int u = 0; u < TP; ++u) {
-                        f2 ax, ay;
-                        ax = pk_sub_bcast<0>(qxa, px[u]); ay = pk_sub_bcast<0>(qya, py[u]);
-                        pxy[u][kk + 0] = ax * ax + ay * ay;
-                        ax = pk_sub_bcast<1>(qxa, px[u]); ay = pk_sub_bcast<1>(qya, py[u]);
-                        pxy[u][kk + 1] = ax * ax + ay * ay;
-                        ax = pk_sub_bcast<0>(qxb, px[u]); ay = pk_sub_bcast<0>(qyb, py[u]);
-                        pxy[u][kk + 2] = ax * ax + ay * ay;
-                        ax = pk_sub_bcast<1>(qxb, px[u]); ay = pk_sub_bcast<1>(qyb, py[u]);
-                        pxy[u][kk + 3] = ax * ax + ay * ay;
-                        mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk].x), pxy[u][kk + 1].x);
-                        mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk + 2].x), pxy[u][kk + 3].x);
-                        mxy[2 * u + 1] = fmin_(fmin_(mxy[2 * u + 1], pxy[u][kk].y), pxy[u][kk + 1].y);
-                        mxy[2 * u + 1] = fmin_(fmin_(mxy[2 * u + 1], pxy[u][kk + 2].y), pxy[u][kk + 3].y);
-                    }
-                }
-                bool need = false;
-#pragma unroll
-                for (int t = 0; t < T; ++t) need |= mxy[t] < best[t];
-                if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;  // wave-uniform early-out
-                // phase B: finish the chunk exactly as the un-culled kernel would have
-#pragma unroll
-                for (int kk = 0; kk < C; kk += 4) {
-                    const float4 qz4 = *reinterpret_cast<const float4*>(&sq[w][2][c + kk]);
-                    const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
-#pragma unroll
-                    for (int u = 0; u < TP; ++u) {
-                        f2 az;
-                        az = pk_sub_bcast<0>(qza, pz[u]); const f2 d0 = pxy[u][kk + 0] + az * az;
-                        az = pk_sub_bcast<1>(qza, pz[u]); const f2 d1 = pxy[u][kk + 1] + az * az;
-                        az = pk_sub_bcast<0>(qzb, pz[u]); const f2 d2 = pxy[u][kk + 2] + az * az;
-                        az = pk_sub_bcast<1>(qzb, pz[u]); const f2 d3 = pxy[u][kk + 3] + az * az;
-                        best[2 * u] = fmin_(fmin_(best[2 * u], d0.x), d1.x);
-                        best[2 * u] = fmin_(fmin_(best[2 * u], d2.x), d3.x);
-                        best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d0.y), d1.y);
-                        best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d2.y), d3.y);
-                    }
-                }
+                scan_chunk_xy_cull<TP, C, false>(&sq[w][0][c], &sq[w][1][c], &sq[w][2][c], px, py, pz, best);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < C; kk += 4) {
@@ -543,6 +666,8 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
             }
         }
     }
+    }  // tile scan
+    ICP_PHASE(3)
 
     // index recovery inside the winning chunk (lowest j with d_j == min), then the in-block merge
 #pragma unroll
@@ -566,7 +691,9 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
         md[w][lane + t * 64] = b;
         mi[w][lane + t * 64] = idx;
     }
+    ICP_PHASE(4)
     __syncthreads();
+    ICP_PHASE(5)
     if (threadIdx.x < 64 * T) {
         float b = md[0][threadIdx.x];
         int bi = mi[0][threadIdx.x];
@@ -590,12 +717,14 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
         static_assert(TAIL == 0 || T == 2, "the fused tail is written for two moving points per lane");
         // every wave drains its atomics, the block meets, one lane draws the row's ticket
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ICP_PHASE(6)
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned int ticket = __hip_atomic_fetch_add(&tail.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *s_flag = (ticket == gridDim.y - 1) ? 1 : 0;
         }
         __syncthreads();
+        ICP_PHASE(7)
         if (*s_flag == 0 || w != 0) return;  // only wave 0 of the row's last block goes on (the LDS is all its own now)
 
         constexpr int NACC = TAIL == 2 ? 28 : 18;
@@ -661,8 +790,453 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
         }
         __threadfence_system();  // the row is visible to a polling host before its tag
         if (lane == 0) row[ICP_NMOM - 1] = tail.tag;
+        ICP_PHASE(8)
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// matching, fp32, sparse -- the shipped kernel whenever the model has chunk boxes.
+//
+// The phase log of the tiled early-out kernel (ICP_NN_PHASES) showed what was left once ~99 % of the chunks
+// were being skipped: the chunks that do survive all sit in the range of ONE wave of the 64 that share a group
+// of moving points, and that wave worked through them alone (median scan 1 us, slowest 17 us of a 27 us kernel).
+// This kernel separates FINDING the surviving chunks from PROCESSING them:
+//   * a block is SP_NW waves that all hold the same 128 moving points (two per lane, packed);
+//   * find: the bounding box G of the 128 points and their largest running bound B are wave-uniform, so the
+//     test "chunk box closer to G than B" runs lane-parallel -- lane l tests chunk l, 64 chunks per ~25 VALU ops;
+//     survivors are appended to a hit list in LDS;
+//   * process: the hits are dealt round-robin to the waves.  Each goes through the per-point box test and the
+//     xy early-out as before; its coordinates arrive through the scalar cache (wave-uniform address).
+// The list is unordered (atomic append), so the tie rule is explicit here instead of implied by scan order:
+// a chunk takes a point's minimum if its own minimum is smaller, or equal with a lower chunk number; the
+// pruning tests therefore let ties through (<=).  Between rounds of the find step the waves exchange their
+// minima through LDS and restart from the best one bumped by an ulp (the seeded-bound argument again), which is
+// what makes an unseeded (cold) pass converge quickly too.  Results are bit-identical to the plain scan.
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_NW = 16;                       // waves per block
+constexpr int SP_HCAP = 4096;                   // hit-list entries = chunks per round (SP_NW * 64 * passes <= this)
+constexpr int SP_MAX_PASSES = SP_HCAP / (SP_NW * 64);
+
+// one hit chunk against the lane's packed pair; (best, cst) follow the lexicographic (distance, chunk) rule
+template <bool QS>
+__device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const float* qyp, const float* qzp, const f2 px,
+                                                     const f2 py, const f2 pz, int ch, float (&best)[2], int (&cst)[2])
+{
+    constexpr int C = 8;
+    f2 pxy[C];
+    float mxy0 = inf_<float>(), mxy1 = inf_<float>();
+#pragma unroll
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qx4 = *reinterpret_cast<const float4*>(qxp + kk);
+        const float4 qy4 = *reinterpret_cast<const float4*>(qyp + kk);
+        const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+        const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+        f2 ax, ay;
+        ax = pk_sub_q<0, QS>(qxa, px); ay = pk_sub_q<0, QS>(qya, py);
+        pxy[kk + 0] = ax * ax + ay * ay;
+        ax = pk_sub_q<1, QS>(qxa, px); ay = pk_sub_q<1, QS>(qya, py);
+        pxy[kk + 1] = ax * ax + ay * ay;
+        ax = pk_sub_q<0, QS>(qxb, px); ay = pk_sub_q<0, QS>(qyb, py);
+        pxy[kk + 2] = ax * ax + ay * ay;
+        ax = pk_sub_q<1, QS>(qxb, px); ay = pk_sub_q<1, QS>(qyb, py);
+        pxy[kk + 3] = ax * ax + ay * ay;
+        mxy0 = fmin_(fmin_(mxy0, pxy[kk].x), pxy[kk + 1].x);
+        mxy0 = fmin_(fmin_(mxy0, pxy[kk + 2].x), pxy[kk + 3].x);
+        mxy1 = fmin_(fmin_(mxy1, pxy[kk].y), pxy[kk + 1].y);
+        mxy1 = fmin_(fmin_(mxy1, pxy[kk + 2].y), pxy[kk + 3].y);
+    }
+    if (__builtin_amdgcn_ballot_w64((mxy0 <= best[0]) | (mxy1 <= best[1])) == 0ull) return;
+    float c0 = inf_<float>(), c1 = inf_<float>();  // the chunk's own minima
+#pragma unroll
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qz4 = *reinterpret_cast<const float4*>(qzp + kk);
+        const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+        f2 az;
+        az = pk_sub_q<0, QS>(qza, pz); const f2 d0 = pxy[kk + 0] + az * az;
+        az = pk_sub_q<1, QS>(qza, pz); const f2 d1 = pxy[kk + 1] + az * az;
+        az = pk_sub_q<0, QS>(qzb, pz); const f2 d2 = pxy[kk + 2] + az * az;
+        az = pk_sub_q<1, QS>(qzb, pz); const f2 d3 = pxy[kk + 3] + az * az;
+        c0 = fmin_(fmin_(c0, d0.x), d1.x);
+        c0 = fmin_(fmin_(c0, d2.x), d3.x);
+        c1 = fmin_(fmin_(c1, d0.y), d1.y);
+        c1 = fmin_(fmin_(c1, d2.y), d3.y);
+    }
+    const bool take0 = (c0 < best[0]) | ((c0 == best[0]) & (ch < cst[0]));
+    const bool take1 = (c1 < best[1]) | ((c1 == best[1]) & (ch < cst[1]));
+    if (__builtin_amdgcn_ballot_w64(take0 | take1) != 0ull) {
+        best[0] = take0 ? c0 : best[0];
+        cst[0] = take0 ? ch : cst[0];
+        best[1] = take1 ? c1 : best[1];
+        cst[1] = take1 ? ch : cst[1];
+    }
+}
+
+// distances from the lane's packed pair to 8 model points held in SGPRs, folded into running minima (no index)
+__device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, const float4 qy0, const float4 qy1,
+                                          const float4 qz0, const float4 qz1, const f2 px, const f2 py, const f2 pz,
+                                          float (&best)[2])
+{
+    const f2 qx[4] = {f2{qx0.x, qx0.y}, f2{qx0.z, qx0.w}, f2{qx1.x, qx1.y}, f2{qx1.z, qx1.w}};
+    const f2 qy[4] = {f2{qy0.x, qy0.y}, f2{qy0.z, qy0.w}, f2{qy1.x, qy1.y}, f2{qy1.z, qy1.w}};
+    const f2 qz[4] = {f2{qz0.x, qz0.y}, f2{qz0.z, qz0.w}, f2{qz1.x, qz1.y}, f2{qz1.z, qz1.w}};
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        f2 ax, ay, az;
+        ax = pk_sub_bcast_s<0>(qx[k], px); ay = pk_sub_bcast_s<0>(qy[k], py); az = pk_sub_bcast_s<0>(qz[k], pz);
+        const f2 d0 = (ax * ax + ay * ay) + az * az;
+        ax = pk_sub_bcast_s<1>(qx[k], px); ay = pk_sub_bcast_s<1>(qy[k], py); az = pk_sub_bcast_s<1>(qz[k], pz);
+        const f2 d1 = (ax * ax + ay * ay) + az * az;
+        ax = pk_sub_bcast_s<0>(qx[k + 1], px); ay = pk_sub_bcast_s<0>(qy[k + 1], py); az = pk_sub_bcast_s<0>(qz[k + 1], pz);
+        const f2 d2 = (ax * ax + ay * ay) + az * az;
+        ax = pk_sub_bcast_s<1>(qx[k + 1], px); ay = pk_sub_bcast_s<1>(qy[k + 1], py); az = pk_sub_bcast_s<1>(qz[k + 1], pz);
+        const f2 d3 = (ax * ax + ay * ay) + az * az;
+        best[0] = fmin_(fmin_(best[0], d0.x), d1.x);
+        best[0] = fmin_(fmin_(best[0], d2.x), d3.x);
+        best[1] = fmin_(fmin_(best[1], d0.y), d1.y);
+        best[1] = fmin_(fmin_(best[1], d2.y), d3.y);
+    }
+}
+
+// moment row of one row of 128 moving points, by ONE wave holding them two per lane (px.x = point lane,
+// px.y = point lane + 64) with their final correspondences j[]: stores idx, gathers q (and the normal),
+// accumulates in fp64, reduces through LDS in lane order and writes the row + completion tag.
+template <int TAIL>
+__device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f2 pz, const int (&j)[2], int lane, int ibase,
+                                               int m_pad, const NNFuse& fuse, const NNTail& tail, double err_row,
+                                               unsigned char* lds_raw)
+{
+    constexpr int w = 0;  // (phase log) the closing wave
+    constexpr int NACC = TAIL == 2 ? 28 : 18;
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    const float* Qg = fuse.Q_gather;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = ibase + t * 64;
+        if (i < fuse.n) {
+            const int jj = j[t];
+            tail.idx_out[i] = jj;
+            const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
+            const double qx = (double)Qg[jj], qy = (double)Qg[(size_t)m_pad + jj], qz = (double)Qg[2 * (size_t)m_pad + jj];
+            acc[0] += 1.0;
+            if constexpr (TAIL == 1) {
+                acc[1] += ppx; acc[2] += ppy; acc[3] += ppz;
+                acc[4] += qx; acc[5] += qy; acc[6] += qz;
+                acc[7] += qx * ppx; acc[8] += qx * ppy; acc[9] += qx * ppz;
+                acc[10] += qy * ppx; acc[11] += qy * ppy; acc[12] += qy * ppz;
+                acc[13] += qz * ppx; acc[14] += qz * ppy; acc[15] += qz * ppz;
+                acc[16] += ppx * ppx + ppy * ppy + ppz * ppz;
+                acc[17] += qx * qx + qy * qy + qz * qz;
+            } else {
+                const double nx = (double)tail.Nrm[jj], ny = (double)tail.Nrm[(size_t)m_pad + jj],
+                             nz = (double)tail.Nrm[2 * (size_t)m_pad + jj];
+                double cn[6];
+                cn[0] = ppy * nz - ppz * ny;
+                cn[1] = ppz * nx - ppx * nz;
+                cn[2] = ppx * ny - ppy * nx;
+                cn[3] = nx; cn[4] = ny; cn[5] = nz;
+                const double bb = (ppx - qx) * nx + (ppy - qy) * ny + (ppz - qz) * nz;
+                int o = 1;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int c2 = a; c2 < 6; ++c2) acc[o++] += cn[a] * cn[c2];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc[22 + a] -= cn[a] * bb;
+            }
+        }
+    }
+    // one wave: transpose through LDS (rows padded to 65 doubles), lane k adds slot k in lane order
+    double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // same wave: DS ops are in order; this pins the compiler
+    double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
+    if (lane < NACC) {
+        double sum = 0.0;
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) sum += tr[lane][l];
+        row[1 + lane] = sum;
+    }
+    if (lane == 0) row[ICP_MOM_ERR] = err_row;
+    ICP_PHASE(8)
+    __threadfence_system();  // the row is visible to a polling host before its tag
+    if (lane == 0) row[ICP_NMOM - 1] = tail.tag;
+}
+
+template <int TAIL>
+__global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __restrict__ P, int n_pad,
+                                                              const float* __restrict__ Q, int m_pad, int seg_len,
+                                                              int round_passes, float* __restrict__ part_d,
+                                                              int32_t* __restrict__ part_idx, RT<float> rt, NNFuse fuse,
+                                                              NNTail tail)
+{
+    constexpr int HITS_BYTES = SP_HCAP * 4, MD_BYTES = SP_NW * 128 * 4;
+    constexpr int TR_BYTES = TAIL ? (TAIL == 2 ? 28 : 18) * 65 * 8 : 0;
+    static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16];
+    int* hits = reinterpret_cast<int*>(lds_raw);
+    float (*md)[128] = reinterpret_cast<float (*)[128]>(lds_raw + HITS_BYTES);
+    int (*mi)[128] = reinterpret_cast<int (*)[128]>(lds_raw + HITS_BYTES + MD_BYTES);
+    unsigned int* smin = reinterpret_cast<unsigned int*>(lds_raw + HITS_BYTES + 2 * MD_BYTES);
+    int* hcount = reinterpret_cast<int*>(lds_raw + HITS_BYTES + 2 * MD_BYTES + 128 * 4);
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ibase = blockIdx.x * 128 + lane;
+    ICP_PHASE(0)
+    f2 px, py, pz;
+    px = f2{P[ibase], P[ibase + 64]};
+    py = f2{P[(size_t)n_pad + ibase], P[(size_t)n_pad + ibase + 64]};
+    pz = f2{P[2 * (size_t)n_pad + ibase], P[2 * (size_t)n_pad + ibase + 64]};
+    double err_row = 0.0;
+    if (fuse.apply) {
+        // every wave re-derives the moved points in registers (same instructions => same bits); wave 0 of the
+        // grid.y == 0 block stores them and accounts the error of the pass that produced (R, t)
+        double err = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
+            apply_rt<float>(rt, x, y, z, x, y, z);
+            if (t) { px.y = x; py.y = y; pz.y = z; } else { px.x = x; py.x = y; pz.x = z; }
+            if (blockIdx.y == 0 && w == 0) {
+                const int i = ibase + t * 64;
+                fuse.P_out[i] = x;
+                fuse.P_out[(size_t)n_pad + i] = y;
+                fuse.P_out[2 * (size_t)n_pad + i] = z;
+                if (i < fuse.n) {
+                    const int j = fuse.idx_prev[i];
+                    const float* Qg = fuse.Q_gather;
+                    const double ex = (double)Qg[j] - (double)x;
+                    const double ey = (double)Qg[(size_t)m_pad + j] - (double)y;
+                    const double ez = (double)Qg[2 * (size_t)m_pad + j] - (double)z;
+                    err += ex * ex + ey * ey + ez * ez;
+                }
+            }
+        }
+        if (blockIdx.y == 0 && w == 0) {
+            err_row = wave_sum(err);
+            if (lane == 0) {
+                if constexpr (TAIL != 0) {
+                    // read by whichever block closes this row: agent-scope store, drained before our ticket
+                    if (gridDim.y > 1) __hip_atomic_store(&tail.err_tile[blockIdx.x], err_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    fuse.err_rows[blockIdx.x] = err_row;
+                }
+            }
+        }
+    }
+    ICP_PHASE(1)
+    float best[2];
+    int cst[2];
+    bool real[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = ibase + t * 64;
+        real[t] = i < fuse.n;
+        cst[t] = -1;
+        best[t] = inf_<float>();
+        if (fuse.seed_idx) {
+            // seeded bound: the distance to ANY model point (last pass's match) bumped by one ulp -- the true minimum
+            // is <= that distance < bound, so the seed changes how much work is skipped, never the answer
+            const float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
+            int j = real[t] ? fuse.seed_idx[i] : -1;
+            const bool ok = (unsigned)j < (unsigned)fuse.m;  // a seed is trusted only if it is a real model index
+            j = ok ? j : 0;
+            const float* Qg = fuse.Q_gather;
+            const float d = dist2<float>(x, y, z, Qg[j], Qg[(size_t)m_pad + j], Qg[2 * (size_t)m_pad + j]);
+            best[t] = (ok && d < inf_<float>()) ? __uint_as_float(__float_as_uint(d) + 1u) : inf_<float>();
+        }
+        // padding lanes never ask for a chunk (their result, "nothing found", is never read)
+        best[t] = real[t] ? best[t] : -1.f;
+    }
+    if (threadIdx.x < 128) smin[threadIdx.x] = 0x7f800000u;
+    if (threadIdx.x == 0) *hcount = 0;
+    if (fuse.seed_idx == nullptr && fuse.samples != nullptr) {
+        // Cold start: no previous match to seed the bounds, so the block measures its points against a thinned-out
+        // model first -- one point per chunk, at most ~4096 of them, a share per wave -- and every wave starts
+        // from the block-wide minimum bumped by an ulp.  Any model point gives a valid bound; the scan below is
+        // then as selective as a seeded one.
+        const int ns8 = ((m_pad / 8) + 7) / 8;                 // groups of 8 samples
+        const int ns_pad = ns8 * 8;
+        const int gs = (ns8 + 511) / 512;                      // group stride: <= 512 groups are visited
+        float sb[2] = {inf_<float>(), inf_<float>()};
+        const float* sx = fuse.samples;
+        int g = w * gs;
+        if (g < ns8) {
+            const float4* a = reinterpret_cast<const float4*>(sx + (size_t)g * 8);
+            const float4* b = reinterpret_cast<const float4*>(sx + (size_t)ns_pad + (size_t)g * 8);
+            const float4* c = reinterpret_cast<const float4*>(sx + 2 * (size_t)ns_pad + (size_t)g * 8);
+            float4 x0 = a[0], x1 = a[1], y0 = b[0], y1 = b[1], z0 = c[0], z1 = c[1];
+            for (;;) {
+                const int gn = g + SP_NW * gs;
+                const bool more = gn < ns8;
+                const int gl = more ? gn : g;                  // the prefetch of the last turn re-reads its own group
+                a = reinterpret_cast<const float4*>(sx + (size_t)gl * 8);
+                b = reinterpret_cast<const float4*>(sx + (size_t)ns_pad + (size_t)gl * 8);
+                c = reinterpret_cast<const float4*>(sx + 2 * (size_t)ns_pad + (size_t)gl * 8);
+                const float4 nx0 = a[0], nx1 = a[1], ny0 = b[0], ny1 = b[1], nz0 = c[0], nz1 = c[1];
+                scan8_min(x0, x1, y0, y1, z0, z1, px, py, pz, sb);
+                if (!more) break;
+                x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1; z0 = nz0; z1 = nz1;
+                g = gn;
+            }
+        }
+        if (real[0]) atomicMin(&smin[lane], __float_as_uint(sb[0]));
+        if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(sb[1]));
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned int v = smin[lane + t * 64];
+            if (real[t] && v < 0x7f800000u) best[t] = __uint_as_float(v + 1u);
+        }
+    }
+    ICP_PHASE(2)
+
+    // bounding box of the block's 128 moving points (every wave derives the same one)
+    float glo[3], ghi[3];
+    glo[0] = wave_minmax<false>(__builtin_fminf(px.x, px.y)); ghi[0] = wave_minmax<true>(__builtin_fmaxf(px.x, px.y));
+    glo[1] = wave_minmax<false>(__builtin_fminf(py.x, py.y)); ghi[1] = wave_minmax<true>(__builtin_fmaxf(py.x, py.y));
+    glo[2] = wave_minmax<false>(__builtin_fminf(pz.x, pz.y)); ghi[2] = wave_minmax<true>(__builtin_fmaxf(pz.x, pz.y));
+
+    const int q0 = blockIdx.y * seg_len;
+    const int c_lo = q0 / 8, c_hi = min(q0 + seg_len, m_pad) / 8;
+    const int round_chunks = SP_NW * 64 * round_passes;
+    for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
+        // B only shrinks while the block works: refreshed once per round
+        const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
+        __syncthreads();  // the list is empty and its counter reset
+        for (int r = 0; r < round_passes; ++r) {
+            const int c0 = rb + (r * SP_NW + w) * 64;
+            if (c0 >= c_hi) break;
+            const int cidx = c0 + lane;
+            const bool valid = cidx < c_hi;
+            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(valid ? cidx : c_lo) * 8);
+            const float4 b0 = bp[0], b1 = bp[1];  // lo.xyz hi.x | hi.yz - -
+            const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - ghi[0], glo[0] - b0.w), 0.f);
+            const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - ghi[1], glo[1] - b1.x), 0.f);
+            const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - ghi[2], glo[2] - b1.y), 0.f);
+            const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;
+            const bool pass = valid && L < B;  // every candidate winner lies strictly below its point's starting bound
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+            if (mask != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(hcount, (int)__builtin_popcountll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (pass) hits[base + rank] = cidx;
+            }
+        }
+        __syncthreads();
+        const int H = *hcount;
+        for (int h = w; h < H; h += SP_NW) {
+            const int ch = __builtin_amdgcn_readfirstlane(hits[h]);
+            const float* bx = fuse.boxes + (size_t)ch * 8;
+            const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
+            if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], pxa, pya, pza, best)) == 0ull)
+                continue;
+            const float* qc = Q + (size_t)ch * 8;
+            scan_chunk_unordered<true>(qc, qc + m_pad, qc + 2 * (size_t)m_pad, px, py, pz, ch, best, cst);
+        }
+        if (rb + round_chunks < c_hi) {
+            // exchange: every wave restarts the next round from the block's best minimum so far, bumped by an ulp
+            // (d >= 0: the bit patterns order like the values, so this is an integer min)
+            if (real[0]) atomicMin(&smin[lane], __float_as_uint(best[0]));
+            if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(best[1]));
+            __syncthreads();
+            if (threadIdx.x == 0) *hcount = 0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned int v = smin[lane + t * 64];
+                if (real[t] && v < 0x7f800000u && v < __float_as_uint(best[t])) { best[t] = __uint_as_float(v + 1u); cst[t] = -1; }
+            }
+        }
+    }
+    ICP_PHASE(3)
+
+    // index recovery inside the winning chunk (lowest j with d_j == min), then the in-block merge
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float pxt = t ? px.y : px.x, pyt = t ? py.y : py.x, pzt = t ? pz.y : pz.x;
+        const bool found = cst[t] >= 0;  // this wave lowered the (possibly seeded or exchanged) bound at least once
+        const int base = found ? cst[t] * 8 : 0;
+        int idx = 0x7fffffff;
+        const float b = found ? best[t] : inf_<float>();
+        if (found) {
+            idx = base;
+#pragma unroll 4
+            for (int kk = 7; kk >= 0; --kk) {
+                const int j = base + kk;
+                const float d = dist2<float>(pxt, pyt, pzt, Q[j], Q[(size_t)m_pad + j], Q[2 * (size_t)m_pad + j]);
+                idx = (d == b) ? j : idx;
+            }
+        }
+        md[w][lane + t * 64] = b;
+        mi[w][lane + t * 64] = idx;
+    }
+    ICP_PHASE(4)
+    __syncthreads();
+    ICP_PHASE(5)
+    if (w != 0) return;  // wave 0 finishes the row: it holds both of every lane's points in registers
+
+    float fb[2];
+    int fj[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float b = md[0][lane + t * 64];
+        int bi = mi[0][lane + t * 64];
+#pragma unroll
+        for (int ww = 1; ww < SP_NW; ++ww) {
+            const float d = md[ww][lane + t * 64];
+            const int j = mi[ww][lane + t * 64];
+            const bool lower = (d < b) | ((d == b) & (j < bi));
+            b = lower ? d : b;
+            bi = lower ? j : bi;
+        }
+        fb[t] = b;
+        fj[t] = bi;
+    }
+    if constexpr (TAIL == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const size_t o = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * 128 + lane + t * 64;
+            part_d[o] = fb[t];
+            part_idx[o] = fj[t];
+        }
+    } else {
+        if (gridDim.y > 1) {
+            // several segment blocks share the row: fold into the 64-bit (d, idx) keys and draw a ticket, the
+            // last arriver closes the row (protocol as in nn_match_f32_v2; only this wave takes part)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(fb[t]) << 32) | (unsigned int)fj[t];
+                __hip_atomic_fetch_min(&tail.keys[(size_t)blockIdx.x * 128 + lane + t * 64], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ICP_PHASE(6)
+            unsigned int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&tail.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            ICP_PHASE(7)
+            if (ticket != gridDim.y - 1) return;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int i = ibase + t * 64;
+                const unsigned long long key = __hip_atomic_load(&tail.keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tail.keys[i] = ~0ull;  // ready for the next launch (nobody touches this row again in this one)
+                fj[t] = (int)(unsigned int)(key & 0xffffffffull);
+            }
+            if (lane == 0) tail.tickets[blockIdx.x] = 0u;
+            if (fuse.apply) err_row = __hip_atomic_load(&tail.err_tile[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fj[t] = ((unsigned)fj[t] < (unsigned)fuse.m) ? fj[t] : fuse.m - 1;  // unreachable clamp
+        tail_close_row<TAIL>(px, py, pz, fj, lane, ibase, m_pad, fuse, tail, fuse.apply ? err_row : 0.0, lds_raw);
+        ICP_PHASE(9)
+    }
+}
+#undef ICP_PHASE
 
 // bounding box of every 8-point chunk of the duplicate-voided scan copy (voided = +inf entries are ignored; an
 // all-void chunk gets lo = +inf, hi = -inf and is skipped by construction).  Once per model.
@@ -684,6 +1258,34 @@ __global__ void model_boxes_kernel(const float* __restrict__ Qs, int m_pad, floa
     }
     float* o = boxes + (size_t)c * 8;
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+}
+
+// one representative per chunk of the scan copy (its first point that is not voided; +inf if there is none),
+// SoA over round_up(m_pad / 8, 8) entries: the thinned-out model of the sparse kernel's cold start
+__global__ void model_samples_kernel(const float* __restrict__ Qs, int m_pad, int ns_pad, float* __restrict__ samples)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ns_pad) return;
+    float v[3] = {inf_<float>(), inf_<float>(), inf_<float>()};
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+        const float x = Qs[j];
+        if (x < inf_<float>() && x > -inf_<float>()) { v[0] = x; v[1] = Qs[(size_t)m_pad + j]; v[2] = Qs[2 * (size_t)m_pad + j]; break; }
+    }
+    samples[c] = v[0];
+    samples[(size_t)ns_pad + c] = v[1];
+    samples[2 * (size_t)ns_pad + c] = v[2];
+}
+
+size_t model_samples_bytes(int m_pad) { return 3 * (size_t)(((m_pad / 8) + 7) / 8 * 8) * sizeof(float); }
+
+hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const int ns_pad = ((m_pad / 8) + 7) / 8 * 8;
+    hipLaunchKernelGGL(model_samples_kernel, dim3((ns_pad + 255) / 256), dim3(256), 0, st, (const float*)Qs_soa, m_pad, ns_pad, samples);
+    return hipGetLastError();
 }
 
 hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st)
@@ -1284,6 +1886,29 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus)
     if (pl.version == 2) {
         // v2: a block (4 waves) owns 64*T moving points, each wave a quarter of the block's segment.
         // 8 resident waves per SIMD = 8 blocks per CU saturate the VALU (valu_rate probe).
+        static const int env_sparse = env_int("ICP_NN_SPARSE", 1);
+        static const int env_boxes = env_int("ICP_NN_BOXES", 1);
+        if (env_sparse && env_boxes) {
+            // sparse kernel: a block of 16 waves owns 128 moving points; split the model only while there are
+            // fewer blocks than CUs, and never below 1024 model points per block
+            pl.sparse = 1;
+            pl.cull = 1;
+            pl.chunk = 8;
+            pl.pts_per_thread = 2;
+            pl.blocks_x = pl.n_pad / 128;
+            if (n <= 0 || m <= 0) { pl.splits = 0; pl.seg_len = 0; return pl; }
+            // (an unsplit row closes without the key/ticket exchange, worth ~3 us: prefer it from half a machine up)
+            int S = (num_cus / 2 + pl.blocks_x - 1) / pl.blocks_x;
+            const int max_S = (pl.m_pad + 1023) / 1024;
+            if (S > max_S) S = max_S;
+            if (env_S > 0) S = env_S;
+            if (S < 1) S = 1;
+            int seg = round_up((pl.m_pad + S - 1) / S, 8);
+            S = (pl.m_pad + seg - 1) / seg;
+            pl.splits = S;
+            pl.seg_len = seg;
+            return pl;
+        }
         const int bpc = env_bpc > 0 ? env_bpc : 8;
         const int target_blocks = num_cus * bpc;
         int T = (pl.n_pad / 256 >= target_blocks) ? 4 : 2;   // big clouds: 4 points per lane halve the LDS reads
@@ -1350,6 +1975,12 @@ static hipError_t launch_nn_t(const NNPlan& pl, const void* P, const void* Q, vo
 
 bool nn_can_fuse_tail(const NNPlan& pl) { return pl.version == 2 && pl.pts_per_thread == 2 && pl.chunk == 8 && pl.n > 0 && pl.m > 0; }
 
+int nn_block_threads(const NNPlan& pl) { return pl.sparse ? SP_NW * 64 : NN_BLOCK; }
+
+static long long* g_phase_log = nullptr;
+static long long g_phase_log_cap = 0;
+void set_phase_log(long long* dev, long long slots) { g_phase_log = dev; g_phase_log_cap = slots; }
+
 static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
                                const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st)
 {
@@ -1359,6 +1990,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     fuse.n = pl.n;
     fuse.m = pl.m;
     fuse.Q_gather = (const float*)Q;
+    fuse.tlog = g_phase_log;
+    fuse.tlog_cap = g_phase_log_cap;
     const void* Qscan = Q;
     if (pl.cull && opt && opt->Q_scan) {
         Qscan = opt->Q_scan;
@@ -1391,20 +2024,46 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
 #define ICP_LAUNCH_NN2(TT, CC, CU)                                                                                  \
     hipLaunchKernelGGL((nn_match_f32_v2<TT, CC, CU, 0>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,     \
                        (const float*)Qscan, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse, tail)
+    if (pl.sparse) {
+        // the plan's geometry is the sparse kernel's: it needs the scan copy and its chunk boxes
+        if (!(opt && opt->Q_scan && opt->boxes)) return hipErrorInvalidValue;
+        fuse.seed_idx = opt->seed_idx;
+        fuse.boxes = (const float*)opt->boxes;
+        static const int env_samples = env_int("ICP_NN_SAMPLES", 1);
+        fuse.samples = env_samples ? (const float*)opt->samples : nullptr;
+        static const int env_passes = env_int("ICP_NN_PASSES", 0);
+        // seeded: few hits, long rounds; cold: short rounds so that the exchanged minima start pruning early
+        int passes = env_passes > 0 ? env_passes : ((fuse.seed_idx || fuse.samples) ? SP_MAX_PASSES : 1);
+        if (passes > SP_MAX_PASSES) passes = SP_MAX_PASSES;
+#define ICP_LAUNCH_SP(TL)                                                                                          \
+    hipLaunchKernelGGL((nn_match_sparse<TL>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,              \
+                       (const float*)opt->Q_scan, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail)
+        if (!ta) ICP_LAUNCH_SP(0);
+        else if (ta->metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_SP(2);
+        else ICP_LAUNCH_SP(1);
+#undef ICP_LAUNCH_SP
+        return hipGetLastError();
+    }
     // measured (profiles/r1/03_nn_sweep_cull.txt): without a seed the early-out variant loses to the plain
     // packed kernel on every cloud (its bound starts at +inf), with one it wins on every cloud
     const bool cull = pl.cull && Qscan != Q && fuse.seed_idx != nullptr;
     if (!cull) { Qscan = Q; fuse.seed_idx = nullptr; fuse.boxes = nullptr; }
+    // with chunk boxes the sparse scan (lane-parallel box test, no LDS tile) replaces the tiled one
+    static const int env_sparse = env_int("ICP_NN_SPARSE", 1);
+    const bool sparse = cull && fuse.boxes != nullptr && pl.chunk == 8 && env_sparse;
     if (ta) {
         const bool plane = ta->metric == ICP_POINT_TO_PLANE;
-        if (cull) { if (plane) ICP_LAUNCH_NN2T(true, 2); else ICP_LAUNCH_NN2T(true, 1); }
-        else { if (plane) ICP_LAUNCH_NN2T(false, 2); else ICP_LAUNCH_NN2T(false, 1); }
+        if (sparse) { if (plane) ICP_LAUNCH_NN2T(2, 2); else ICP_LAUNCH_NN2T(2, 1); }
+        else if (cull) { if (plane) ICP_LAUNCH_NN2T(1, 2); else ICP_LAUNCH_NN2T(1, 1); }
+        else { if (plane) ICP_LAUNCH_NN2T(0, 2); else ICP_LAUNCH_NN2T(0, 1); }
     } else if (pl.pts_per_thread == 4) {
-        if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8, false); else ICP_LAUNCH_NN2(4, 16, false);
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8, 0); else ICP_LAUNCH_NN2(4, 16, 0);
+    } else if (sparse) {
+        ICP_LAUNCH_NN2(2, 8, 2);
     } else if (cull) {
-        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, true); else ICP_LAUNCH_NN2(2, 16, true);
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, 1); else ICP_LAUNCH_NN2(2, 16, 1);
     } else {
-        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, false); else ICP_LAUNCH_NN2(2, 16, false);
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, 0); else ICP_LAUNCH_NN2(2, 16, 0);
     }
 #undef ICP_LAUNCH_NN2
 #undef ICP_LAUNCH_NN2T
