@@ -50,6 +50,7 @@ int fail(int code, const std::string& msg)
             return fail(ICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
     } while (0)
 
+static constexpr int kMailSlots = 4;  // armed launches: ring of mailboxes (one is live at a time)
 static constexpr size_t kPhaseSlots = 512 * 1024;  // ICP_NN_PHASES: 10 stamps per wave
 
 struct DevBuf {
@@ -84,6 +85,12 @@ struct LoopState {
     bool host_reduce = false;  // how the pending enqueue's partial rows are being reduced
     bool matched = false;      // a matching pass of THIS loop has filled idx[cur]
     bool rows_have_err = false; // slot 0 of the pending moment rows carries the error shares (fused tail)
+    double wait_tag = 0.0;      // completion tag of the pending enqueue's rows
+    // armed launch: the matching pass AFTER the pending one is already enqueued and waits for its (R, t)
+    bool armed = false;
+    double armed_tag = 0.0;
+    int armed_slot = 0;
+    int armed_prev_cur = 0;
 };
 
 }  // namespace
@@ -134,6 +141,12 @@ struct icp_ctx {
     uint64_t tr_n = 0;
     void* comm = nullptr;              // RCCL communicator (icp_comm_init): the loop all-reduces its vector itself
     bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
+    bool arm = true;                   // ICP_ARMED=0: icp_loop_run never enqueues a pass ahead of its (R, t)
+    // ring of mailboxes for armed launches, in fine-grained DEVICE memory that the CPU writes through the PCIe BAR:
+    // the waiting kernel polls its own memory (tools/mailbox_probe.hip: 2.1 us host->kernel->host whatever the number
+    // of polling blocks, against 22.7 us when 128 blocks poll pinned host memory)
+    icp::NNMailbox* h_mail = nullptr;
+    uint64_t mail_seq = 0;
     bool host_reduce() const { return !comm && mom_dev == (double*)mom_own.p && h_mom_partials != nullptr; }
     icp::NNPlan plan{};
     LoopState loop;
@@ -314,6 +327,17 @@ int icp_create(int device, icp_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mom, ICP_NMOM * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) {
+        int large_bar = 0;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
+            hipExtMallocWithFlags((void**)&c->h_mail, kMailSlots * sizeof(icp::NNMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
+            std::memset(c->h_mail, 0, kMailSlots * sizeof(icp::NNMailbox));
+            __sync_synchronize();
+        } else {
+            (void)hipGetLastError();
+            c->h_mail = nullptr;  // no CPU-visible device memory: icp_loop_run launches every pass after its solve
+        }
+    }
 
     if (e != hipSuccess) {
         const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
@@ -322,6 +346,7 @@ int icp_create(int device, icp_ctx** out)
     }
     c->stream = c->own_stream;
     if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
+    if (const char* v = std::getenv("ICP_ARMED")) c->arm = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_TRACE")) c->trace = v[0] == '1';
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
@@ -360,6 +385,7 @@ void icp_destroy(icp_ctx* c)
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
+    if (c->h_mail) (void)hipFree(c->h_mail);
     if (c->h_mom_partials) (void)hipHostFree(c->h_mom_partials);
     if (c->h_err_partials) (void)hipHostFree(c->h_err_partials);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -738,6 +764,7 @@ int icp_loop_enqueue(icp_ctx* c)
         }
     }
     L.host_reduce = host_reduce;
+    L.wait_tag = (double)c->tag_seq;
     L.pending = true;
     if (c->trace) c->tr_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
     return ICP_OK;
@@ -770,30 +797,47 @@ int icp_loop_complete(icp_ctx* c, int* done)
         // synchronisation the host polls the per-row completion tags (each row is released to system
         // scope before its tag); the matching kernel's error rows were complete before the moments
         // kernel started.  Fixed block order => the same bits every run.
+        // Rows are summed in block order AS their tags arrive, so the reduction overlaps the kernel's last blocks.
+        double* mom = c->h_mom;
+        auto start_sum = [&]() {
+            for (int k = 0; k < ICP_NMOM; ++k) mom[k] = 0.0;
+            for (int b = 0; b < L.err_blocks; ++b) mom[ICP_MOM_ERR] += c->h_err_partials[b];
+        };
+        auto add_row = [&](int b) {
+            const double* row = c->h_mom_partials + (size_t)b * ICP_NMOM;
+            for (int k = 0; k < ICP_NMOM - 1; ++k) mom[k] += row[k];  // the last slot is the completion tag
+        };
         bool polled = false;
-        if (L.mom_blocks > 0 && !L.timed_nn && c->poll) {
-            const double want = (double)c->tag_seq;
+        if (L.mom_blocks > 0 && !L.timed_nn && c->poll && L.err_blocks == 0) {
+            const double want = L.wait_tag;
             const auto t0 = std::chrono::steady_clock::now();
             int b = 0;
             unsigned spins = 0;
+            start_sum();
             while (b < L.mom_blocks) {
                 const volatile double* tagp = c->h_mom_partials + (size_t)b * ICP_NMOM + (ICP_NMOM - 1);
-                if (*tagp == want) { ++b; continue; }
+                if (*tagp == want) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    add_row(b++);
+                    continue;
+                }
                 if ((++spins & 0x3ff) == 0 &&
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
                     break;  // something is wrong (fault, hang): let the runtime report it
             }
             polled = b == L.mom_blocks;
-            std::atomic_thread_fence(std::memory_order_acquire);
         }
-        if (!polled) HIP_TRY(hipStreamSynchronize(c->stream));
         tr1 = std::chrono::steady_clock::now();
-        double* mom = c->h_mom;
-        for (int k = 0; k < ICP_NMOM; ++k) mom[k] = 0.0;
-        for (int b = 0; b < L.err_blocks; ++b) mom[ICP_MOM_ERR] += c->h_err_partials[b];
-        for (int b = 0; b < L.mom_blocks; ++b) {
-            const double* row = c->h_mom_partials + (size_t)b * ICP_NMOM;
-            for (int k = 0; k < ICP_NMOM - 1; ++k) mom[k] += row[k];  // the last slot is the completion tag
+        if (!polled) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            tr1 = std::chrono::steady_clock::now();
+            for (int b = 0; b < L.mom_blocks; ++b)
+                if (c->h_mom_partials[(size_t)b * ICP_NMOM + (ICP_NMOM - 1)] != L.wait_tag) {
+                    L.pending = false;
+                    return fail(ICP_ERR_HIP, "a matching pass ended without producing its rows (armed launch timed out?)");
+                }
+            start_sum();
+            for (int b = 0; b < L.mom_blocks; ++b) add_row(b);
         }
     } else {
         HIP_TRY(hipMemcpyAsync(c->h_mom, c->mom_dev, ICP_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -826,13 +870,109 @@ int icp_loop_complete(icp_ctx* c, int* done)
     return ICP_OK;
 }
 
+// ---- armed launches ------------------------------------------------------------------------------
+// icp_loop_run keeps one matching pass enqueued AHEAD of the (R, t) it will apply: the kernel is launched and
+// dispatched while the previous pass still runs and the host still solves, waits on a mailbox in pinned memory
+// and starts the moment the solution is published -- the launch + dispatch latency (~8 us of a ~23 us iteration
+// on the hall cloud) leaves the critical path.  If the loop stops instead, the pass is withdrawn and exits
+// without having touched anything.
+namespace {
+
+bool can_arm(icp_ctx* c)
+{
+    const LoopState& L = c->loop;
+    const icp::NNPlan& pl = c->plan;
+    return c->arm && c->h_mail && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
+           icp::nn_can_fuse_transform(pl) && c->have_scan_copy && c->use_boxes && L.active && L.pending && !L.armed &&
+           L.matched && !L.H.done && !L.H.have_rt &&
+           !L.timed_nn &&  // a timed pass is completed with a stream synchronisation: nothing may wait behind it
+           L.H.applied + 1 < L.H.prm.max_iter &&  // the pass after the pending one still matches (it is not the final, error-only one)
+           !(c->profile_stride > 0 && (c->nn_launch_count % (uint64_t)c->profile_stride) == 0);  // timed launches stay plain
+}
+
+int loop_arm(icp_ctx* c)
+{
+    LoopState& L = c->loop;
+    const icp::NNPlan& pl = c->plan;
+    const icp::NNCullInputs cull{c->Qs.p, (const int32_t*)c->idx[c->cur].p, c->Qbox.p, c->Qsamp.p};
+    const int prev_cur = c->cur;
+    const int slot = (int)(c->mail_seq++ % kMailSlots);
+    icp::NNMailbox* mb = c->h_mail + slot;
+    const double tag = (double)(++c->tag_seq);
+    *(volatile double*)&mb->seq = 0.0;
+    __sync_synchronize();  // BAR memory is write-combining: a full fence orders AND flushes the stores
+    icp::NNTailArgs ta{};
+    ta.metric = L.H.prm.metric;
+    ta.keys = (unsigned long long*)c->keys.p;
+    ta.tickets = (unsigned int*)c->tickets.p;
+    ta.err_tile = (double*)c->err_partials.p;
+    ta.idx_out = (int32_t*)c->idx[prev_cur ^ 1].p;
+    ta.Nrm_soa = c->Nrm.p;
+    ta.rows = c->h_mom_partials;
+    ta.tag = tag;
+    icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[prev_cur].p, c->P2.p, (double*)c->err_partials.p, mb, tag};
+    if (c->profile_stride > 0) c->nn_launch_count++;
+    HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream));
+    std::swap(c->P, c->P2);
+    c->cur = prev_cur ^ 1;
+    L.armed = true;
+    L.armed_tag = tag;
+    L.armed_slot = slot;
+    L.armed_prev_cur = prev_cur;
+    return ICP_OK;
+}
+
+// the solution is in: publish it to the waiting kernel, which becomes the pending pass
+void loop_release_armed(icp_ctx* c)
+{
+    LoopState& L = c->loop;
+    icp::NNMailbox* mb = c->h_mail + L.armed_slot;
+    for (int k = 0; k < 9; ++k) mb->rt[k] = (float)L.H.R[k];
+    for (int k = 0; k < 3; ++k) mb->rt[9 + k] = (float)L.H.t[k];
+    __sync_synchronize();
+    *(volatile double*)&mb->seq = L.armed_tag;
+    __sync_synchronize();
+    L.applied_idx = L.armed_prev_cur;
+    L.H.note_applied();
+    L.mom_blocks = c->plan.blocks_x;
+    L.err_blocks = 0;
+    L.rows_have_err = true;
+    L.host_reduce = true;
+    L.timed_nn = false;
+    L.wait_tag = L.armed_tag;
+    L.pending = true;
+    L.armed = false;
+}
+
+// the loop ended (or failed): the waiting kernel exits without touching anything; undo the bookkeeping
+void loop_withdraw_armed(icp_ctx* c)
+{
+    LoopState& L = c->loop;
+    if (!L.armed) return;
+    icp::NNMailbox* mb = c->h_mail + L.armed_slot;
+    *(volatile double*)&mb->seq = -L.armed_tag;
+    __sync_synchronize();
+    std::swap(c->P, c->P2);
+    c->cur = L.armed_prev_cur;
+    L.armed = false;
+}
+
+}  // namespace
+
 int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
 {
     if (max_steps < 0) return fail(ICP_ERR_INVALID, "max_steps < 0");
     int d = c && c->loop.active && c->loop.H.done ? 1 : 0, k = 0;
     while (!d && k < max_steps) {
-        if (int rc = icp_loop_enqueue(c)) return rc;
-        if (int rc = icp_loop_complete(c, &d)) return rc;
+        if (!c->loop.pending)
+            if (int rc = icp_loop_enqueue(c)) return rc;
+        if (k + 1 < max_steps && can_arm(c))
+            if (int rc = loop_arm(c)) return rc;
+        if (int rc = icp_loop_complete(c, &d)) { loop_withdraw_armed(c); return rc; }
+        if (c->loop.armed) {
+            if (d) loop_withdraw_armed(c);
+            else loop_release_armed(c);
+        }
         ++k;
     }
     if (steps_done) *steps_done = k;
@@ -875,10 +1015,8 @@ static int run_loop(icp_ctx* c, const icp_params* prm, icp_result* out)
     if (int rc = icp_loop_begin(c, prm)) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     int done = 0;
-    while (!done) {
-        if (int rc = icp_loop_enqueue(c)) return rc;
-        if (int rc = icp_loop_complete(c, &done)) return rc;
-    }
+    while (!done)
+        if (int rc = icp_loop_run(c, 1 << 20, nullptr, &done)) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     const LoopState& L = c->loop;
     if (out) {

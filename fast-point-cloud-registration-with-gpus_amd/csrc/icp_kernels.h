@@ -42,12 +42,20 @@ size_t elem_size(int precision);
 
 // the transform of the previous pass, fused into the front of the matching kernel (fp32 kernel only):
 // P_out <- R * P_in + t, err_rows[block_x] <- sum |p_new - q[idx_prev]|^2
+// mailbox of an armed launch, in CPU-visible fine-grained device memory: the host stores rt, then (fenced) seq = +tag
+// to let the waiting kernel go, or seq = -tag to withdraw it
+struct NNMailbox {
+    float rt[12];  // R row-major, then t -- already rounded to the storage precision
+    double seq;
+};
 struct NNFusedTransform {
-    const double* R9;
+    const double* R9;  // NULL with a mailbox
     const double* t3;
     const int32_t* idx_prev;
     void* P_out;       // SoA, same padding as the input; must not alias it
     double* err_rows;  // >= blocks_x doubles
+    const NNMailbox* mailbox = nullptr;  // armed launch (sparse kernel only): R9/t3 are not read
+    double want = 0.0;
 };
 bool nn_can_fuse_transform(const NNPlan& pl);
 

@@ -435,6 +435,9 @@ struct NNFuse {
                              // tightens the starting bound, the result does not depend on it
     const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
     const float* boxes;      // CULL kernels: per 8-point chunk of the scan copy {lo.xyz, hi.xyz, -, -} (or NULL)
+    int sample_groups;       // sparse kernel: at most this many groups of 8 samples are used by the cold start (<= 256)
+    const NNMailbox* mailbox; // armed launch (sparse kernel): (R, t) arrive here from the host AFTER the kernel was enqueued
+    double want;             // ... under this sequence number (+want: go, -want: withdrawn)
     const float* samples;    // sparse kernel: one point per chunk of the scan copy (SoA, round_up(m_pad/8, 8) entries) or NULL
     long long* tlog;         // diagnostic (ICP_NN_PHASES): per-wave s_memrealtime stamps, 10 slots per wave, or NULL
     long long tlog_cap;      // slots available
@@ -817,13 +820,15 @@ constexpr int SP_NW = 16;                       // waves per block
 constexpr int SP_HCAP = 4096;                   // hit-list entries = chunks per round (SP_NW * 64 * passes <= this)
 constexpr int SP_MAX_PASSES = SP_HCAP / (SP_NW * 64);
 
-// one hit chunk against the lane's packed pair; (best, cst) follow the lexicographic (distance, chunk) rule
+// one hit chunk against the lane's packed pair; (best, bj) follow the lexicographic (distance, index) rule:
+// the chunk takes a point's minimum if its own minimum is smaller, or equal and the chunk lies below the current
+// winner's; the index inside the chunk (lowest k with d_k == minimum) is worked out only then
 template <bool QS>
 __device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const float* qyp, const float* qzp, const f2 px,
-                                                     const f2 py, const f2 pz, int ch, float (&best)[2], int (&cst)[2])
+                                                     const f2 py, const f2 pz, int ch, float (&best)[2], int (&bj)[2])
 {
     constexpr int C = 8;
-    f2 pxy[C];
+    f2 d[C];  // first dx*dx + dy*dy (the inner sum of the reference's association), then the distances
     float mxy0 = inf_<float>(), mxy1 = inf_<float>();
 #pragma unroll
     for (int kk = 0; kk < C; kk += 4) {
@@ -833,18 +838,19 @@ __device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const flo
         const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
         f2 ax, ay;
         ax = pk_sub_q<0, QS>(qxa, px); ay = pk_sub_q<0, QS>(qya, py);
-        pxy[kk + 0] = ax * ax + ay * ay;
+        d[kk + 0] = ax * ax + ay * ay;
         ax = pk_sub_q<1, QS>(qxa, px); ay = pk_sub_q<1, QS>(qya, py);
-        pxy[kk + 1] = ax * ax + ay * ay;
+        d[kk + 1] = ax * ax + ay * ay;
         ax = pk_sub_q<0, QS>(qxb, px); ay = pk_sub_q<0, QS>(qyb, py);
-        pxy[kk + 2] = ax * ax + ay * ay;
+        d[kk + 2] = ax * ax + ay * ay;
         ax = pk_sub_q<1, QS>(qxb, px); ay = pk_sub_q<1, QS>(qyb, py);
-        pxy[kk + 3] = ax * ax + ay * ay;
-        mxy0 = fmin_(fmin_(mxy0, pxy[kk].x), pxy[kk + 1].x);
-        mxy0 = fmin_(fmin_(mxy0, pxy[kk + 2].x), pxy[kk + 3].x);
-        mxy1 = fmin_(fmin_(mxy1, pxy[kk].y), pxy[kk + 1].y);
-        mxy1 = fmin_(fmin_(mxy1, pxy[kk + 2].y), pxy[kk + 3].y);
+        d[kk + 3] = ax * ax + ay * ay;
+        mxy0 = fmin_(fmin_(mxy0, d[kk].x), d[kk + 1].x);
+        mxy0 = fmin_(fmin_(mxy0, d[kk + 2].x), d[kk + 3].x);
+        mxy1 = fmin_(fmin_(mxy1, d[kk].y), d[kk + 1].y);
+        mxy1 = fmin_(fmin_(mxy1, d[kk + 2].y), d[kk + 3].y);
     }
+    // d = fl(pxy + dz*dz) >= pxy: a chunk whose smallest pxy is above every lane's minimum cannot matter (ties pass)
     if (__builtin_amdgcn_ballot_w64((mxy0 <= best[0]) | (mxy1 <= best[1])) == 0ull) return;
     float c0 = inf_<float>(), c1 = inf_<float>();  // the chunk's own minima
 #pragma unroll
@@ -852,26 +858,33 @@ __device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const flo
         const float4 qz4 = *reinterpret_cast<const float4*>(qzp + kk);
         const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
         f2 az;
-        az = pk_sub_q<0, QS>(qza, pz); const f2 d0 = pxy[kk + 0] + az * az;
-        az = pk_sub_q<1, QS>(qza, pz); const f2 d1 = pxy[kk + 1] + az * az;
-        az = pk_sub_q<0, QS>(qzb, pz); const f2 d2 = pxy[kk + 2] + az * az;
-        az = pk_sub_q<1, QS>(qzb, pz); const f2 d3 = pxy[kk + 3] + az * az;
-        c0 = fmin_(fmin_(c0, d0.x), d1.x);
-        c0 = fmin_(fmin_(c0, d2.x), d3.x);
-        c1 = fmin_(fmin_(c1, d0.y), d1.y);
-        c1 = fmin_(fmin_(c1, d2.y), d3.y);
+        az = pk_sub_q<0, QS>(qza, pz); d[kk + 0] = d[kk + 0] + az * az;
+        az = pk_sub_q<1, QS>(qza, pz); d[kk + 1] = d[kk + 1] + az * az;
+        az = pk_sub_q<0, QS>(qzb, pz); d[kk + 2] = d[kk + 2] + az * az;
+        az = pk_sub_q<1, QS>(qzb, pz); d[kk + 3] = d[kk + 3] + az * az;
+        c0 = fmin_(fmin_(c0, d[kk].x), d[kk + 1].x);
+        c0 = fmin_(fmin_(c0, d[kk + 2].x), d[kk + 3].x);
+        c1 = fmin_(fmin_(c1, d[kk].y), d[kk + 1].y);
+        c1 = fmin_(fmin_(c1, d[kk + 2].y), d[kk + 3].y);
     }
-    const bool take0 = (c0 < best[0]) | ((c0 == best[0]) & (ch < cst[0]));
-    const bool take1 = (c1 < best[1]) | ((c1 == best[1]) & (ch < cst[1]));
+    const bool take0 = (c0 < best[0]) | ((c0 == best[0]) & (ch < (bj[0] >> 3)));  // bj = -1: nothing to tie with
+    const bool take1 = (c1 < best[1]) | ((c1 == best[1]) & (ch < (bj[1] >> 3)));
     if (__builtin_amdgcn_ballot_w64(take0 | take1) != 0ull) {
+        int k0 = C - 1, k1 = C - 1;
+#pragma unroll
+        for (int kk = C - 2; kk >= 0; --kk) {
+            k0 = (d[kk].x == c0) ? kk : k0;
+            k1 = (d[kk].y == c1) ? kk : k1;
+        }
         best[0] = take0 ? c0 : best[0];
-        cst[0] = take0 ? ch : cst[0];
+        bj[0] = take0 ? ch * C + k0 : bj[0];
         best[1] = take1 ? c1 : best[1];
-        cst[1] = take1 ? ch : cst[1];
+        bj[1] = take1 ? ch * C + k1 : bj[1];
     }
 }
 
-// distances from the lane's packed pair to 8 model points held in SGPRs, folded into running minima (no index)
+// distances from the lane's packed pair to 8 model points (QS: held in SGPRs), folded into running minima (no index)
+template <bool QS>
 __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, const float4 qy0, const float4 qy1,
                                           const float4 qz0, const float4 qz1, const f2 px, const f2 py, const f2 pz,
                                           float (&best)[2])
@@ -882,13 +895,13 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
 #pragma unroll
     for (int k = 0; k < 4; k += 2) {
         f2 ax, ay, az;
-        ax = pk_sub_bcast_s<0>(qx[k], px); ay = pk_sub_bcast_s<0>(qy[k], py); az = pk_sub_bcast_s<0>(qz[k], pz);
+        ax = pk_sub_q<0, QS>(qx[k], px); ay = pk_sub_q<0, QS>(qy[k], py); az = pk_sub_q<0, QS>(qz[k], pz);
         const f2 d0 = (ax * ax + ay * ay) + az * az;
-        ax = pk_sub_bcast_s<1>(qx[k], px); ay = pk_sub_bcast_s<1>(qy[k], py); az = pk_sub_bcast_s<1>(qz[k], pz);
+        ax = pk_sub_q<1, QS>(qx[k], px); ay = pk_sub_q<1, QS>(qy[k], py); az = pk_sub_q<1, QS>(qz[k], pz);
         const f2 d1 = (ax * ax + ay * ay) + az * az;
-        ax = pk_sub_bcast_s<0>(qx[k + 1], px); ay = pk_sub_bcast_s<0>(qy[k + 1], py); az = pk_sub_bcast_s<0>(qz[k + 1], pz);
+        ax = pk_sub_q<0, QS>(qx[k + 1], px); ay = pk_sub_q<0, QS>(qy[k + 1], py); az = pk_sub_q<0, QS>(qz[k + 1], pz);
         const f2 d2 = (ax * ax + ay * ay) + az * az;
-        ax = pk_sub_bcast_s<1>(qx[k + 1], px); ay = pk_sub_bcast_s<1>(qy[k + 1], py); az = pk_sub_bcast_s<1>(qz[k + 1], pz);
+        ax = pk_sub_q<1, QS>(qx[k + 1], px); ay = pk_sub_q<1, QS>(qy[k + 1], py); az = pk_sub_q<1, QS>(qz[k + 1], pz);
         const f2 d3 = (ax * ax + ay * ay) + az * az;
         best[0] = fmin_(fmin_(best[0], d0.x), d1.x);
         best[0] = fmin_(fmin_(best[0], d2.x), d3.x);
@@ -969,13 +982,14 @@ template <int TAIL>
 __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __restrict__ P, int n_pad,
                                                               const float* __restrict__ Q, int m_pad, int seg_len,
                                                               int round_passes, float* __restrict__ part_d,
-                                                              int32_t* __restrict__ part_idx, RT<float> rt, NNFuse fuse,
+                                                              int32_t* __restrict__ part_idx, RT<float> rt_arg, NNFuse fuse,
                                                               NNTail tail)
 {
     constexpr int HITS_BYTES = SP_HCAP * 4, MD_BYTES = SP_NW * 128 * 4;
     constexpr int TR_BYTES = TAIL ? (TAIL == 2 ? 28 : 18) * 65 * 8 : 0;
     static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16];
+    constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * 32 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_OFF + STAGE_BYTES];
     int* hits = reinterpret_cast<int*>(lds_raw);
     float (*md)[128] = reinterpret_cast<float (*)[128]>(lds_raw + HITS_BYTES);
     int (*mi)[128] = reinterpret_cast<int (*)[128]>(lds_raw + HITS_BYTES + MD_BYTES);
@@ -985,16 +999,80 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ibase = blockIdx.x * 128 + lane;
+    float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * 32);  // per wave: 8 hits x {box 8, x 8, y 8, z 8}
     ICP_PHASE(0)
+    // issued first, with everything else that does not depend on the points: the chunk boxes of the wave's first
+    // two find passes ...
+    const int q0 = blockIdx.y * seg_len;
+    const int c_lo = q0 / 8, c_hi = min(q0 + seg_len, m_pad) / 8;
+    constexpr int PRE = 2;
+    float4 pb[PRE][2];
+#pragma unroll
+    for (int r = 0; r < PRE; ++r) {
+        const int cidx = c_lo + (r * SP_NW + w) * 64 + lane;
+        const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cidx < c_hi ? cidx : 0) * 8);
+        pb[r][0] = bp[0];
+        pb[r][1] = bp[1];
+    }
+    // ... and the seed gather does not depend on the points (the compiler cannot move these loads above the
+    // stores to P_out itself), and when the seeds are the correspondences the fused transform came from -- the
+    // ordinary loop -- the same gathered q serves the error of that pass
+    bool real[2], sok[2];
+    float sq[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = ibase + t * 64;
+        real[t] = i < fuse.n;
+        sok[t] = false;
+        sq[t][0] = sq[t][1] = sq[t][2] = 0.f;
+        if (fuse.seed_idx) {
+            int j = real[t] ? fuse.seed_idx[i] : -1;
+            sok[t] = (unsigned)j < (unsigned)fuse.m;  // a seed is trusted only if it is a real model index
+            j = sok[t] ? j : 0;
+            const float* Qg = fuse.Q_gather;
+            sq[t][0] = Qg[j]; sq[t][1] = Qg[(size_t)m_pad + j]; sq[t][2] = Qg[2 * (size_t)m_pad + j];
+        }
+    }
     f2 px, py, pz;
     px = f2{P[ibase], P[ibase + 64]};
     py = f2{P[(size_t)n_pad + ibase], P[(size_t)n_pad + ibase + 64]};
     pz = f2{P[2 * (size_t)n_pad + ibase], P[2 * (size_t)n_pad + ibase + 64]};
     double err_row = 0.0;
+    RT<float> rt = rt_arg;
+    if (fuse.mailbox != nullptr) {
+        // Armed launch: this kernel was enqueued while the previous pass was still running, so the launch and
+        // dispatch latencies are already behind it; what it still lacks is the (R, t) the host is solving for.
+        // Wave 0 watches the mailbox -- device memory the host writes through the BAR, so the poll is a local read;
+        // the other waves sleep at the barrier -- and everything above (points, seeds, boxes) is already in flight.
+        // The poll budget (a few seconds) is the exit every wave reaches if the host never answers.
+        float* rtl = reinterpret_cast<float*>(lds_raw);  // 12 floats + status, over the (still idle) hit list
+        if (w == 0) {
+            const double* seqp = &fuse.mailbox->seq;
+            double sq_ = 0.0;
+            for (int spins = 0; spins < (1 << 22); ++spins) {
+                sq_ = __hip_atomic_load(seqp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (sq_ == fuse.want || sq_ == -fuse.want) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (R, t) were released before the sequence number
+            const bool go = sq_ == fuse.want;
+            if (go && lane < 12) rtl[lane] = __hip_atomic_load(&fuse.mailbox->rt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) reinterpret_cast<int*>(rtl)[12] = go ? 1 : 0;
+        }
+        __syncthreads();
+        const int go = reinterpret_cast<const int*>(rtl)[12];
+        if (go == 0) return;  // withdrawn (the loop stopped) or timed out: nothing has been touched
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rt.r[k] = rtl[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rt.t[k] = rtl[9 + k];
+        __syncthreads();  // the hit list takes this space over
+    }
     if (fuse.apply) {
         // every wave re-derives the moved points in registers (same instructions => same bits); wave 0 of the
         // grid.y == 0 block stores them and accounts the error of the pass that produced (R, t)
         double err = 0.0;
+        const bool shared_gather = fuse.idx_prev == fuse.seed_idx;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
@@ -1006,11 +1084,13 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 fuse.P_out[(size_t)n_pad + i] = y;
                 fuse.P_out[2 * (size_t)n_pad + i] = z;
                 if (i < fuse.n) {
-                    const int j = fuse.idx_prev[i];
-                    const float* Qg = fuse.Q_gather;
-                    const double ex = (double)Qg[j] - (double)x;
-                    const double ey = (double)Qg[(size_t)m_pad + j] - (double)y;
-                    const double ez = (double)Qg[2 * (size_t)m_pad + j] - (double)z;
+                    float qx = sq[t][0], qy = sq[t][1], qz = sq[t][2];
+                    if (!(shared_gather && sok[t])) {
+                        const int j = fuse.idx_prev[i];
+                        const float* Qg = fuse.Q_gather;
+                        qx = Qg[j]; qy = Qg[(size_t)m_pad + j]; qz = Qg[2 * (size_t)m_pad + j];
+                    }
+                    const double ex = (double)qx - (double)x, ey = (double)qy - (double)y, ez = (double)qz - (double)z;
                     err += ex * ex + ey * ey + ez * ez;
                 }
             }
@@ -1029,24 +1109,17 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     }
     ICP_PHASE(1)
     float best[2];
-    int cst[2];
-    bool real[2];
+    int bj[2];  // index of the running minimum; -1: this wave has not lowered the bound it started from
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int i = ibase + t * 64;
-        real[t] = i < fuse.n;
-        cst[t] = -1;
+        bj[t] = -1;
         best[t] = inf_<float>();
         if (fuse.seed_idx) {
             // seeded bound: the distance to ANY model point (last pass's match) bumped by one ulp -- the true minimum
             // is <= that distance < bound, so the seed changes how much work is skipped, never the answer
             const float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
-            int j = real[t] ? fuse.seed_idx[i] : -1;
-            const bool ok = (unsigned)j < (unsigned)fuse.m;  // a seed is trusted only if it is a real model index
-            j = ok ? j : 0;
-            const float* Qg = fuse.Q_gather;
-            const float d = dist2<float>(x, y, z, Qg[j], Qg[(size_t)m_pad + j], Qg[2 * (size_t)m_pad + j]);
-            best[t] = (ok && d < inf_<float>()) ? __uint_as_float(__float_as_uint(d) + 1u) : inf_<float>();
+            const float d = dist2<float>(x, y, z, sq[t][0], sq[t][1], sq[t][2]);
+            best[t] = (sok[t] && d < inf_<float>()) ? __uint_as_float(__float_as_uint(d) + 1u) : inf_<float>();
         }
         // padding lanes never ask for a chunk (their result, "nothing found", is never read)
         best[t] = real[t] ? best[t] : -1.f;
@@ -1055,37 +1128,33 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     if (threadIdx.x == 0) *hcount = 0;
     if (fuse.seed_idx == nullptr && fuse.samples != nullptr) {
         // Cold start: no previous match to seed the bounds, so the block measures its points against a thinned-out
-        // model first -- one point per chunk, at most ~4096 of them, a share per wave -- and every wave starts
-        // from the block-wide minimum bumped by an ulp.  Any model point gives a valid bound; the scan below is
-        // then as selective as a seeded one.
-        const int ns8 = ((m_pad / 8) + 7) / 8;                 // groups of 8 samples
+        // model first -- one point per chunk, at most 2048 of them, staged in LDS (over the hit list and the merge
+        // scratch, both idle until later), a share per wave -- and every wave starts from the block-wide minimum
+        // bumped by an ulp.  Any model point gives a valid bound; the scan below is then as selective as a seeded one.
+        constexpr int SMAX = 2048;
+        static_assert(3 * SMAX * 4 <= HITS_BYTES + 2 * MD_BYTES, "the staged samples overlay the hit list and merge scratch");
+        const int ns8 = ((m_pad / 8) + 7) / 8;                 // groups of 8 samples in the array
         const int ns_pad = ns8 * 8;
-        const int gs = (ns8 + 511) / 512;                      // group stride: <= 512 groups are visited
+        const int gcap = min(max(fuse.sample_groups, 1), SMAX / 8);
+        const int gs = (ns8 + gcap - 1) / gcap;                // group stride: <= gcap groups are staged
+        const int ng = (ns8 + gs - 1) / gs;
+        float* sl = reinterpret_cast<float*>(lds_raw);         // [3][SMAX]
+        for (int v = threadIdx.x; v < ng * 6; v += SP_NW * 64) {
+            const int gp = v / 6, r = v % 6, a = r >> 1, hh = r & 1;
+            *reinterpret_cast<float4*>(sl + a * SMAX + gp * 8 + hh * 4) =
+                *reinterpret_cast<const float4*>(fuse.samples + (size_t)a * ns_pad + (size_t)gp * gs * 8 + hh * 4);
+        }
+        __syncthreads();
         float sb[2] = {inf_<float>(), inf_<float>()};
-        const float* sx = fuse.samples;
-        int g = w * gs;
-        if (g < ns8) {
-            const float4* a = reinterpret_cast<const float4*>(sx + (size_t)g * 8);
-            const float4* b = reinterpret_cast<const float4*>(sx + (size_t)ns_pad + (size_t)g * 8);
-            const float4* c = reinterpret_cast<const float4*>(sx + 2 * (size_t)ns_pad + (size_t)g * 8);
-            float4 x0 = a[0], x1 = a[1], y0 = b[0], y1 = b[1], z0 = c[0], z1 = c[1];
-            for (;;) {
-                const int gn = g + SP_NW * gs;
-                const bool more = gn < ns8;
-                const int gl = more ? gn : g;                  // the prefetch of the last turn re-reads its own group
-                a = reinterpret_cast<const float4*>(sx + (size_t)gl * 8);
-                b = reinterpret_cast<const float4*>(sx + (size_t)ns_pad + (size_t)gl * 8);
-                c = reinterpret_cast<const float4*>(sx + 2 * (size_t)ns_pad + (size_t)gl * 8);
-                const float4 nx0 = a[0], nx1 = a[1], ny0 = b[0], ny1 = b[1], nz0 = c[0], nz1 = c[1];
-                scan8_min(x0, x1, y0, y1, z0, z1, px, py, pz, sb);
-                if (!more) break;
-                x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1; z0 = nz0; z1 = nz1;
-                g = gn;
-            }
+        for (int gp = w; gp < ng; gp += SP_NW) {
+            const float4* a = reinterpret_cast<const float4*>(sl + gp * 8);
+            const float4* b = reinterpret_cast<const float4*>(sl + SMAX + gp * 8);
+            const float4* c = reinterpret_cast<const float4*>(sl + 2 * SMAX + gp * 8);
+            scan8_min<false>(a[0], a[1], b[0], b[1], c[0], c[1], px, py, pz, sb);
         }
         if (real[0]) atomicMin(&smin[lane], __float_as_uint(sb[0]));
         if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(sb[1]));
-        __syncthreads();
+        __syncthreads();  // (also: the staging area is free again)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const unsigned int v = smin[lane + t * 64];
@@ -1100,80 +1169,97 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     glo[1] = wave_minmax<false>(__builtin_fminf(py.x, py.y)); ghi[1] = wave_minmax<true>(__builtin_fmaxf(py.x, py.y));
     glo[2] = wave_minmax<false>(__builtin_fminf(pz.x, pz.y)); ghi[2] = wave_minmax<true>(__builtin_fmaxf(pz.x, pz.y));
 
-    const int q0 = blockIdx.y * seg_len;
-    const int c_lo = q0 / 8, c_hi = min(q0 + seg_len, m_pad) / 8;
     const int round_chunks = SP_NW * 64 * round_passes;
+    // one find pass: lane l tests chunk c0 + l (box b0 = lo.xyz hi.x, b1 = hi.yz - -) and appends it to the hit list
+    auto find_pass = [&](int c0, const float4 b0, const float4 b1, float B) {
+        const int cidx = c0 + lane;
+        const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - ghi[0], glo[0] - b0.w), 0.f);
+        const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - ghi[1], glo[1] - b1.x), 0.f);
+        const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - ghi[2], glo[2] - b1.y), 0.f);
+        const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;
+        const bool pass = cidx < c_hi && L < B;  // every candidate winner lies strictly below its point's starting bound
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+        if (mask != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(hcount, (int)__builtin_popcountll(mask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (pass) hits[base + rank] = cidx;
+        }
+    };
     for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
         // B only shrinks while the block works: refreshed once per round
         const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
         __syncthreads();  // the list is empty and its counter reset
-        for (int r = 0; r < round_passes; ++r) {
+        int r = 0;
+        if (rb == c_lo) {  // the first round's first passes use the boxes fetched at kernel entry
+#pragma unroll
+            for (; r < PRE; ++r) {
+                const int c0 = rb + (r * SP_NW + w) * 64;
+                if (r < round_passes && c0 < c_hi) find_pass(c0, pb[r][0], pb[r][1], B);
+            }
+        }
+        for (; r < round_passes; ++r) {
             const int c0 = rb + (r * SP_NW + w) * 64;
             if (c0 >= c_hi) break;
-            const int cidx = c0 + lane;
-            const bool valid = cidx < c_hi;
-            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(valid ? cidx : c_lo) * 8);
-            const float4 b0 = bp[0], b1 = bp[1];  // lo.xyz hi.x | hi.yz - -
-            const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - ghi[0], glo[0] - b0.w), 0.f);
-            const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - ghi[1], glo[1] - b1.x), 0.f);
-            const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - ghi[2], glo[2] - b1.y), 0.f);
-            const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;
-            const bool pass = valid && L < B;  // every candidate winner lies strictly below its point's starting bound
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
-            if (mask != 0ull) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(hcount, (int)__builtin_popcountll(mask));
-                base = __builtin_amdgcn_readfirstlane(base);
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                if (pass) hits[base + rank] = cidx;
-            }
+            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
+            find_pass(c0, bp[0], bp[1], B);
         }
         __syncthreads();
         const int H = *hcount;
-        for (int h = w; h < H; h += SP_NW) {
-            const int ch = __builtin_amdgcn_readfirstlane(hits[h]);
-            const float* bx = fuse.boxes + (size_t)ch * 8;
-            const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
-            if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], pxa, pya, pza, best)) == 0ull)
-                continue;
-            const float* qc = Q + (size_t)ch * 8;
-            scan_chunk_unordered<true>(qc, qc + m_pad, qc + 2 * (size_t)m_pad, px, py, pz, ch, best, cst);
-        }
-        if (rb + round_chunks < c_hi) {
-            // exchange: every wave restarts the next round from the block's best minimum so far, bumped by an ulp
-            // (d >= 0: the bit patterns order like the values, so this is an integer min)
-            if (real[0]) atomicMin(&smin[lane], __float_as_uint(best[0]));
-            if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(best[1]));
-            __syncthreads();
-            if (threadIdx.x == 0) *hcount = 0;
+        // The hits are dealt round-robin; a wave fetches the box and the coordinates of up to 8 of its hits with ONE
+        // gather -- 8 lanes x 16 bytes per hit -- into its private LDS stage, so a batch of hits costs one trip to
+        // memory instead of three or four each.
+        // (exchanging minima between the batches of a cold pass was measured too: the barriers cost more than they save)
+        {
+            const int h1 = H;
+            for (int hb = 0; hb < h1; hb += SP_NW * 8) {
+                {
+                    const int r = lane >> 3, part = lane & 7;
+                    const int h = hb + r * SP_NW + w;
+                    if (h < h1) {
+                        const int chl = hits[h];
+                        const float* src = part < 2 ? fuse.boxes + (size_t)chl * 8 + part * 4
+                                                    : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)chl * 8 + (part & 1) * 4;
+                        *reinterpret_cast<float4*>(stage + r * 32 + part * 4) = *reinterpret_cast<const float4*>(src);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // same wave: DS ops are in order; this pins the compiler
+                const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
+                const int cnt = mine < 8 ? mine : 8;
+                for (int rr = 0; rr < cnt; ++rr) {
+                    const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * SP_NW + w]);
+                    const float* sb = stage + rr * 32;
+                    const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
+                    if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull)
+                        continue;
+                    scan_chunk_unordered<false>(sb + 8, sb + 16, sb + 24, px, py, pz, ch, best, bj);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            }
+            if (rb + round_chunks < c_hi) {
+                // exchange before the next round: every wave goes on from the block's best minimum so far, bumped by
+                // an ulp (d >= 0: the bit patterns order like the values, so this is an integer min)
+                if (real[0]) atomicMin(&smin[lane], __float_as_uint(best[0]));
+                if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(best[1]));
+                __syncthreads();
+                if (threadIdx.x == 0) *hcount = 0;  // the list is consumed
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const unsigned int v = smin[lane + t * 64];
-                if (real[t] && v < 0x7f800000u && v < __float_as_uint(best[t])) { best[t] = __uint_as_float(v + 1u); cst[t] = -1; }
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned int v = smin[lane + t * 64];
+                    if (real[t] && v < 0x7f800000u && v < __float_as_uint(best[t])) { best[t] = __uint_as_float(v + 1u); bj[t] = -1; }
+                }
             }
         }
     }
     ICP_PHASE(3)
 
-    // index recovery inside the winning chunk (lowest j with d_j == min), then the in-block merge
+    // in-block merge: every wave hands in what it found (nothing: +inf)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const float pxt = t ? px.y : px.x, pyt = t ? py.y : py.x, pzt = t ? pz.y : pz.x;
-        const bool found = cst[t] >= 0;  // this wave lowered the (possibly seeded or exchanged) bound at least once
-        const int base = found ? cst[t] * 8 : 0;
-        int idx = 0x7fffffff;
-        const float b = found ? best[t] : inf_<float>();
-        if (found) {
-            idx = base;
-#pragma unroll 4
-            for (int kk = 7; kk >= 0; --kk) {
-                const int j = base + kk;
-                const float d = dist2<float>(pxt, pyt, pzt, Q[j], Q[(size_t)m_pad + j], Q[2 * (size_t)m_pad + j]);
-                idx = (d == b) ? j : idx;
-            }
-        }
-        md[w][lane + t * 64] = b;
-        mi[w][lane + t * 64] = idx;
+        const bool found = bj[t] >= 0;
+        md[w][lane + t * 64] = found ? best[t] : inf_<float>();
+        mi[w][lane + t * 64] = found ? bj[t] : 0x7fffffff;
     }
     ICP_PHASE(4)
     __syncthreads();
@@ -1999,8 +2085,14 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         fuse.boxes = pl.chunk == 8 ? (const float*)opt->boxes : nullptr;
     }
     if (ft) {
-        for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
-        for (int k = 0; k < 3; ++k) rt.t[k] = (float)ft->t3[k];
+        if (ft->mailbox) {
+            if (!pl.sparse) return hipErrorInvalidValue;  // only the sparse kernel can be armed
+            fuse.mailbox = ft->mailbox;
+            fuse.want = ft->want;
+        } else {
+            for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
+            for (int k = 0; k < 3; ++k) rt.t[k] = (float)ft->t3[k];
+        }
         fuse.apply = 1;
         fuse.n = pl.n;
         fuse.idx_prev = ft->idx_prev;
@@ -2031,6 +2123,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         fuse.boxes = (const float*)opt->boxes;
         static const int env_samples = env_int("ICP_NN_SAMPLES", 1);
         fuse.samples = env_samples ? (const float*)opt->samples : nullptr;
+        static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 64);
+        fuse.sample_groups = env_sgroups;
         static const int env_passes = env_int("ICP_NN_PASSES", 0);
         // seeded: few hits, long rounds; cold: short rounds so that the exchanged minima start pruning early
         int passes = env_passes > 0 ? env_passes : ((fuse.seed_idx || fuse.samples) ? SP_MAX_PASSES : 1);

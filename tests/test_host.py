@@ -38,7 +38,7 @@ def test_matching_isa_has_no_fused_multiply_add():
     asm = os.path.join(ROOT, "fast-point-cloud-registration-with-gpus_amd", "csrc", "build", "icp_kernels.s")
     assert os.path.exists(asm), "run `python __graft_entry__.py build` first"
     text = open(asm).read()
-    kernels = re.findall(r"^(_ZN3icp\w*(?:nn_match|knn4)\w*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    kernels = re.findall(r"^(_ZN3icp\w*(?:nn_match|knn4)\w*):[^\n]*\n(.*?)\.Lfunc_end", text, flags=re.S | re.M)
     assert len(kernels) >= 6
     bad = re.compile(r"\bv_(?:pk_)?(?:fma|fmac|mad|mac)_(?:f32|f64|legacy_f32)")
     for name, body in kernels:
