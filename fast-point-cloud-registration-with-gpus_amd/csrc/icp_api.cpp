@@ -15,6 +15,10 @@
 // indices of the last CONTRIBUTING pass survive the speculative one.
 #include <hip/hip_runtime.h>
 
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+#endif
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -49,6 +53,17 @@ int fail(int code, const std::string& msg)
         if (e_ != hipSuccess)                                                                                 \
             return fail(ICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
     } while (0)
+
+// orders the stores of a mailbox message before its sequence number (and pushes them out, should the mailbox ever
+// live in write-combining memory: the `lock or` compilers emit for a seq_cst fence does not do that)
+static inline void bar_fence()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    _mm_sfence();
+#else
+    __sync_synchronize();
+#endif
+}
 
 static constexpr int kMailSlots = 4;  // armed launches: ring of mailboxes (one is live at a time)
 static constexpr size_t kPhaseSlots = 512 * 1024;  // ICP_NN_PHASES: 10 stamps per wave
@@ -137,15 +152,24 @@ struct icp_ctx {
     int prof_nn_launches = 0;
     // ICP_TRACE=1: host-side time split of the loop, printed by icp_destroy
     bool trace = false;
+    double tr_first_row = 0.0;
+    bool trace_passes = false;         // ICP_TRACE=2: one line per pass of a resident registration
     double tr_enqueue = 0, tr_wait = 0, tr_reduce = 0, tr_solve = 0;
     uint64_t tr_n = 0;
     void* comm = nullptr;              // RCCL communicator (icp_comm_init): the loop all-reduces its vector itself
     bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
     bool arm = true;                   // ICP_ARMED=0: icp_loop_run never enqueues a pass ahead of its (R, t)
-    // ring of mailboxes for armed launches, in fine-grained DEVICE memory that the CPU writes through the PCIe BAR:
-    // the waiting kernel polls its own memory (tools/mailbox_probe.hip: 2.1 us host->kernel->host whatever the number
-    // of polling blocks, against 22.7 us when 128 blocks poll pinned host memory)
+    bool resident = true;              // ICP_RESIDENT=0: icp_loop_run never keeps one kernel for a whole registration
+    bool resident_refused = false;     // the cooperative launch did not fit this plan: do not try again
+    // ring of mailboxes for armed / resident launches, in pinned mapped host memory, and the device-memory relay.
+    // (Fine-grained device memory written through the PCIe BAR is ~0.5 us faster per message and needs no relay --
+    // tools/mailbox_probe.hip -- but with the HIP runtime that PyTorch bundles the waiting kernel never sees a
+    // store made after it started; host memory polled by ONE block works with every runtime.)
     icp::NNMailbox* h_mail = nullptr;
+    bool mail_in_bar = false;
+    // fine-grained device memory: ordinary (coarse-grained) device memory is cached per XCD L2, and a block polling
+    // it from another XCD keeps reading its stale line (seen as 24 of 128 blocks never receiving the message)
+    icp::NNMailbox* relay = nullptr;
     uint64_t mail_seq = 0;
     bool host_reduce() const { return !comm && mom_dev == (double*)mom_own.p && h_mom_partials != nullptr; }
     icp::NNPlan plan{};
@@ -163,8 +187,10 @@ int use(icp_ctx* c)
 
 int ensure_work_buffers(icp_ctx* c)
 {
+    const icp::NNPlan before = c->plan;
     c->plan = icp::nn_plan(c->n, c->m, c->prec, c->num_cus);
     const icp::NNPlan& pl = c->plan;
+    if (before.n_pad != pl.n_pad || before.m_pad != pl.m_pad) c->resident_refused = false;  // another geometry: ask again
     const size_t es = icp::elem_size(c->prec);
     const size_t S = pl.splits > 0 ? (size_t)pl.splits : 1;
     HIP_TRY(c->part_d.ensure(S * (size_t)pl.n_pad * es));
@@ -176,7 +202,7 @@ int ensure_work_buffers(icp_ctx* c)
     if ((size_t)pl.blocks_x > rows) rows = (size_t)pl.blocks_x;
     if (rows > c->rows_cap) {
         if (c->h_mom_partials) { (void)hipHostFree(c->h_mom_partials); c->h_mom_partials = nullptr; }
-        HIP_TRY(hipHostMalloc((void**)&c->h_mom_partials, rows * ICP_NMOM * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void**)&c->h_mom_partials, rows * ICP_NMOM * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(c->h_mom_partials, 0, rows * ICP_NMOM * sizeof(double));
         c->rows_cap = rows;
     }
@@ -197,7 +223,7 @@ int ensure_work_buffers(icp_ctx* c)
     if ((size_t)pl.blocks_x > err_rows) err_rows = (size_t)pl.blocks_x;
     if (err_rows > c->err_cap) {
         if (c->h_err_partials) { (void)hipHostFree(c->h_err_partials); c->h_err_partials = nullptr; }
-        HIP_TRY(hipHostMalloc((void**)&c->h_err_partials, err_rows * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void**)&c->h_err_partials, err_rows * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(c->h_err_partials, 0, err_rows * sizeof(double));
         c->err_cap = err_rows;
     }
@@ -307,6 +333,28 @@ int icp_device_count(void)
     return n;
 }
 
+static void mailbox_selftest(icp_ctx* c, int slot, const char* when)
+{
+    icp::NNMailbox* mb = c->h_mail + slot;
+    volatile double* ack = c->h_mom;
+    *ack = 0.0;
+    *(volatile double*)&mb->seq = 1.0;
+    bar_fence();
+    (void)icp::launch_mailbox_selftest(mb, c->h_mom, c->stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    while (*ack != 1.0 && since() < 5.0) {}
+    const double t_start = since();
+    *(volatile double*)&mb->seq = 2.0;
+    bar_fence();
+    while (*ack != 2.0 && *ack != -1.0 && since() < 10.0) {}
+    std::fprintf(stderr, "[icp selftest %s slot %d] kernel running after %.6f s; live store %s after %.6f s (ack %.0f)\n", when, slot, t_start,
+                 *ack == 2.0 ? "SEEN" : "NOT seen", since() - t_start, *ack);
+    (void)hipStreamSynchronize(c->stream);
+    *(volatile double*)&mb->seq = 0.0;
+    bar_fence();
+}
+
 int icp_create(int device, icp_ctx** out)
 {
     if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
@@ -328,14 +376,25 @@ int icp_create(int device, icp_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mom, ICP_NMOM * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) {
+        // mailbox: fine-grained device memory written through the PCIe BAR when the machine allows it (every block
+        // polls its own memory), else pinned host memory polled by block 0 and relayed (ICP_MAILBOX=host forces that)
+        const char* mv = std::getenv("ICP_MAILBOX");
         int large_bar = 0;
-        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
+        if (!(mv && mv[0] == 'h') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
             hipExtMallocWithFlags((void**)&c->h_mail, kMailSlots * sizeof(icp::NNMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
-            std::memset(c->h_mail, 0, kMailSlots * sizeof(icp::NNMailbox));
-            __sync_synchronize();
+            c->mail_in_bar = true;
         } else {
             (void)hipGetLastError();
-            c->h_mail = nullptr;  // no CPU-visible device memory: icp_loop_run launches every pass after its solve
+            e = hipHostMalloc((void**)&c->h_mail, kMailSlots * sizeof(icp::NNMailbox), hipHostMallocMapped | hipHostMallocCoherent);
+        }
+        if (e == hipSuccess) { std::memset(c->h_mail, 0, kMailSlots * sizeof(icp::NNMailbox)); bar_fence(); }
+    }
+    if (e == hipSuccess) {
+        if (hipExtMallocWithFlags((void**)&c->relay, sizeof(icp::NNMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
+            e = hipMemset(c->relay, 0, sizeof(icp::NNMailbox));
+        } else {
+            (void)hipGetLastError();
+            c->relay = nullptr;  // no armed / resident launches on this device: every pass is launched after its solve
         }
     }
 
@@ -347,7 +406,8 @@ int icp_create(int device, icp_ctx** out)
     c->stream = c->own_stream;
     if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
     if (const char* v = std::getenv("ICP_ARMED")) c->arm = !(v[0] == '0');
-    if (const char* v = std::getenv("ICP_TRACE")) c->trace = v[0] == '1';
+    if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_TRACE")) { c->trace = v[0] == '1' || v[0] == '2'; c->trace_passes = v[0] == '2'; }
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_PHASES")) {
@@ -359,6 +419,8 @@ int icp_create(int device, icp_ctx** out)
             icp::set_phase_log((long long*)c->phase_log.p, (long long)kPhaseSlots);
         }
     }
+    if (const char* v = std::getenv("ICP_SELFTEST"))
+        if (v[0] == '1') mailbox_selftest(c, 3, "create");
     *out = c;
     return ICP_OK;
 }
@@ -385,7 +447,8 @@ void icp_destroy(icp_ctx* c)
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
-    if (c->h_mail) (void)hipFree(c->h_mail);
+    if (c->h_mail) { if (c->mail_in_bar) (void)hipFree(c->h_mail); else (void)hipHostFree(c->h_mail); }
+    if (c->relay) (void)hipFree(c->relay);
     if (c->h_mom_partials) (void)hipHostFree(c->h_mom_partials);
     if (c->h_err_partials) (void)hipHostFree(c->h_err_partials);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -818,6 +881,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
                 const volatile double* tagp = c->h_mom_partials + (size_t)b * ICP_NMOM + (ICP_NMOM - 1);
                 if (*tagp == want) {
                     std::atomic_thread_fence(std::memory_order_acquire);
+                    if (c->trace_passes && b == 0) c->tr_first_row = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     add_row(b++);
                     continue;
                 }
@@ -826,6 +890,13 @@ int icp_loop_complete(icp_ctx* c, int* done)
                     break;  // something is wrong (fault, hang): let the runtime report it
             }
             polled = b == L.mom_blocks;
+            if (!polled && c->trace) {
+                std::fprintf(stderr, "[icp trace]   poll gave up at row %d; rows still missing:", b);
+                int shown = 0;
+                for (int r = 0; r < L.mom_blocks && shown < 40; ++r)
+                    if (c->h_mom_partials[(size_t)r * ICP_NMOM + (ICP_NMOM - 1)] != want) { std::fprintf(stderr, " %d", r); ++shown; }
+                std::fprintf(stderr, "\n");
+            }
         }
         tr1 = std::chrono::steady_clock::now();
         if (!polled) {
@@ -834,7 +905,12 @@ int icp_loop_complete(icp_ctx* c, int* done)
             for (int b = 0; b < L.mom_blocks; ++b)
                 if (c->h_mom_partials[(size_t)b * ICP_NMOM + (ICP_NMOM - 1)] != L.wait_tag) {
                     L.pending = false;
-                    return fail(ICP_ERR_HIP, "a matching pass ended without producing its rows (armed launch timed out?)");
+                    char msg[240];
+                    int have = 0;
+                    for (int r = 0; r < L.mom_blocks; ++r) have += c->h_mom_partials[(size_t)r * ICP_NMOM + (ICP_NMOM - 1)] == L.wait_tag ? 1 : 0;
+                    std::snprintf(msg, sizeof msg, "a matching pass ended without producing its rows: row %d of %d carries tag %.0f, expected %.0f; %d rows arrived (armed / resident launch timed out?)",
+                                  b, L.mom_blocks, c->h_mom_partials[(size_t)b * ICP_NMOM + (ICP_NMOM - 1)], L.wait_tag, have);
+                    return fail(ICP_ERR_HIP, msg);
                 }
             start_sum();
             for (int b = 0; b < L.mom_blocks; ++b) add_row(b);
@@ -882,7 +958,7 @@ bool can_arm(icp_ctx* c)
 {
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    return c->arm && c->h_mail && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
+    return c->arm && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
            icp::nn_can_fuse_transform(pl) && c->have_scan_copy && c->use_boxes && L.active && L.pending && !L.armed &&
            L.matched && !L.H.done && !L.H.have_rt &&
            !L.timed_nn &&  // a timed pass is completed with a stream synchronisation: nothing may wait behind it
@@ -900,7 +976,7 @@ int loop_arm(icp_ctx* c)
     icp::NNMailbox* mb = c->h_mail + slot;
     const double tag = (double)(++c->tag_seq);
     *(volatile double*)&mb->seq = 0.0;
-    __sync_synchronize();  // BAR memory is write-combining: a full fence orders AND flushes the stores
+    bar_fence();
     icp::NNTailArgs ta{};
     ta.metric = L.H.prm.metric;
     ta.keys = (unsigned long long*)c->keys.p;
@@ -910,7 +986,7 @@ int loop_arm(icp_ctx* c)
     ta.Nrm_soa = c->Nrm.p;
     ta.rows = c->h_mom_partials;
     ta.tag = tag;
-    icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[prev_cur].p, c->P2.p, (double*)c->err_partials.p, mb, tag};
+    icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[prev_cur].p, c->P2.p, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, tag};
     if (c->profile_stride > 0) c->nn_launch_count++;
     HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream));
     std::swap(c->P, c->P2);
@@ -929,9 +1005,10 @@ void loop_release_armed(icp_ctx* c)
     icp::NNMailbox* mb = c->h_mail + L.armed_slot;
     for (int k = 0; k < 9; ++k) mb->rt[k] = (float)L.H.R[k];
     for (int k = 0; k < 3; ++k) mb->rt[9 + k] = (float)L.H.t[k];
-    __sync_synchronize();
+    mb->cmd = icp::ICP_CMD_TRANSFORM_MATCH;
+    bar_fence();
     *(volatile double*)&mb->seq = L.armed_tag;
-    __sync_synchronize();
+    bar_fence();
     L.applied_idx = L.armed_prev_cur;
     L.H.note_applied();
     L.mom_blocks = c->plan.blocks_x;
@@ -951,10 +1028,119 @@ void loop_withdraw_armed(icp_ctx* c)
     if (!L.armed) return;
     icp::NNMailbox* mb = c->h_mail + L.armed_slot;
     *(volatile double*)&mb->seq = -L.armed_tag;
-    __sync_synchronize();
+    bar_fence();
     std::swap(c->P, c->P2);
     c->cur = L.armed_prev_cur;
     L.armed = false;
+}
+
+}  // namespace
+
+// ---- resident registration ---------------------------------------------------------------------------
+// One cooperative launch carries the whole loop: the blocks keep their points in registers and their seeds in
+// LDS, every pass is one mailbox message (command + R, t) and one set of rows coming back.  No launch, no
+// dispatch and no kernel boundary between two passes; what is left of an iteration is the pass itself plus one
+// host <-> device round trip (~2 us, tools/mailbox_probe.hip).  The host side is the step-wise loop unchanged:
+// the same HostLoop decides, the same rows are reduced in the same order -- the results are bit-identical.
+namespace {
+
+bool can_reside(icp_ctx* c)
+{
+    const LoopState& L = c->loop;
+    const icp::NNPlan& pl = c->plan;
+    return c->resident && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
+           icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done &&
+           c->profile_stride == 0;   // per-launch kernel timing (icp_set_profiling) wants one launch per pass
+}
+
+// returns ICP_OK with *fell_back = true when the resident kernel could not be launched (nothing has been done)
+int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fell_back)
+{
+    LoopState& L = c->loop;
+    icp::NNPlan rp = c->plan;   // the resident kernel closes every row inside its block: one segment
+    rp.splits = 1;
+    rp.seg_len = icp::round_up(rp.m_pad, 8);
+    if (const char* v = std::getenv("ICP_SELFTEST"))
+        if (v[0] == '2') { mailbox_selftest(c, 0, "loop"); mailbox_selftest(c, 1, "loop"); }
+    icp::NNMailbox* mb = c->h_mail + (int)(c->mail_seq++ % kMailSlots);
+    const int pass_cap = L.H.prm.max_iter + 2;
+    const double base = (double)(c->tag_seq + 1);
+    c->tag_seq += (uint64_t)pass_cap + 1;
+    *(volatile double*)&mb->seq = 0.0;
+    bar_fence();
+    const int c0 = c->cur;
+    const icp::NNCullInputs cull{c->Qs.p, L.matched ? (const int32_t*)c->idx[c0].p : nullptr, c->Qbox.p, c->Qsamp.p};
+    icp::NNTailArgs ta{};
+    ta.metric = L.H.prm.metric;
+    ta.keys = (unsigned long long*)c->keys.p;
+    ta.tickets = (unsigned int*)c->tickets.p;
+    ta.err_tile = (double*)c->err_partials.p;
+    ta.idx_out = (int32_t*)c->idx[c0 ^ 1].p;   // pass 0, 2, ... (the step-wise loop flips before it writes, too)
+    ta.idx_out_odd = (int32_t*)c->idx[c0].p;
+    ta.Nrm_soa = c->Nrm.p;
+    ta.rows = c->h_mom_partials;
+    ta.tag = 0.0;
+    icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[c0].p, c->P.p /* in place */, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, base, true};
+    const hipError_t le = icp::launch_nn(rp, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream);
+    if (le != hipSuccess) {
+        (void)hipGetLastError();
+        c->resident_refused = true;   // does not fit the machine (or cooperative launches are unavailable)
+        *fell_back = true;
+        return ICP_OK;
+    }
+    *fell_back = false;
+    if (c->trace) std::fprintf(stderr, "[icp trace] resident launch: mailbox %p relay %p base %.0f\n", (void*)mb, (void*)c->relay, base);
+    auto send = [&](int cmd, double seq) {
+        mb->cmd = cmd;
+        bar_fence();
+        *(volatile double*)&mb->seq = seq;
+        bar_fence();
+    };
+    int k = *k_io, d = *d_io, sent = 0, rc = ICP_OK;
+    bool alive = true;
+    while (!d && k < max_steps && sent < pass_cap) {
+        const auto tr0 = std::chrono::steady_clock::now();
+        const bool apply = L.H.have_rt;
+        const bool final_only = L.H.next_is_final();
+        const int cmd = !apply ? icp::ICP_CMD_MATCH : (final_only ? icp::ICP_CMD_TRANSFORM_ONLY : icp::ICP_CMD_TRANSFORM_MATCH);
+        if (apply) {
+            for (int q = 0; q < 9; ++q) mb->rt[q] = (float)L.H.R[q];
+            for (int q = 0; q < 3; ++q) mb->rt[9 + q] = (float)L.H.t[q];
+            L.applied_idx = c->cur;
+            L.H.note_applied();
+        }
+        if (cmd != icp::ICP_CMD_TRANSFORM_ONLY) {
+            c->cur ^= 1;
+            L.matched = true;
+            c->idx_valid = true;
+        }
+        send(cmd, base + (double)sent);
+        L.mom_blocks = rp.blocks_x;
+        L.err_blocks = 0;
+        L.rows_have_err = true;
+        L.host_reduce = true;
+        L.timed_nn = false;
+        L.wait_tag = base + (double)sent;
+        L.pending = true;
+        ++sent;
+        if (c->trace) c->tr_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+        const auto tc0 = std::chrono::steady_clock::now();
+        rc = icp_loop_complete(c, &d);
+        if (c->trace_passes)
+            std::fprintf(stderr, "[icp trace] resident pass %d cmd %d: %.2f us from message to reduced rows (row 0 after %.2f us)\n", sent - 1, cmd,
+                         1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count(), 1e6 * c->tr_first_row);
+        if (rc != ICP_OK) {
+            if (c->trace) std::fprintf(stderr, "[icp trace] resident pass %d failed: mailbox %p reads back seq %.0f cmd %d (sent seq %.0f)\n",
+                                       sent - 1, (void*)mb, *(volatile double*)&mb->seq, *(volatile int*)&mb->cmd, base + (double)(sent - 1));
+            break;
+        }
+        ++k;
+        if (cmd == icp::ICP_CMD_TRANSFORM_ONLY) { alive = false; break; }  // the kernel ends itself after that pass
+    }
+    if (alive) send(icp::ICP_CMD_EXIT, -(base + (double)sent));
+    *k_io = k;
+    *d_io = d;
+    return rc;
 }
 
 }  // namespace
@@ -964,6 +1150,11 @@ int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
     if (max_steps < 0) return fail(ICP_ERR_INVALID, "max_steps < 0");
     int d = c && c->loop.active && c->loop.H.done ? 1 : 0, k = 0;
     while (!d && k < max_steps) {
+        if (can_reside(c)) {
+            bool fell_back = false;
+            if (int rc = loop_run_resident(c, max_steps, &k, &d, &fell_back)) return rc;
+            if (!fell_back) continue;
+        }
         if (!c->loop.pending)
             if (int rc = icp_loop_enqueue(c)) return rc;
         if (k + 1 < max_steps && can_arm(c))

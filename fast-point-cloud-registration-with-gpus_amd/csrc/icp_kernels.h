@@ -42,12 +42,17 @@ size_t elem_size(int precision);
 
 // the transform of the previous pass, fused into the front of the matching kernel (fp32 kernel only):
 // P_out <- R * P_in + t, err_rows[block_x] <- sum |p_new - q[idx_prev]|^2
-// mailbox of an armed launch, in CPU-visible fine-grained device memory: the host stores rt, then (fenced) seq = +tag
-// to let the waiting kernel go, or seq = -tag to withdraw it
+// mailbox of an armed / resident launch, in pinned mapped host memory: the host stores rt and cmd, then (fenced)
+// seq = +tag to let the waiting kernel go, or seq = -tag to withdraw it.  Block 0 polls it and relays the message to
+// the other blocks through a copy in device memory (`relay`).
 struct NNMailbox {
     float rt[12];  // R row-major, then t -- already rounded to the storage precision
     double seq;
+    int cmd;       // ICP_CMD_*
+    int pad_;
 };
+enum { ICP_CMD_EXIT = 0, ICP_CMD_MATCH = 1, ICP_CMD_TRANSFORM_MATCH = 2, ICP_CMD_TRANSFORM_ONLY = 3 };
+hipError_t launch_mailbox_selftest(const NNMailbox* mb, double* ack, hipStream_t st);
 struct NNFusedTransform {
     const double* R9;  // NULL with a mailbox
     const double* t3;
@@ -55,7 +60,9 @@ struct NNFusedTransform {
     void* P_out;       // SoA, same padding as the input; must not alias it
     double* err_rows;  // >= blocks_x doubles
     const NNMailbox* mailbox = nullptr;  // armed launch (sparse kernel only): R9/t3 are not read
-    double want = 0.0;
+    NNMailbox* relay = nullptr;          // device-memory copy for the blocks other than block 0 (one per context)
+    double want = 0.0;                   // sequence number of the (first) message
+    bool resident = false;               // the kernel stays for the whole registration: pass p is message want + p
 };
 bool nn_can_fuse_transform(const NNPlan& pl);
 
@@ -86,6 +93,7 @@ struct NNTailArgs {
     unsigned int* tickets;      // [blocks_x]
     double* err_tile;           // [blocks_x] device
     int32_t* idx_out;           // [n_pad]
+    int32_t* idx_out_odd = nullptr;  // resident launch: odd passes write here (NULL: idx_out)
     const void* Nrm_soa;        // normals (plane)
     double* rows;               // [blocks_x][ICP_NMOM], pinned host or device
     double tag;

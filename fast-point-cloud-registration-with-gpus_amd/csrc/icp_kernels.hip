@@ -398,6 +398,7 @@ struct NNTail {
     unsigned int* tickets;     // [gridDim.x], zero between launches (reset by the last block)
     double* err_tile;          // [gridDim.x] device: error of the fused transform, from the grid.y == 0 block
     int32_t* idx_out;          // [n_pad]
+    int32_t* idx_out_odd;      // resident launch: the odd passes' correspondences (ping-pong with idx_out)
     const float* Nrm;          // model normals (SoA, m_pad) for TAIL == 2
     double* rows;              // [gridDim.x][ICP_NMOM]: pinned host (single GPU) or device (finalize follows)
     double tag;                // completion tag stored in slot ICP_NMOM-1 of the row
@@ -436,16 +437,19 @@ struct NNFuse {
     const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
     const float* boxes;      // CULL kernels: per 8-point chunk of the scan copy {lo.xyz, hi.xyz, -, -} (or NULL)
     int sample_groups;       // sparse kernel: at most this many groups of 8 samples are used by the cold start (<= 256)
+    int resident;            // resident launch: after a pass the block waits for the next message instead of ending
+    NNMailbox* relay;        // ... relayed by block 0 to the other blocks through this device-memory copy
     const NNMailbox* mailbox; // armed launch (sparse kernel): (R, t) arrive here from the host AFTER the kernel was enqueued
     double want;             // ... under this sequence number (+want: go, -want: withdrawn)
     const float* samples;    // sparse kernel: one point per chunk of the scan copy (SoA, round_up(m_pad/8, 8) entries) or NULL
     long long* tlog;         // diagnostic (ICP_NN_PHASES): per-wave s_memrealtime stamps, 10 slots per wave, or NULL
     long long tlog_cap;      // slots available
+    int tlog_pass;           // resident launch: stamp this pass only (-1: every pass, the last one survives)
 };
 
 // phase stamp of the diagnostic log: one scalar branch when the log is off
 #define ICP_PHASE(PH)                                                                                              \
-    if (fuse.tlog != nullptr && lane == 0) {                                                                       \
+    if (fuse.tlog != nullptr && lane == 0 && (fuse.tlog_pass < 0 || fuse.tlog_pass == phase_pass_)) {                                                                       \
         const long long slot_ = (((long long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + w) * 10 + (PH);            \
         if (slot_ < fuse.tlog_cap) fuse.tlog[slot_] = (long long)wall_clock64();                                   \
     }
@@ -474,6 +478,7 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
     // the wave id as a SCALAR: everything derived from it (ranges, loop bounds, the box addresses) then lives in
     // SGPRs, the loops are scalar loops and the per-chunk boxes arrive through the scalar cache
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int phase_pass_ = 0;  // (phase log)
     const int wseg = seg_len >> 2;              // model points per wave (multiple of C)
     const int q0 = blockIdx.y * seg_len;
     const int my0 = q0 + w * wseg;
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
             tail.tickets[blockIdx.x] = 0u;
         }
         __threadfence_system();  // the row is visible to a polling host before its tag
-        if (lane == 0) row[ICP_NMOM - 1] = tail.tag;
+        if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], tail.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         ICP_PHASE(8)
     }
 }
@@ -916,9 +921,10 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
 template <int TAIL>
 __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f2 pz, const int (&j)[2], int lane, int ibase,
                                                int m_pad, const NNFuse& fuse, const NNTail& tail, double err_row,
-                                               unsigned char* lds_raw)
+                                               unsigned char* lds_raw, float (&qout)[2][3])
 {
     constexpr int w = 0;  // (phase log) the closing wave
+    const int phase_pass_ = fuse.tlog_pass;
     constexpr int NACC = TAIL == 2 ? 28 : 18;
     double acc[NACC];
 #pragma unroll
@@ -931,7 +937,8 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
             const int jj = j[t];
             tail.idx_out[i] = jj;
             const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
-            const double qx = (double)Qg[jj], qy = (double)Qg[(size_t)m_pad + jj], qz = (double)Qg[2 * (size_t)m_pad + jj];
+            qout[t][0] = Qg[jj]; qout[t][1] = Qg[(size_t)m_pad + jj]; qout[t][2] = Qg[2 * (size_t)m_pad + jj];
+            const double qx = (double)qout[t][0], qy = (double)qout[t][1], qz = (double)qout[t][2];
             acc[0] += 1.0;
             if constexpr (TAIL == 1) {
                 acc[1] += ppx; acc[2] += ppy; acc[3] += ppz;
@@ -975,7 +982,9 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
     if (lane == 0) row[ICP_MOM_ERR] = err_row;
     ICP_PHASE(8)
     __threadfence_system();  // the row is visible to a polling host before its tag
-    if (lane == 0) row[ICP_NMOM - 1] = tail.tag;
+    // (a system-scope store: it must reach the host NOW -- a plain one may sit in the L2 until the kernel ends,
+    // which a resident kernel does not do for a long time)
+    if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], tail.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int TAIL>
@@ -989,7 +998,8 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     constexpr int TR_BYTES = TAIL ? (TAIL == 2 ? 28 : 18) * 65 * 8 : 0;
     static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
     constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * 32 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_OFF + STAGE_BYTES];
+    constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SEED_OFF + 3 * 128 * 4];
     int* hits = reinterpret_cast<int*>(lds_raw);
     float (*md)[128] = reinterpret_cast<float (*)[128]>(lds_raw + HITS_BYTES);
     int (*mi)[128] = reinterpret_cast<int (*)[128]>(lds_raw + HITS_BYTES + MD_BYTES);
@@ -1000,6 +1010,9 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ibase = blockIdx.x * 128 + lane;
     float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * 32);  // per wave: 8 hits x {box 8, x 8, y 8, z 8}
+    float* msg = reinterpret_cast<float*>(lds_raw + MSG_OFF);
+    float (*seedq)[128] = reinterpret_cast<float (*)[128]>(lds_raw + SEED_OFF);
+    int phase_pass_ = 0;  // (phase log)
     ICP_PHASE(0)
     // issued first, with everything else that does not depend on the points: the chunk boxes of the wave's first
     // two find passes ...
@@ -1037,42 +1050,88 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     px = f2{P[ibase], P[ibase + 64]};
     py = f2{P[(size_t)n_pad + ibase], P[(size_t)n_pad + ibase + 64]};
     pz = f2{P[2 * (size_t)n_pad + ibase], P[2 * (size_t)n_pad + ibase + 64]};
+    // ---- the pass loop: one turn for an ordinary launch, one per ICP pass for a resident one -------------------
+    // Armed launch: the kernel was enqueued while the previous pass was still running, so the launch and dispatch
+    // latencies are behind it; what it lacks is the (R, t) the host is solving for.  Resident launch: the same,
+    // carried through -- the blocks stay on the machine for the whole registration (cooperative launch: they are
+    // all resident), keep their points in registers and their seeds in LDS, and every pass is one message from the
+    // host: no launch, no dispatch, no kernel boundary between two passes.
+    // Wave 0 of every block waits for the message (see below), the other waves sleep at the barrier.  The poll budget
+    // (a few seconds) is the exit every wave reaches if the host never answers.
+    for (int pass = 0;; ++pass) {
+    phase_pass_ = pass;
     double err_row = 0.0;
     RT<float> rt = rt_arg;
+    int cmd = fuse.apply ? ICP_CMD_TRANSFORM_MATCH : ICP_CMD_MATCH;
+    double row_tag = tail.tag;
+    const bool have_seeds = pass > 0 || fuse.seed_idx != nullptr;
+    if (threadIdx.x < 128) smin[threadIdx.x] = 0x7f800000u;
+    if (threadIdx.x == 0) *hcount = 0;
     if (fuse.mailbox != nullptr) {
-        // Armed launch: this kernel was enqueued while the previous pass was still running, so the launch and
-        // dispatch latencies are already behind it; what it still lacks is the (R, t) the host is solving for.
-        // Wave 0 watches the mailbox -- device memory the host writes through the BAR, so the poll is a local read;
-        // the other waves sleep at the barrier -- and everything above (points, seeds, boxes) is already in flight.
-        // The poll budget (a few seconds) is the exit every wave reaches if the host never answers.
-        float* rtl = reinterpret_cast<float*>(lds_raw);  // 12 floats + status, over the (still idle) hit list
+        const double want = fuse.want + (double)pass;
         if (w == 0) {
-            const double* seqp = &fuse.mailbox->seq;
+            // Block 0 alone talks to the host: it polls the mailbox in pinned host memory (one reader: ~1.3 us each
+            // way; 128 readers would queue up to ~20 us, tools/mailbox_probe.hip) and relays the message through
+            // device memory, where the other blocks wait for it with agent-scope loads.
+            // (no relay: the mailbox itself is device memory the host writes through the BAR, every block polls it)
+            const bool first = (blockIdx.x == 0 && blockIdx.y == 0) || fuse.relay == nullptr;
+            const NNMailbox* src = first ? fuse.mailbox : fuse.relay;
             double sq_ = 0.0;
             for (int spins = 0; spins < (1 << 22); ++spins) {
-                sq_ = __hip_atomic_load(seqp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (sq_ == fuse.want || sq_ == -fuse.want) break;
-                __builtin_amdgcn_s_sleep(4);
+                sq_ = first ? __hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                            : __hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sq_ == want || sq_ == -want) break;
+                __builtin_amdgcn_s_sleep(2);
             }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (R, t) were released before the sequence number
-            const bool go = sq_ == fuse.want;
-            if (go && lane < 12) rtl[lane] = __hip_atomic_load(&fuse.mailbox->rt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (lane == 0) reinterpret_cast<int*>(rtl)[12] = go ? 1 : 0;
+            // the message was written before its sequence number
+            if (first) __atomic_thread_fence(__ATOMIC_ACQUIRE); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const bool go = sq_ == want;
+            float v = 0.f;
+            int cm = ICP_CMD_EXIT;
+            if (first) {
+                if (lane < 12) v = __hip_atomic_load(&src->rt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (go) cm = __hip_atomic_load(&src->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // relay (also a withdrawal or a time-out: the other blocks must end too)
+                if (fuse.relay != nullptr) {
+                    NNMailbox* dst = fuse.relay;
+                    if (lane < 12) __hip_atomic_store(&dst->rt[lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_store(&dst->cmd, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) __hip_atomic_store(&dst->seq, go ? want : -want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                }
+            } else {
+                if (lane < 12) v = __hip_atomic_load(&src->rt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (go) cm = __hip_atomic_load(&src->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane < 12) msg[lane] = v;
+            if (lane == 0) reinterpret_cast<int*>(msg)[12] = cm;
         }
         __syncthreads();
-        const int go = reinterpret_cast<const int*>(rtl)[12];
-        if (go == 0) return;  // withdrawn (the loop stopped) or timed out: nothing has been touched
+        cmd = reinterpret_cast<const int*>(msg)[12];
+        if (cmd == ICP_CMD_EXIT) return;  // withdrawn (the loop stopped) or timed out: nothing more is touched
 #pragma unroll
-        for (int k = 0; k < 9; ++k) rt.r[k] = rtl[k];
+        for (int k = 0; k < 9; ++k) rt.r[k] = msg[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) rt.t[k] = rtl[9 + k];
-        __syncthreads();  // the hit list takes this space over
+        for (int k = 0; k < 3; ++k) rt.t[k] = msg[9 + k];
+        row_tag = want;
+        if (pass > 0) {
+            // the seeds of a resident pass are the matches of the one before: wave 0 left their coordinates in LDS
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                sok[t] = real[t];
+                sq[t][0] = seedq[0][lane + t * 64]; sq[t][1] = seedq[1][lane + t * 64]; sq[t][2] = seedq[2][lane + t * 64];
+            }
+        }
+    } else {
+        __syncthreads();  // the list counter and the exchange minima are reset
     }
-    if (fuse.apply) {
+    const bool apply = cmd != ICP_CMD_MATCH;
+    if (apply) {
         // every wave re-derives the moved points in registers (same instructions => same bits); wave 0 of the
         // grid.y == 0 block stores them and accounts the error of the pass that produced (R, t)
         double err = 0.0;
-        const bool shared_gather = fuse.idx_prev == fuse.seed_idx;
+        const bool shared_gather = pass > 0 || fuse.idx_prev == fuse.seed_idx;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
@@ -1108,13 +1167,25 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         }
     }
     ICP_PHASE(1)
+    if (cmd == ICP_CMD_TRANSFORM_ONLY) {
+        // the loop's last pass: nothing is matched any more, the row carries the error alone
+        if constexpr (TAIL != 0) {
+            if (w == 0) {
+                double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
+                if (lane < ICP_NMOM - 1) row[lane] = lane == ICP_MOM_ERR ? err_row : 0.0;
+                __threadfence_system();
+                if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], row_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
     float best[2];
     int bj[2];  // index of the running minimum; -1: this wave has not lowered the bound it started from
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         bj[t] = -1;
         best[t] = inf_<float>();
-        if (fuse.seed_idx) {
+        if (have_seeds) {
             // seeded bound: the distance to ANY model point (last pass's match) bumped by one ulp -- the true minimum
             // is <= that distance < bound, so the seed changes how much work is skipped, never the answer
             const float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
@@ -1124,9 +1195,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         // padding lanes never ask for a chunk (their result, "nothing found", is never read)
         best[t] = real[t] ? best[t] : -1.f;
     }
-    if (threadIdx.x < 128) smin[threadIdx.x] = 0x7f800000u;
-    if (threadIdx.x == 0) *hcount = 0;
-    if (fuse.seed_idx == nullptr && fuse.samples != nullptr) {
+    if (!have_seeds && fuse.samples != nullptr) {
         // Cold start: no previous match to seed the bounds, so the block measures its points against a thinned-out
         // model first -- one point per chunk, at most 2048 of them, staged in LDS (over the hit list and the merge
         // scratch, both idle until later), a share per wave -- and every wave starts from the block-wide minimum
@@ -1190,7 +1259,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
         // B only shrinks while the block works: refreshed once per round
         const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
-        __syncthreads();  // the list is empty and its counter reset
+        if (rb != c_lo) __syncthreads();  // the list is empty and its counter reset (first round: the barrier above)
         int r = 0;
         if (rb == c_lo) {  // the first round's first passes use the boxes fetched at kernel entry
 #pragma unroll
@@ -1264,7 +1333,11 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     ICP_PHASE(4)
     __syncthreads();
     ICP_PHASE(5)
-    if (w != 0) return;  // wave 0 finishes the row: it holds both of every lane's points in registers
+    // wave 0 finishes the row: it holds both of every lane's points in registers
+    if (w != 0) {
+        if (!fuse.resident) return;
+        continue;  // resident: on to the next message (asleep at its barrier while wave 0 works)
+    }
 
     float fb[2];
     int fj[2];
@@ -1290,6 +1363,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             part_d[o] = fb[t];
             part_idx[o] = fj[t];
         }
+        return;
     } else {
         if (gridDim.y > 1) {
             // several segment blocks share the row: fold into the 64-bit (d, idx) keys and draw a ticket, the
@@ -1318,11 +1392,41 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) fj[t] = ((unsigned)fj[t] < (unsigned)fuse.m) ? fj[t] : fuse.m - 1;  // unreachable clamp
-        tail_close_row<TAIL>(px, py, pz, fj, lane, ibase, m_pad, fuse, tail, fuse.apply ? err_row : 0.0, lds_raw);
+        NNTail tl = tail;
+        tl.tag = row_tag;
+        tl.idx_out = (pass & 1) ? tail.idx_out_odd : tail.idx_out;
+        tail_close_row<TAIL>(px, py, pz, fj, lane, ibase, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq);
         ICP_PHASE(9)
+        if (!fuse.resident) return;
+        // the matches of this pass seed the next one and are what its error is measured against
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            sok[t] = real[t];
+            seedq[0][lane + t * 64] = sq[t][0]; seedq[1][lane + t * 64] = sq[t][1]; seedq[2][lane + t * 64] = sq[t][2];
+        }
     }
+    }  // pass loop
 }
 #undef ICP_PHASE
+
+// diagnostic (ICP_SELFTEST=1): does a running kernel see a store the host makes AFTER the kernel has started?
+// The kernel reports that it runs (ack = 1), waits for mb->seq == 2 and answers ack = 2 (or -1 when its budget ends).
+__global__ void mailbox_selftest_kernel(const NNMailbox* mb, double* ack)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(ack, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    double s = 0.0;
+    for (int spins = 0; spins < (1 << 20); ++spins) {
+        s = __hip_atomic_load(&mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (s == 2.0) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ack, s == 2.0 ? 2.0 : -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_mailbox_selftest(const NNMailbox* mb, double* ack, hipStream_t st)
+{
+    hipLaunchKernelGGL(mailbox_selftest_kernel, dim3(1), dim3(64), 0, st, mb, ack);
+    return hipGetLastError();
+}
 
 // bounding box of every 8-point chunk of the duplicate-voided scan copy (voided = +inf entries are ignored; an
 // all-void chunk gets lo = +inf, hi = -inf and is skipped by construction).  Once per model.
@@ -2078,6 +2182,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     fuse.Q_gather = (const float*)Q;
     fuse.tlog = g_phase_log;
     fuse.tlog_cap = g_phase_log_cap;
+    static const int env_tpass = env_int("ICP_NN_PHASE_PASS", -1);
+    fuse.tlog_pass = env_tpass;
     const void* Qscan = Q;
     if (pl.cull && opt && opt->Q_scan) {
         Qscan = opt->Q_scan;
@@ -2088,7 +2194,9 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         if (ft->mailbox) {
             if (!pl.sparse) return hipErrorInvalidValue;  // only the sparse kernel can be armed
             fuse.mailbox = ft->mailbox;
+            fuse.relay = ft->relay;
             fuse.want = ft->want;
+            fuse.resident = ft->resident ? 1 : 0;
         } else {
             for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
             for (int k = 0; k < 3; ++k) rt.t[k] = (float)ft->t3[k];
@@ -2106,6 +2214,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         tail.tickets = ta->tickets;
         tail.err_tile = ta->err_tile;
         tail.idx_out = ta->idx_out;
+        tail.idx_out_odd = ta->idx_out_odd ? ta->idx_out_odd : ta->idx_out;
         tail.Nrm = (const float*)ta->Nrm_soa;
         tail.rows = ta->rows;
         tail.tag = ta->tag;
@@ -2129,6 +2238,20 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         // seeded: few hits, long rounds; cold: short rounds so that the exchanged minima start pruning early
         int passes = env_passes > 0 ? env_passes : ((fuse.seed_idx || fuse.samples) ? SP_MAX_PASSES : 1);
         if (passes > SP_MAX_PASSES) passes = SP_MAX_PASSES;
+        if (fuse.resident) {
+            // one cooperative launch for the whole registration: every block must be on the machine at once (they
+            // all wait for the same host), which is exactly what the cooperative launch guarantees or refuses
+            if (!ta || pl.splits != 1) return hipErrorInvalidValue;
+            const float* Pp = (const float*)P;
+            const float* Qp = (const float*)opt->Q_scan;
+            int n_pad = pl.n_pad, m_pad = pl.m_pad, seg = pl.seg_len;
+            float* pd = (float*)part_d;
+            void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
+            const void* fn = ta->metric == ICP_POINT_TO_PLANE ? (const void*)nn_match_sparse<2> : (const void*)nn_match_sparse<1>;
+            static const int env_coop = env_int("ICP_COOP", 1);
+            if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
+            return hipLaunchKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
+        }
 #define ICP_LAUNCH_SP(TL)                                                                                          \
     hipLaunchKernelGGL((nn_match_sparse<TL>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,              \
                        (const float*)opt->Q_scan, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail)
