@@ -830,7 +830,8 @@ constexpr int SP_MAX_PASSES = SP_HCAP / (SP_NW * 64);
 // winner's; the index inside the chunk (lowest k with d_k == minimum) is worked out only then
 template <bool QS>
 __device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const float* qyp, const float* qzp, const f2 px,
-                                                     const f2 py, const f2 pz, int ch, float (&best)[2], int (&bj)[2])
+                                                     const f2 py, const f2 pz, int ch, float (&best)[2], int (&bj)[2],
+                                                     float (&bq)[2][3])
 {
     constexpr int C = 8;
     f2 d[C];  // first dx*dx + dy*dy (the inner sum of the reference's association), then the distances
@@ -885,6 +886,10 @@ __device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const flo
         bj[0] = take0 ? ch * C + k0 : bj[0];
         best[1] = take1 ? c1 : best[1];
         bj[1] = take1 ? ch * C + k1 : bj[1];
+        // the coordinates of the new minimum are at hand (LDS stage): keeping them saves the closing wave a
+        // dependent gather from global memory
+        if (take0) { bq[0][0] = qxp[k0]; bq[0][1] = qyp[k0]; bq[0][2] = qzp[k0]; }
+        if (take1) { bq[1][0] = qxp[k1]; bq[1][1] = qyp[k1]; bq[1][2] = qzp[k1]; }
     }
 }
 
@@ -918,13 +923,13 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
 // moment row of one row of 128 moving points, by ONE wave holding them two per lane (px.x = point lane,
 // px.y = point lane + 64) with their final correspondences j[]: stores idx, gathers q (and the normal),
 // accumulates in fp64, reduces through LDS in lane order and writes the row + completion tag.
+// (qio: the coordinates of the correspondences -- gathered here when `gather`, else supplied by the caller)
 template <int TAIL>
 __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f2 pz, const int (&j)[2], int lane, int ibase,
                                                int m_pad, const NNFuse& fuse, const NNTail& tail, double err_row,
-                                               unsigned char* lds_raw, float (&qout)[2][3])
+                                               unsigned char* lds_raw, float (&qio)[2][3], bool gather, int phase_pass_ = 0)
 {
     constexpr int w = 0;  // (phase log) the closing wave
-    const int phase_pass_ = fuse.tlog_pass;
     constexpr int NACC = TAIL == 2 ? 28 : 18;
     double acc[NACC];
 #pragma unroll
@@ -937,8 +942,8 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
             const int jj = j[t];
             tail.idx_out[i] = jj;
             const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
-            qout[t][0] = Qg[jj]; qout[t][1] = Qg[(size_t)m_pad + jj]; qout[t][2] = Qg[2 * (size_t)m_pad + jj];
-            const double qx = (double)qout[t][0], qy = (double)qout[t][1], qz = (double)qout[t][2];
+            if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
+            const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
             acc[0] += 1.0;
             if constexpr (TAIL == 1) {
                 acc[1] += ppx; acc[2] += ppy; acc[3] += ppz;
@@ -967,23 +972,42 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
             }
         }
     }
+    ICP_PHASE(7)
     // one wave: transpose through LDS (rows padded to 65 doubles), lane k adds slot k in lane order
     double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
 #pragma unroll
     for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // same wave: DS ops are in order; this pins the compiler
     double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
-    if (lane < NACC) {
-        double sum = 0.0;
-#pragma unroll 8
-        for (int l = 0; l < 64; ++l) sum += tr[lane][l];
-        row[1 + lane] = sum;
+    // Slot k is the sum of its 64 lane entries in a FIXED order: PARTS lanes per slot add a contiguous share each
+    // (loaded first, added after: the LDS latencies overlap), the shares are then added in part order.
+    constexpr int PARTS = 64 / NACC, PER = (64 + PARTS - 1) / PARTS;
+    double* tp = &tr[NACC][0];  // PARTS x NACC partial sums, behind the transpose rows
+    {
+        const int slot = lane % NACC, part = lane / NACC;
+        if (part < PARTS) {
+            double v[PER];
+#pragma unroll
+            for (int l = 0; l < PER; ++l) v[l] = (part * PER + l < 64) ? tr[slot][part * PER + l] : 0.0;
+            double sum = 0.0;
+#pragma unroll
+            for (int l = 0; l < PER; ++l) sum += v[l];
+            tp[part * NACC + slot] = sum;
+        }
     }
-    if (lane == 0) row[ICP_MOM_ERR] = err_row;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    // The row goes out as system-scope (write-through) stores, drained before the tag is issued: the host may
+    // read the row as soon as it sees the tag.  (No L2 write-back here -- it would flush the whole cache for the
+    // sake of 19 doubles; the other outputs of the pass are for later kernels and become visible at kernel end.)
+    if (lane < NACC) {
+        double sum = tp[lane];
+#pragma unroll
+        for (int q = 1; q < PARTS; ++q) sum += tp[q * NACC + lane];
+        __hip_atomic_store(&row[1 + lane], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lane == 0) __hip_atomic_store(&row[ICP_MOM_ERR], err_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     ICP_PHASE(8)
-    __threadfence_system();  // the row is visible to a polling host before its tag
-    // (a system-scope store: it must reach the host NOW -- a plain one may sit in the L2 until the kernel ends,
-    // which a resident kernel does not do for a long time)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], tail.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -995,14 +1019,19 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                                                               NNTail tail)
 {
     constexpr int HITS_BYTES = SP_HCAP * 4, MD_BYTES = SP_NW * 128 * 4;
-    constexpr int TR_BYTES = TAIL ? (TAIL == 2 ? 28 : 18) * 65 * 8 : 0;
+    constexpr int TR_BYTES = TAIL ? ((TAIL == 2 ? 28 : 18) * 65 + 64) * 8 : 0;
     static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
     constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * 32 * 4;
     constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SEED_OFF + 3 * 128 * 4];
+    constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x SP_NW x 128
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MQ_OFF + 3 * MD_BYTES];
     int* hits = reinterpret_cast<int*>(lds_raw);
-    float (*md)[128] = reinterpret_cast<float (*)[128]>(lds_raw + HITS_BYTES);
-    int (*mi)[128] = reinterpret_cast<int (*)[128]>(lds_raw + HITS_BYTES + MD_BYTES);
+    // merge scratch: one (distance, index, wave) key per moving point, folded with LDS atomic mins -- the 64-bit
+    // integer order is the lexicographic order the tie rule needs (d >= 0; index < 2^28; the wave id rides in the
+    // low 4 bits and tells the closing wave whose coordinates to pick up)
+    // (placed behind the 24 KB the cold start stages its samples in)
+    unsigned long long* mkey = reinterpret_cast<unsigned long long*>(lds_raw + 3 * 2048 * 4);
+    static_assert(3 * 2048 * 4 + 128 * 8 <= HITS_BYTES + 2 * MD_BYTES, "merge keys fit behind the sample stage");
     unsigned int* smin = reinterpret_cast<unsigned int*>(lds_raw + HITS_BYTES + 2 * MD_BYTES);
     int* hcount = reinterpret_cast<int*>(lds_raw + HITS_BYTES + 2 * MD_BYTES + 128 * 4);
 
@@ -1012,6 +1041,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * 32);  // per wave: 8 hits x {box 8, x 8, y 8, z 8}
     float* msg = reinterpret_cast<float*>(lds_raw + MSG_OFF);
     float (*seedq)[128] = reinterpret_cast<float (*)[128]>(lds_raw + SEED_OFF);
+    float (*mq)[SP_NW][128] = reinterpret_cast<float (*)[SP_NW][128]>(lds_raw + MQ_OFF);
     int phase_pass_ = 0;  // (phase log)
     ICP_PHASE(0)
     // issued first, with everything else that does not depend on the points: the chunk boxes of the wave's first
@@ -1065,7 +1095,10 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     int cmd = fuse.apply ? ICP_CMD_TRANSFORM_MATCH : ICP_CMD_MATCH;
     double row_tag = tail.tag;
     const bool have_seeds = pass > 0 || fuse.seed_idx != nullptr;
-    if (threadIdx.x < 128) smin[threadIdx.x] = 0x7f800000u;
+    if (w == 0) {  // (wave 0 alone: in a resident launch it may still be reading last pass's keys when the others get here)
+        smin[lane] = 0x7f800000u; smin[lane + 64] = 0x7f800000u;
+        mkey[lane] = ~0ull; mkey[lane + 64] = ~0ull;
+    }
     if (threadIdx.x == 0) *hcount = 0;
     if (fuse.mailbox != nullptr) {
         const double want = fuse.want + (double)pass;
@@ -1180,6 +1213,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         return;
     }
     float best[2];
+    float bq[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // coordinates of the running minimum
     int bj[2];  // index of the running minimum; -1: this wave has not lowered the bound it started from
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1302,7 +1336,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                     const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
                     if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull)
                         continue;
-                    scan_chunk_unordered<false>(sb + 8, sb + 16, sb + 24, px, py, pz, ch, best, bj);
+                    scan_chunk_unordered<false>(sb + 8, sb + 16, sb + 24, px, py, pz, ch, best, bj, bq);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             }
@@ -1323,12 +1357,14 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     }
     ICP_PHASE(3)
 
-    // in-block merge: every wave hands in what it found (nothing: +inf)
+    // in-block merge: every wave that lowered its bound folds its candidate into the point's key
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const bool found = bj[t] >= 0;
-        md[w][lane + t * 64] = found ? best[t] : inf_<float>();
-        mi[w][lane + t * 64] = found ? bj[t] : 0x7fffffff;
+        if (bj[t] >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best[t]) << 32) | ((unsigned int)bj[t] << 4) | (unsigned int)w;
+            atomicMin(&mkey[lane + t * 64], key);
+            mq[0][w][lane + t * 64] = bq[t][0]; mq[1][w][lane + t * 64] = bq[t][1]; mq[2][w][lane + t * 64] = bq[t][2];
+        }
     }
     ICP_PHASE(4)
     __syncthreads();
@@ -1343,18 +1379,13 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     int fj[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        float b = md[0][lane + t * 64];
-        int bi = mi[0][lane + t * 64];
-#pragma unroll
-        for (int ww = 1; ww < SP_NW; ++ww) {
-            const float d = md[ww][lane + t * 64];
-            const int j = mi[ww][lane + t * 64];
-            const bool lower = (d < b) | ((d == b) & (j < bi));
-            b = lower ? d : b;
-            bi = lower ? j : bi;
-        }
-        fb[t] = b;
-        fj[t] = bi;
+        const unsigned long long key = mkey[lane + t * 64];
+        const bool none = key == ~0ull;  // no wave found anything below the bound (padding lanes)
+        const unsigned int lo = (unsigned int)key;
+        fb[t] = none ? inf_<float>() : __uint_as_float((unsigned int)(key >> 32));
+        fj[t] = none ? 0x7fffffff : (int)(lo >> 4);
+        const int bw = none ? 0 : (int)(lo & 15u);
+        sq[t][0] = mq[0][bw][lane + t * 64]; sq[t][1] = mq[1][bw][lane + t * 64]; sq[t][2] = mq[2][bw][lane + t * 64];
     }
     if constexpr (TAIL == 0) {
 #pragma unroll
@@ -1395,7 +1426,9 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         NNTail tl = tail;
         tl.tag = row_tag;
         tl.idx_out = (pass & 1) ? tail.idx_out_odd : tail.idx_out;
-        tail_close_row<TAIL>(px, py, pz, fj, lane, ibase, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq);
+        // (a row closed over several segment blocks may have been won elsewhere: its coordinates are gathered)
+        if (gridDim.y == 1) { ICP_PHASE(6) }
+        tail_close_row<TAIL>(px, py, pz, fj, lane, ibase, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gridDim.y > 1, pass);
         ICP_PHASE(9)
         if (!fuse.resident) return;
         // the matches of this pass seed the next one and are what its error is measured against
@@ -2228,6 +2261,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     if (pl.sparse) {
         // the plan's geometry is the sparse kernel's: it needs the scan copy and its chunk boxes
         if (!(opt && opt->Q_scan && opt->boxes)) return hipErrorInvalidValue;
+        if (pl.m_pad >= (1 << 28)) return hipErrorInvalidValue;  // the in-block merge key carries 28 index bits
         fuse.seed_idx = opt->seed_idx;
         fuse.boxes = (const float*)opt->boxes;
         static const int env_samples = env_int("ICP_NN_SAMPLES", 1);

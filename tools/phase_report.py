@@ -4,8 +4,8 @@
     ICP_NN_PHASES=/tmp/ph.bin python tools/phase_run.py && python tools/phase_report.py /tmp/ph.bin [waves_per_block]
 
 Stamps are s_memrealtime ticks (100 MHz -> 10 ns).  Phases: 0 entry, 1 points loaded (+ message received, fused
-transform/error), 2 bounds seeded, 3 scan done, 4 results handed in, 5 block met, 6 keys merged (atomics drained),
-7 ticket drawn, 8 row stored, 9 fenced + tagged (closing wave only).  With ICP_NN_PHASE_PASS=p only pass p of a
+transform/error), 2 bounds seeded, 3 scan done, 4 results handed in, 5 block met, 6 results merged (or keys merged, atomics
+drained), 7 moments accumulated (or ticket drawn), 8 row stores issued, 9 drained + tagged (closing wave only).  With ICP_NN_PHASE_PASS=p only pass p of a
 resident launch is stamped (phase 0 then belongs to the launch, not to the pass)."""
 import sys
 import numpy as np
@@ -18,7 +18,7 @@ first = 0 if (a[:, 0] > 0).all() and a[:, 0].max() <= a[:, 1][a[:, 1] > 0].min()
 t0 = a[:, first][a[:, first] > 0].min()
 us = lambda x: (x - t0) / 100.0
 print(f"waves {len(a)}; span (first phase-{first} stamp -> last stamp) {us(a[:, first:][a[:, first:] > 0].max()):.2f} us")
-names = ["entry", "points/message(+transform)", "bounds seeded", "scan", "handed in", "block met", "keys merged", "ticket", "row stored", "tagged"]
+names = ["entry", "points/message(+transform)", "bounds seeded", "scan", "handed in", "block met", "merged", "accumulated", "row stores issued", "tagged"]
 last = np.zeros(len(a))
 for ph in range(first, 10):
     if ph > first:
