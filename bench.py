@@ -67,8 +67,8 @@ def cpu_baseline(P, Q, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -140,7 +140,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx.set_profiling(7)   # HIP events around every 7th matching launch (co-prime with the registration length)
+    ctx.set_profiling(7)   # HIP events around every 7th launch of the loop's kernel (with a resident kernel: every 7th registration)
     in_library = not (use_dist and not native_comm)   # nothing Python has to do between the steps
     TOL, MAX_ITER = 1e-6, 100   # src/CUDA/GPU_point_to_point_real.cu:18,404-405
     stats = {"registrations": 0, "iterations": 0}
@@ -173,6 +173,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     sec1, cnt1 = ctx.loop_timing()
+    passes1 = ctx.loop_timing_passes()
     sec0, cnt0 = 0.0, 0
     st = ctx.loop_state()
 
@@ -190,21 +191,23 @@ def main():
         info = ctx.nn_launch_info()
         nn_launches = max(1, cnt1 - cnt0)
         nn_avg_s = (sec1 - sec0) / nn_launches
-        flops = 8.0 * n * m                                  # 3 sub + 3 mul + 2 add per pair
-        alg_bytes = 12.0 * n + 12.0 * m + 4.0 * n            # read P, read Q, write idx (fp32)
-        # back-to-back launches of the same kernel, no other work between (cross-check, not the headline)
+        passes_per_launch = max(1, passes1) / nn_launches    # 1 when every pass is its own launch; a resident kernel runs a whole registration
+        flops_pass = 8.0 * n * m                             # 3 sub + 3 mul + 2 add per pair
+        flops = flops_pass * passes_per_launch
+        alg_bytes = (12.0 * n + 12.0 * m + 4.0 * n) * passes_per_launch   # read P, read Q, write idx (fp32), per pass
+        # back-to-back launches of the stand-alone matching kernel, no other work between: the kernel-quality figure
         b2b_ms = ctx.nn_match_bench(50) / 50.0
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1", "06_pmc_hbm_traffic_fused_tail.json")
+        pmc = os.path.join(ROOT, "profiles", "r1", "08_pmc_hbm_traffic_sparse.json")
         if world == 1 and os.path.exists(pmc):
-            # HBM bytes per launch of the seeded matching kernel from the committed rocprofv3 PMC passes of THIS
-            # command (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units, FETCH doubled: gfx950 correction)
-            rec = json.load(open(pmc)).get("void icp::nn_match_f32_v2<2, 8, true, 1>")
+            # HBM bytes per launch of the seeded stand-alone matching kernel from the committed rocprofv3 PMC passes
+            # (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units, FETCH doubled: gfx950 correction), scaled to the
+            # passes one timed launch runs
+            rec = next((v for k, v in json.load(open(pmc)).items() if "nn_match_sparse" in k), None)
             if rec:
-                traffic = rec["hbm_bytes_corrected"]
-                traffic_src = ("profiles/r1/06_pmc_hbm_traffic_fused_tail.json: FETCH_SIZE %.0f B raw (x2 corrected) + WRITE_SIZE %.0f B "
-                               "(atomic key updates count as writes)" %
-                               (rec["fetch_bytes_raw"], rec["write_bytes"]))
+                traffic = rec["hbm_bytes_corrected"] * passes_per_launch
+                traffic_src = ("profiles/r1/08_pmc_hbm_traffic_sparse.json: per pass FETCH_SIZE %.0f B raw (x2 corrected) + WRITE_SIZE %.0f B, "
+                               "times %.2f passes per launch" % (rec["fetch_bytes_raw"], rec["write_bytes"], passes_per_launch))
         out = {
             "metric": "ICP iterations/sec + NN HBM GB/s (% roofline), hall cloud",
             "value": world * K / t_max,
@@ -226,21 +229,27 @@ def main():
                        "collective": ("1 RCCL all-reduce of 32 doubles per iteration, issued by "
                                       + ("libicp_mi355x on the loop's stream" if native_comm else "torch.distributed")) if use_dist else "none"},
             "roofline": {
-                "kernel": "nn_match_f32_v2<2,8,*,1>: ONE launch per iteration = [transform + error of the previous pass] + brute-force "
-                          "matching (packed fp32; cold first pass without, later passes with the seeded early-out) + segment merge "
-                          "(atomic keys) + gather/moment rows by each row's last block -- average over the timed registrations",
+                "kernel": ("nn_match_sparse<1>, resident: ONE cooperative launch per REGISTRATION (%.2f matching passes on average); every "
+                           "pass = mailbox message from the host (command, R, t) -> [transform + error of the previous pass] -> "
+                           "lane-parallel chunk-box search -> hit processing (packed fp32, exact arithmetic) -> LDS key merge -> moment row "
+                           "to the host.  The duration INCLUDES the host round trips between the passes (the kernel waits for every solve)."
+                           % passes_per_launch) if passes_per_launch > 1.5 else
+                          "nn_match_sparse<1>: one launch per iteration = [transform + error of the previous pass] + matching + moment rows",
                 "bound": "valu",
-                "bound_note": "brute-force NN is 4681 flop/B on this cloud (ridge ~20): VALU-bound, not HBM-bound; "
-                              "fp32 vector peak == fp32 MFMA peak on gfx950. Exact (non-FMA) arithmetic caps frac at 0.5.",
+                "bound_note": "brute-force NN is 4681 flop/B on this cloud (ridge ~20): VALU-bound, not HBM-bound; fp32 vector peak == fp32 MFMA "
+                              "peak on gfx950.  'achieved' counts the ALGORITHMIC 8*N*M flop of every pass; the kernel skips most of them "
+                              "(exactly: results are bit-identical to the full scan), so frac measures time-to-solution against the "
+                              "brute-force roofline, not executed instructions.",
                 "achieved": flops / nn_avg_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / nn_avg_s / 1e12 / FP32_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": flops, "avg_launch_us": 1e6 * nn_avg_s, "launches_timed": nn_launches,
-                "pairs_per_s": n * m / nn_avg_s,
-                "matching_only": {"what": "the same matching kernel WITHOUT the fused transform/tail (icp_nn_match_bench_ex: 50 back-to-back "
-                                          "seeded launches), i.e. the part the 8*N*M flop belong to",
-                                  "avg_launch_us": 1e3 * b2b_ms, "achieved": flops / (1e-3 * b2b_ms) / 1e12,
-                                  "frac": flops / (1e-3 * b2b_ms) / 1e12 / FP32_PEAK_TFLOPS},
+                "passes_per_launch": passes_per_launch, "avg_pass_us": 1e6 * nn_avg_s / passes_per_launch,
+                "pairs_per_s": n * m * passes_per_launch / nn_avg_s,
+                "matching_only": {"what": "the stand-alone matching kernel (no transform, no moment rows; icp_nn_match_bench_ex: 50 back-to-back "
+                                          "seeded launches of nn_match_sparse<0>), i.e. the part the 8*N*M flop belong to",
+                                  "avg_launch_us": 1e3 * b2b_ms, "achieved": flops_pass / (1e-3 * b2b_ms) / 1e12,
+                                  "frac": flops_pass / (1e-3 * b2b_ms) / 1e12 / FP32_PEAK_TFLOPS},
                 "launch": info,
                 "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / nn_avg_s / 1e9,
                         "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes / nn_avg_s / 1e9 / HBM_PEAK_GBPS},

@@ -73,6 +73,7 @@ SIGNATURES = {
     "icp_loop_run": (_i, [_vp, _i, _pi, _pi]),
     "icp_loop_state": (_i, [_vp, _pi, _pi, _pd, _i, _pd]),
     "icp_loop_timing": (_i, [_vp, _pd, _pi]),
+    "icp_loop_timing_passes": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "icp_loop_indices": (_i, [_vp, _vp]),
     "icp_comm_unique_id": (_i, [_vp]),
     "icp_comm_init": (_i, [_vp, _vp, _i, _i]),

@@ -150,6 +150,8 @@ struct icp_ctx {
     uint64_t nn_launch_count = 0;
     double prof_seconds_nn = 0.0;      // cumulative over loops since icp_set_profiling
     int prof_nn_launches = 0;
+    long long prof_nn_passes = 0;      // matching passes inside those launches (resident kernels run many)
+    uint64_t resident_launch_count = 0;
     // ICP_TRACE=1: host-side time split of the loop, printed by icp_destroy
     bool trace = false;
     double tr_first_row = 0.0;
@@ -502,6 +504,7 @@ int icp_set_profiling(icp_ctx* c, int enable)
     c->profile_stride = enable > 0 ? enable : 0;
     c->prof_seconds_nn = 0.0;
     c->prof_nn_launches = 0;
+    c->prof_nn_passes = 0;
     return ICP_OK;
 }
 
@@ -929,6 +932,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
         L.nn_launches += 1;
         c->prof_seconds_nn += 1e-3 * ms;
         c->prof_nn_launches += 1;
+        c->prof_nn_passes += 1;
     }
     const int adv = L.H.advance(c->h_mom);
     if (adv != ICP_OK) {
@@ -1049,8 +1053,7 @@ bool can_reside(icp_ctx* c)
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
     return c->resident && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
-           icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done &&
-           c->profile_stride == 0;   // per-launch kernel timing (icp_set_profiling) wants one launch per pass
+           icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done;
 }
 
 // returns ICP_OK with *fell_back = true when the resident kernel could not be launched (nothing has been done)
@@ -1081,6 +1084,9 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     ta.rows = c->h_mom_partials;
     ta.tag = 0.0;
     icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[c0].p, c->P.p /* in place */, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, base, true};
+    // icp_set_profiling(n): every n-th resident kernel is bracketed by events (read after it has ended)
+    const bool time_this = c->profile_stride > 0 && (c->resident_launch_count++ % (uint64_t)c->profile_stride) == 0;
+    if (time_this) HIP_TRY(hipEventRecord(c->ev0, c->stream));
     const hipError_t le = icp::launch_nn(rp, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream);
     if (le != hipSuccess) {
         (void)hipGetLastError();
@@ -1089,14 +1095,15 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
         return ICP_OK;
     }
     *fell_back = false;
-    if (c->trace) std::fprintf(stderr, "[icp trace] resident launch: mailbox %p relay %p base %.0f\n", (void*)mb, (void*)c->relay, base);
+    if (time_this) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (c->trace_passes) std::fprintf(stderr, "[icp trace] resident launch: mailbox %p relay %p base %.0f\n", (void*)mb, (void*)c->relay, base);
     auto send = [&](int cmd, double seq) {
         mb->cmd = cmd;
         bar_fence();
         *(volatile double*)&mb->seq = seq;
         bar_fence();
     };
-    int k = *k_io, d = *d_io, sent = 0, rc = ICP_OK;
+    int k = *k_io, d = *d_io, sent = 0, matched = 0, rc = ICP_OK;
     bool alive = true;
     while (!d && k < max_steps && sent < pass_cap) {
         const auto tr0 = std::chrono::steady_clock::now();
@@ -1113,6 +1120,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
             c->cur ^= 1;
             L.matched = true;
             c->idx_valid = true;
+            ++matched;
         }
         send(cmd, base + (double)sent);
         L.mom_blocks = rp.blocks_x;
@@ -1138,6 +1146,16 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
         if (cmd == icp::ICP_CMD_TRANSFORM_ONLY) { alive = false; break; }  // the kernel ends itself after that pass
     }
     if (alive) send(icp::ICP_CMD_EXIT, -(base + (double)sent));
+    if (time_this && rc == ICP_OK) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        L.seconds_nn += 1e-3 * ms;
+        L.nn_launches += 1;
+        c->prof_seconds_nn += 1e-3 * ms;
+        c->prof_nn_launches += 1;
+        c->prof_nn_passes += matched;
+    }
     *k_io = k;
     *d_io = d;
     return rc;
@@ -1191,6 +1209,13 @@ int icp_loop_timing(icp_ctx* c, double* seconds_nn, int* nn_launches)
     if (!c) return fail(ICP_ERR_INVALID, "null context");
     if (seconds_nn) *seconds_nn = c->prof_seconds_nn;
     if (nn_launches) *nn_launches = c->prof_nn_launches;
+    return ICP_OK;
+}
+
+int icp_loop_timing_passes(icp_ctx* c, long long* passes)
+{
+    if (!c || !passes) return fail(ICP_ERR_INVALID, "null argument");
+    *passes = c->prof_nn_passes;
     return ICP_OK;
 }
 

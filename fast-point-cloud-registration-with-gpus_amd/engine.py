@@ -233,6 +233,11 @@ class Context:
         capi.check(self._lib.icp_loop_timing(self._h, C.byref(sec), C.byref(cnt)), "icp_loop_timing")
         return sec.value, cnt.value
 
+    def loop_timing_passes(self):
+        n = C.c_longlong(0)
+        capi.check(self._lib.icp_loop_timing_passes(self._h, C.byref(n)), "icp_loop_timing_passes")
+        return n.value
+
     def loop_indices(self):
         out = np.empty(self._n, dtype=np.int32)
         capi.check(self._lib.icp_loop_indices(self._h, out.ctypes.data), "icp_loop_indices")

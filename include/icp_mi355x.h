@@ -92,7 +92,8 @@ void icp_destroy(icp_ctx* ctx);
  * NULL restores the context's own stream */
 int icp_set_stream(icp_ctx* ctx, void* hip_stream);
 /* hipEvent timing of the matching kernel inside the loop: 0 = off, n > 0 = time every n-th launch
- * (two event records + a stream synchronisation on the timed iterations only) */
+ * (two event records + a stream synchronisation on the timed launches only; with a resident registration
+ * kernel the launch is the whole registration) */
 int icp_set_profiling(icp_ctx* ctx, int every_nth);
 
 /* ---- matching seam: replaces  Matching<<<>>>(n, P, Q, q_points, idx)
@@ -161,6 +162,10 @@ int icp_loop_state(icp_ctx* ctx, int* iterations, int* passes, double* err, int 
 /* summed hipEvent time and count of the matching-kernel launches timed since icp_set_profiling was last called
  * (cumulative over loops; the bench's roofline leg reads the timed region through this) */
 int icp_loop_timing(icp_ctx* ctx, double* seconds_nn, int* nn_launches);
+/* matching passes executed by those timed launches: equal to their count when every pass is its own launch, larger
+ * when icp_loop_run keeps ONE resident kernel for a whole registration (that kernel is then the timed launch, every
+ * n-th one, host round trips between its passes included) */
+int icp_loop_timing_passes(icp_ctx* ctx, long long* passes);
 /* correspondences of the last pass that contributed to T (ping-pong buffer), n int32 */
 int icp_loop_indices(icp_ctx* ctx, int32_t* idx_out);
 
