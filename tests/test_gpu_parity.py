@@ -376,3 +376,78 @@ def test_fused_and_two_kernel_forms_agree(pkg, orc, golden, tail):
     want = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
     assert got["it"] == want["iterations"] and rel(np.array(got["T"]), want["T"]) < TOL_T
     assert got["idx"] == int(np.bitwise_xor.reduce(want["idx"] * np.arange(1, want["idx"].size + 1, dtype=np.int64)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# the three forms of the loop (resident kernel, armed launches, one launch per pass) are the same computation
+# ---------------------------------------------------------------------------------------------------
+LOOP_FORMS = {
+    "resident": {},
+    "resident_host_mailbox": {"ICP_MAILBOX": "host"},
+    "armed": {"ICP_RESIDENT": "0"},
+    "stepwise": {"ICP_RESIDENT": "0", "ICP_ARMED": "0"},
+}
+
+
+def _run_form(pkg, monkeypatch, env, fn):
+    for k in ("ICP_MAILBOX", "ICP_RESIDENT", "ICP_ARMED"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)           # read by icp_create
+    with pkg.Context(0) as c:
+        return fn(c)
+
+
+@pytest.mark.parametrize("metric", ["point_to_point", "point_to_plane"])
+def test_loop_forms_are_bit_identical(pkg, orc, golden, monkeypatch, metric):
+    """icp_loop_run keeps one resident kernel for the registration (mailbox in BAR-visible device memory, or in
+    pinned host memory relayed by block 0), or arms the next pass ahead of its (R, t), or launches pass by pass:
+    same rows, same host half -> the same bits, and the oracle's run."""
+    P, Q = orc.hall_clouds(golden)
+    if metric == "point_to_point":
+        fn = lambda c: c.point_to_point(P, Q, max_iter=100, tol=1e-6)
+    else:
+        fn = lambda c: c.point_to_plane(P, Q, max_iter=50, tol=1e-6)
+    res = {name: _run_form(pkg, monkeypatch, env, fn) for name, env in LOOP_FORMS.items()}
+    ref = res["stepwise"]
+    for name, r in res.items():
+        assert r.iterations == ref.iterations, name
+        assert np.array_equal(r.T, ref.T) and np.array_equal(r.err, ref.err) and np.array_equal(r.idx, ref.idx), name
+    if metric == "point_to_point":
+        want = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
+        assert_same_run(ref.iterations, ref.err, ref.T, want, 1e-6, fp32=True)
+        assert np.array_equal(ref.idx, want["idx"]) or ref.iterations != want["iterations"]
+
+
+def test_resident_kernel_resumes_and_fixed_iterations(pkg, orc, golden, monkeypatch):
+    """a resident registration cut by max_steps leaves memory as the step-wise kernels do: the next icp_loop_run (a new
+    resident kernel, seeded from the index buffer) continues it; fixed_iterations ends with the transform-only pass"""
+    P, Q = orc.hall_clouds(golden)
+    def cut(c):
+        c.set_model(Q); c.set_moving(P)
+        c.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=9, tol=1e-6, fixed_iterations=True)
+        steps, done = 0, False
+        for chunk in (1, 2, 3, 100):
+            k, done = c.loop_run(chunk)
+            steps += k
+            if done:
+                break
+        assert done
+        return c.loop_state(), c.get_moving(), c.loop_indices(), steps
+    whole = _run_form(pkg, monkeypatch, {}, lambda c: c.point_to_point(P, Q, max_iter=9, tol=1e-6, fixed_iterations=True))
+    st, moved, idx, steps = _run_form(pkg, monkeypatch, {}, cut)
+    assert steps == 10 and st["iterations"] == whole.iterations == 9
+    assert np.array_equal(st["T"], whole.T) and np.array_equal(st["err"], whole.err) and np.array_equal(idx, whole.idx)
+    want = orc.icp_p2p_f32x(P, Q, 9, 1e-6, fixed=True)
+    assert rel(st["T"], want["T"]) < TOL_T and np.array_equal(idx, want["idx"])
+
+
+def test_moving_cloud_too_large_for_a_resident_kernel(ctx, pkg, orc):
+    """more than one block per CU cannot be resident together: the cooperative launch is refused once and the loop
+    runs pass by pass (armed) -- same answer"""
+    D = pkg.datasets.synthetic_grid(192, np.float32)              # 36 864 moving points = 288 blocks of 128
+    M = pkg.datasets.make_model_gpu(D[:4096], *pkg.datasets.P2P_GPU)
+    res = ctx.point_to_point(D, M, max_iter=4, tol=1e-6)
+    want = orc.icp_p2p_f32x(D, M, 4, 1e-6)
+    assert res.iterations == want["iterations"] and np.array_equal(res.idx, want["idx"])
+    assert rel(res.T, want["T"]) < TOL_T
