@@ -154,7 +154,7 @@ struct icp_ctx {
     uint64_t resident_launch_count = 0;
     // ICP_TRACE=1: host-side time split of the loop, printed by icp_destroy
     bool trace = false;
-    double tr_first_row = 0.0;
+    double tr_first_row = 0.0, tr_last_row = 0.0;
     bool trace_passes = false;         // ICP_TRACE=2: one line per pass of a resident registration
     double tr_enqueue = 0, tr_wait = 0, tr_reduce = 0, tr_solve = 0;
     uint64_t tr_n = 0;
@@ -169,6 +169,7 @@ struct icp_ctx {
     // store made after it started; host memory polled by ONE block works with every runtime.)
     icp::NNMailbox* h_mail = nullptr;
     bool mail_in_bar = false;
+    bool moving_is_pristine = false;   // icp_reset_moving: P is stale, the cloud to use is P0 (copied on first need)
     // fine-grained device memory: ordinary (coarse-grained) device memory is cached per XCD L2, and a block polling
     // it from another XCD keeps reading its stale line (seen as 24 of 128 blocks never receiving the message)
     icp::NNMailbox* relay = nullptr;
@@ -557,6 +558,7 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
         HIP_TRY(hipMemcpyAsync(c->P0.p, c->P.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     }
     c->have_moving = true;
+    c->moving_is_pristine = false;
     return ICP_OK;
 }
 
@@ -565,10 +567,7 @@ int icp_reset_moving(icp_ctx* c)
     if (int rc = use(c)) return rc;
     if (!c->have_moving) return fail(ICP_ERR_STATE, "no moving cloud resident");
     if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
-    if (c->n > 0) {
-        const size_t bytes = 3 * (size_t)icp::pad_moving(c->n) * icp::elem_size(c->prec);
-        HIP_TRY(hipMemcpyAsync(c->P.p, c->P0.p, bytes, hipMemcpyDeviceToDevice, c->stream));
-    }
+    c->moving_is_pristine = true;
     c->loop.active = false;
     c->idx_valid = false;
     return ICP_OK;
@@ -584,9 +583,23 @@ int icp_set_model_normals(icp_ctx* c, const void* nxyz, int m)
     return ICP_OK;
 }
 
+// icp_reset_moving is lazy: whoever needs the moving cloud in c->P asks for it here (the resident kernel does not --
+// it reads the pristine copy directly and writes c->P itself, which saves a device-to-device copy and a dependent
+// dispatch per registration)
+static int materialize_moving(icp_ctx* c)
+{
+    if (c->moving_is_pristine && c->n > 0) {
+        const size_t bytes = 3 * (size_t)icp::pad_moving(c->n) * icp::elem_size(c->prec);
+        HIP_TRY(hipMemcpyAsync(c->P.p, c->P0.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->moving_is_pristine = false;
+    return ICP_OK;
+}
+
 int icp_get_moving(icp_ctx* c, void* out)
 {
     if (int rc = use(c)) return rc;
+    if (int rc = materialize_moving(c)) return rc;
     if (!c->have_moving) return fail(ICP_ERR_STATE, "no moving cloud resident");
     if (c->n == 0) return ICP_OK;
     if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
@@ -626,6 +639,7 @@ int icp_nn_match_resident(icp_ctx* c, float* kernel_ms)
     if (int rc = use(c)) return rc;
     if (int rc = require_clouds(c)) return rc;
     if (int rc = ensure_work_buffers(c)) return rc;
+    if (int rc = materialize_moving(c)) return rc;
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
     const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr, nullptr, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
@@ -645,6 +659,7 @@ int icp_nn_match_bench_ex(icp_ctx* c, int reps, int seeded, float* total_ms)
     if (int rc = require_clouds(c)) return rc;
     if (reps <= 0 || !total_ms) return fail(ICP_ERR_INVALID, "reps/total_ms");
     if (int rc = ensure_work_buffers(c)) return rc;
+    if (int rc = materialize_moving(c)) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     // seeded with the most recent correspondences when there are any: this is how the loop launches it
     const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
@@ -754,6 +769,7 @@ int icp_loop_enqueue(icp_ctx* c)
     if (int rc = use(c)) return rc;
     LoopState& L = c->loop;
     if (!L.active || L.H.done || L.pending) return fail(ICP_ERR_STATE, "enqueue: loop not ready");
+    if (int rc = materialize_moving(c)) return rc;
     const auto tr0 = std::chrono::steady_clock::now();
     const icp::NNPlan& pl = c->plan;
     L.err_blocks = 0;
@@ -893,6 +909,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
                     break;  // something is wrong (fault, hang): let the runtime report it
             }
             polled = b == L.mom_blocks;
+            if (c->trace_passes) c->tr_last_row = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (!polled && c->trace) {
                 std::fprintf(stderr, "[icp trace]   poll gave up at row %d; rows still missing:", b);
                 int shown = 0;
@@ -1087,13 +1104,17 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     // icp_set_profiling(n): every n-th resident kernel is bracketed by events (read after it has ended)
     const bool time_this = c->profile_stride > 0 && (c->resident_launch_count++ % (uint64_t)c->profile_stride) == 0;
     if (time_this) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    const hipError_t le = icp::launch_nn(rp, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream);
+    // after icp_reset_moving the kernel reads the pristine copy and (re)writes c->P itself -- no copy is enqueued
+    const void* P_in = c->moving_is_pristine ? c->P0.p : c->P.p;
+    ft.store_first = c->moving_is_pristine;
+    const hipError_t le = icp::launch_nn(rp, P_in, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream);
     if (le != hipSuccess) {
         (void)hipGetLastError();
         c->resident_refused = true;   // does not fit the machine (or cooperative launches are unavailable)
         *fell_back = true;
         return ICP_OK;
     }
+    c->moving_is_pristine = false;
     *fell_back = false;
     if (time_this) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     if (c->trace_passes) std::fprintf(stderr, "[icp trace] resident launch: mailbox %p relay %p base %.0f\n", (void*)mb, (void*)c->relay, base);
@@ -1135,8 +1156,8 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
         const auto tc0 = std::chrono::steady_clock::now();
         rc = icp_loop_complete(c, &d);
         if (c->trace_passes)
-            std::fprintf(stderr, "[icp trace] resident pass %d cmd %d: %.2f us from message to reduced rows (row 0 after %.2f us)\n", sent - 1, cmd,
-                         1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count(), 1e6 * c->tr_first_row);
+            std::fprintf(stderr, "[icp trace] resident pass %d cmd %d: %.2f us from message to reduced rows + solve (row 0 after %.2f us, all rows after %.2f us)\n", sent - 1, cmd,
+                         1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count(), 1e6 * c->tr_first_row, 1e6 * c->tr_last_row);
         if (rc != ICP_OK) {
             if (c->trace) std::fprintf(stderr, "[icp trace] resident pass %d failed: mailbox %p reads back seq %.0f cmd %d (sent seq %.0f)\n",
                                        sent - 1, (void*)mb, *(volatile double*)&mb->seq, *(volatile int*)&mb->cmd, base + (double)(sent - 1));

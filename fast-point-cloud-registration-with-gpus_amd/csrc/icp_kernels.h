@@ -63,6 +63,7 @@ struct NNFusedTransform {
     NNMailbox* relay = nullptr;          // device-memory copy for the blocks other than block 0 (one per context)
     double want = 0.0;                   // sequence number of the (first) message
     bool resident = false;               // the kernel stays for the whole registration: pass p is message want + p
+    bool store_first = false;            // resident: the input is not P_out (pristine copy): store the cloud in pass 0 as well
 };
 bool nn_can_fuse_transform(const NNPlan& pl);
 

@@ -278,6 +278,11 @@ __device__ __forceinline__ f2 pk_sub_q(f2 q, f2 p)
     if constexpr (QS) return pk_sub_bcast_s<HI>(q, p); else return pk_sub_bcast<HI>(q, p);
 }
 
+// One wave passing data to itself through LDS: DS instructions of a wave execute in order, so all that is needed is
+// that the COMPILER keeps the order (and does not cache the values in registers).  A workgroup-scope fence would also
+// drain the wave's global stores (s_waitcnt vmcnt(0)) -- ~1 us of idle time in the matching kernel's tail.
+__device__ __forceinline__ void lds_same_wave_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // wave-wide min / max of a float by DPP (no LDS): row_shr 1,2,4,8 leave each row's result in its lane 15
 // (min/max are idempotent, overlapping windows are harmless), row_bcast15/31 carry it to lane 63.
 template <bool MAX>
@@ -437,6 +442,7 @@ struct NNFuse {
     const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
     const float* boxes;      // CULL kernels: per 8-point chunk of the scan copy {lo.xyz, hi.xyz, -, -} (or NULL)
     int sample_groups;       // sparse kernel: at most this many groups of 8 samples are used by the cold start (<= 256)
+    int store_first;         // resident launch reading a pristine copy: pass 0 stores the cloud to P_out even without a transform
     int resident;            // resident launch: after a pass the block waits for the next message instead of ending
     NNMailbox* relay;        // ... relayed by block 0 to the other blocks through this device-memory copy
     const NNMailbox* mailbox; // armed launch (sparse kernel): (R, t) arrive here from the host AFTER the kernel was enqueued
@@ -977,7 +983,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
     double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
 #pragma unroll
     for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // same wave: DS ops are in order; this pins the compiler
+    lds_same_wave_order();
     double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
     // Slot k is the sum of its 64 lane entries in a FIXED order: PARTS lanes per slot add a contiguous share each
     // (loaded first, added after: the LDS latencies overlap), the shares are then added in part order.
@@ -995,7 +1001,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
             tp[part * NACC + slot] = sum;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    lds_same_wave_order();
     // The row goes out as system-scope (write-through) stores, drained before the tag is issued: the host may
     // read the row as soon as it sees the tag.  (No L2 write-back here -- it would flush the whole cache for the
     // sake of 19 doubles; the other outputs of the pass are for later kernels and become visible at kernel end.)
@@ -1068,8 +1074,10 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         real[t] = i < fuse.n;
         sok[t] = false;
         sq[t][0] = sq[t][1] = sq[t][2] = 0.f;
-        if (fuse.seed_idx) {
-            int j = real[t] ? fuse.seed_idx[i] : -1;
+        {
+            // no previous match (cold start): the model point at the same RELATIVE index -- consecutive scans of one
+            // sensor, or a cloud and its moved copy, keep their order, and any valid index is a valid bound
+            int j = !real[t] ? -1 : fuse.seed_idx ? fuse.seed_idx[i] : (int)(((long long)i * fuse.m) / fuse.n);
             sok[t] = (unsigned)j < (unsigned)fuse.m;  // a seed is trusted only if it is a real model index
             j = sok[t] ? j : 0;
             const float* Qg = fuse.Q_gather;
@@ -1164,7 +1172,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         // every wave re-derives the moved points in registers (same instructions => same bits); wave 0 of the
         // grid.y == 0 block stores them and accounts the error of the pass that produced (R, t)
         double err = 0.0;
-        const bool shared_gather = pass > 0 || fuse.idx_prev == fuse.seed_idx;
+        const bool shared_gather = pass > 0 || (fuse.seed_idx != nullptr && fuse.idx_prev == fuse.seed_idx);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
@@ -1199,6 +1207,15 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             }
         }
     }
+    if (!apply && pass == 0 && fuse.store_first && blockIdx.y == 0 && w == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = ibase + t * 64;
+            fuse.P_out[i] = t ? px.y : px.x;
+            fuse.P_out[(size_t)n_pad + i] = t ? py.y : py.x;
+            fuse.P_out[2 * (size_t)n_pad + i] = t ? pz.y : pz.x;
+        }
+    }
     ICP_PHASE(1)
     if (cmd == ICP_CMD_TRANSFORM_ONLY) {
         // the loop's last pass: nothing is matched any more, the row carries the error alone
@@ -1219,7 +1236,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     for (int t = 0; t < 2; ++t) {
         bj[t] = -1;
         best[t] = inf_<float>();
-        if (have_seeds) {
+        {
             // seeded bound: the distance to ANY model point (last pass's match) bumped by one ulp -- the true minimum
             // is <= that distance < bound, so the seed changes how much work is skipped, never the answer
             const float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
@@ -1261,7 +1278,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const unsigned int v = smin[lane + t * 64];
-            if (real[t] && v < 0x7f800000u) best[t] = __uint_as_float(v + 1u);
+            if (real[t] && v < 0x7f800000u) best[t] = fmin_(best[t], __uint_as_float(v + 1u));
         }
     }
     ICP_PHASE(2)
@@ -1327,7 +1344,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                         *reinterpret_cast<float4*>(stage + r * 32 + part * 4) = *reinterpret_cast<const float4*>(src);
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // same wave: DS ops are in order; this pins the compiler
+                lds_same_wave_order();
                 const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
                 const int cnt = mine < 8 ? mine : 8;
                 for (int rr = 0; rr < cnt; ++rr) {
@@ -1338,7 +1355,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                         continue;
                     scan_chunk_unordered<false>(sb + 8, sb + 16, sb + 24, px, py, pz, ch, best, bj, bq);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                lds_same_wave_order();
             }
             if (rb + round_chunks < c_hi) {
                 // exchange before the next round: every wave goes on from the block's best minimum so far, bumped by
@@ -2230,6 +2247,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             fuse.relay = ft->relay;
             fuse.want = ft->want;
             fuse.resident = ft->resident ? 1 : 0;
+            fuse.store_first = ft->store_first ? 1 : 0;
         } else {
             for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
             for (int k = 0; k < 3; ++k) rt.t[k] = (float)ft->t3[k];
@@ -2273,8 +2291,6 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         int passes = env_passes > 0 ? env_passes : ((fuse.seed_idx || fuse.samples) ? SP_MAX_PASSES : 1);
         if (passes > SP_MAX_PASSES) passes = SP_MAX_PASSES;
         if (fuse.resident) {
-            // one cooperative launch for the whole registration: every block must be on the machine at once (they
-            // all wait for the same host), which is exactly what the cooperative launch guarantees or refuses
             if (!ta || pl.splits != 1) return hipErrorInvalidValue;
             const float* Pp = (const float*)P;
             const float* Qp = (const float*)opt->Q_scan;
@@ -2282,8 +2298,18 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             float* pd = (float*)part_d;
             void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
             const void* fn = ta->metric == ICP_POINT_TO_PLANE ? (const void*)nn_match_sparse<2> : (const void*)nn_match_sparse<1>;
-            static const int env_coop = env_int("ICP_COOP", 1);
+            // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
+            // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
+            // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that
+            // start late (behind the previous kernel of the stream) only delay the first pass, nothing waits on them
+            // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
+            static const int env_coop = env_int("ICP_COOP", 0);
             if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
+            int per_cu = 0, dev = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                return hipErrorCooperativeLaunchTooLarge;
+            if ((long long)grid.x * grid.y > (long long)per_cu * cus) return hipErrorCooperativeLaunchTooLarge;
             return hipLaunchKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
         }
 #define ICP_LAUNCH_SP(TL)                                                                                          \
