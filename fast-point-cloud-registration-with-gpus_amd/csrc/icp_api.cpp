@@ -124,6 +124,10 @@ struct icp_ctx {
     DevBuf P0;  // pristine copy of the moving cloud as uploaded (icp_reset_moving)
     DevBuf Qbox;  // chunk bounding boxes of Qs
     DevBuf Qsamp; // one point per chunk of Qs
+    DevBuf Qss;   // Morton-ordered scan copy (sparse kernel), when the model's own order has no locality
+    DevBuf Qperm; // ... and its permutation: sorted position -> model index
+    DevBuf Pperm; // slot -> moving point (Morton order of the initial positions), when the cloud's own order has no locality
+    bool model_sorted = false, moving_sorted = false;
     DevBuf phase_log;        // ICP_NN_PHASES diagnostic
     std::string phase_path;
     DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
@@ -295,6 +299,83 @@ int void_duplicate_points(const float* in, int m, int m_pad, float* out)
     return voided;
 }
 
+// ---- spatial order -------------------------------------------------------------------------------------------
+// The sparse matching kernel prunes by bounding boxes of 8 consecutive model points and of 128 consecutive moving
+// points: it needs clouds whose index order has spatial locality.  A LiDAR scan has it; a mesh's vertex list
+// (Bunny) does not.  Where Morton order makes the groups clearly tighter than the given order, the kernel works
+// on a Morton-ordered view (a permutation, the clouds at the ABI and every index it returns stay in user order).
+static void morton_order(const float* xyz, int n, std::vector<int32_t>& perm)
+{
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        const float* p = xyz + 3 * (size_t)i;
+        if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = any ? std::min(lo[a], p[a]) : p[a];
+            hi[a] = any ? std::max(hi[a], p[a]) : p[a];
+        }
+        any = true;
+    }
+    float ext = 0.f;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
+    const double scale = ext > 0.f ? 1023.0 / ext : 0.0;   // one cube for all axes: cells stay cubic
+    auto spread = [](uint32_t v) {                          // 10 bits -> every third bit
+        v &= 1023u;
+        v = (v | (v << 16)) & 0x030000FFu;
+        v = (v | (v << 8)) & 0x0300F00Fu;
+        v = (v | (v << 4)) & 0x030C30C3u;
+        v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    };
+    std::vector<uint64_t> key((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const float* p = xyz + 3 * (size_t)i;
+        uint32_t code = 0x7fffffffu;  // non-finite points go last
+        if (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; ++a) q[a] = (uint32_t)std::min(1023.0, std::max(0.0, ((double)p[a] - lo[a]) * scale));
+            code = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        }
+        key[i] = ((uint64_t)code << 32) | (uint32_t)i;      // ties keep index order
+    }
+    std::sort(key.begin(), key.end());
+    perm.resize((size_t)n);
+    for (int i = 0; i < n; ++i) perm[i] = (int32_t)(uint32_t)key[i];
+}
+
+// sum over groups of `group` consecutive points (in the given order) of the group's bounding-box extent dx + dy + dz
+static double grouped_extent(const float* xyz, const int32_t* perm, int n, int group)
+{
+    double total = 0.0;
+    for (int g0 = 0; g0 < n; g0 += group) {
+        float lo[3], hi[3];
+        bool any = false;
+        for (int k = g0; k < std::min(n, g0 + group); ++k) {
+            const float* p = xyz + 3 * (size_t)(perm ? perm[k] : k);
+            if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = any ? std::min(lo[a], p[a]) : p[a];
+                hi[a] = any ? std::max(hi[a], p[a]) : p[a];
+            }
+            any = true;
+        }
+        if (any) total += (double)(hi[0] - lo[0]) + (double)(hi[1] - lo[1]) + (double)(hi[2] - lo[2]);
+    }
+    return total;
+}
+
+// true (and perm filled) when Morton order makes the groups at least 30 % tighter than the cloud's own order
+static bool morton_is_tighter(const float* xyz, int n, int group, std::vector<int32_t>& perm)
+{
+    static const char* force = std::getenv("ICP_SORT");   // ICP_SORT=0 never, =1 always (A/B runs)
+    if (force && force[0] == '0') return false;
+    if (n <= group) return false;
+    morton_order(xyz, n, perm);
+    if (force && force[0] == '1') return true;
+    return grouped_extent(xyz, perm.data(), n, group) < 0.7 * grouped_extent(xyz, nullptr, n, group);
+}
+
 int check_precision(int precision)
 {
     if (precision != ICP_F32 && precision != ICP_F64) return fail(ICP_ERR_INVALID, "unknown precision");
@@ -446,7 +527,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -529,11 +610,26 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         std::vector<float> scan(3 * (size_t)m_pad);
         c->voided = void_duplicate_points((const float*)xyz, m, m_pad, scan.data());
         if (int rc = upload_cloud(c, scan.data(), m_pad, m_pad, precision, c->Qs)) return rc;
-        // bounding boxes of its 8-point chunks: the first, cheapest level of the early-out
+        // the sparse kernel's view: the same voided copy, in Morton order if the model's own order has no locality
+        std::vector<int32_t> perm;
+        c->model_sorted = morton_is_tighter((const float*)xyz, m, 8, perm);
+        const void* view = c->Qs.p;
+        if (c->model_sorted) {
+            std::vector<float> sorted(3 * (size_t)m_pad, std::numeric_limits<float>::infinity());
+            for (int k = 0; k < m; ++k)
+                for (int a = 0; a < 3; ++a) sorted[3 * (size_t)k + a] = scan[3 * (size_t)perm[k] + a];
+            perm.resize((size_t)m_pad, 0x7fffffff);
+            if (int rc = upload_cloud(c, sorted.data(), m_pad, m_pad, precision, c->Qss)) return rc;
+            HIP_TRY(c->Qperm.ensure((size_t)m_pad * sizeof(int32_t)));
+            HIP_TRY(hipMemcpyAsync(c->Qperm.p, perm.data(), (size_t)m_pad * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));  // perm is a local
+            view = c->Qss.p;
+        }
+        // bounding boxes of its 8-point chunks (the first, cheapest level of the early-out) and one point per chunk
         HIP_TRY(c->Qbox.ensure((size_t)((m_pad + 7) / 8) * 8 * sizeof(float)));
-        HIP_TRY(icp::launch_model_boxes(c->Qs.p, m_pad, (float*)c->Qbox.p, c->stream));
+        HIP_TRY(icp::launch_model_boxes(view, m_pad, (float*)c->Qbox.p, c->stream));
         HIP_TRY(c->Qsamp.ensure(icp::model_samples_bytes(m_pad)));
-        HIP_TRY(icp::launch_model_samples(c->Qs.p, m_pad, (float*)c->Qsamp.p, c->stream));
+        HIP_TRY(icp::launch_model_samples(view, m_pad, (float*)c->Qsamp.p, c->stream));
         c->have_scan_copy = true;
     }
     c->have_model = true;
@@ -556,6 +652,19 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
         const size_t bytes = 3 * (size_t)icp::pad_moving(n) * icp::elem_size(precision);
         HIP_TRY(c->P0.ensure(bytes));
         HIP_TRY(hipMemcpyAsync(c->P0.p, c->P.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->moving_sorted = false;
+    if (precision == ICP_F32 && n > 0) {
+        std::vector<int32_t> perm;
+        if (morton_is_tighter((const float*)xyz, n, 128, perm)) {
+            const int n_pad = icp::pad_moving(n);
+            perm.resize((size_t)n_pad);
+            for (int k = n; k < n_pad; ++k) perm[k] = k;   // padding slots keep themselves
+            HIP_TRY(c->Pperm.ensure((size_t)n_pad * sizeof(int32_t)));
+            HIP_TRY(hipMemcpyAsync(c->Pperm.p, perm.data(), (size_t)n_pad * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->moving_sorted = true;
+        }
     }
     c->have_moving = true;
     c->moving_is_pristine = false;
@@ -581,6 +690,14 @@ int icp_set_model_normals(icp_ctx* c, const void* nxyz, int m)
     if (int rc = upload_cloud(c, nxyz, m, icp::pad_model(m), c->prec, c->Nrm)) return rc;
     c->have_normals = true;
     return ICP_OK;
+}
+
+static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
+{
+    icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
+    if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
+    if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
+    return o;
 }
 
 // icp_reset_moving is lazy: whoever needs the moving cloud in c->P asks for it here (the resident kernel does not --
@@ -641,7 +758,7 @@ int icp_nn_match_resident(icp_ctx* c, float* kernel_ms)
     if (int rc = ensure_work_buffers(c)) return rc;
     if (int rc = materialize_moving(c)) return rc;
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr, nullptr, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
+    const icp::NNCullInputs cull = make_cull(c, nullptr);
     HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
     if (kernel_ms) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(icp::launch_merge(c->plan, c->part_d.p, (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, c->stream));
@@ -662,9 +779,7 @@ int icp_nn_match_bench_ex(icp_ctx* c, int reps, int seeded, float* total_ms)
     if (int rc = materialize_moving(c)) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     // seeded with the most recent correspondences when there are any: this is how the loop launches it
-    const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
-                                 (seeded && c->idx_valid) ? (const int32_t*)c->idx[c->cur].p : nullptr,
-                                 c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
+    const icp::NNCullInputs cull = make_cull(c, (seeded && c->idx_valid) ? (const int32_t*)c->idx[c->cur].p : nullptr);
     for (int r = 0; r < reps; ++r)
         HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -795,9 +910,7 @@ int icp_loop_enqueue(icp_ctx* c)
     L.timed_nn = false;
     if (!final_only) {
         // the previous pass's matches seed the early-out bound (any valid index would do)
-        const icp::NNCullInputs cull{c->have_scan_copy ? c->Qs.p : nullptr,
-                                     L.matched ? (const int32_t*)c->idx[c->cur].p : nullptr,
-                                     c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
+        const icp::NNCullInputs cull = make_cull(c, L.matched ? (const int32_t*)c->idx[c->cur].p : nullptr);
         c->cur ^= 1;
         L.matched = true;
         c->idx_valid = true;
@@ -991,7 +1104,7 @@ int loop_arm(icp_ctx* c)
 {
     LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    const icp::NNCullInputs cull{c->Qs.p, (const int32_t*)c->idx[c->cur].p, c->Qbox.p, c->Qsamp.p};
+    const icp::NNCullInputs cull = make_cull(c, (const int32_t*)c->idx[c->cur].p);
     const int prev_cur = c->cur;
     const int slot = (int)(c->mail_seq++ % kMailSlots);
     icp::NNMailbox* mb = c->h_mail + slot;
@@ -1089,7 +1202,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     *(volatile double*)&mb->seq = 0.0;
     bar_fence();
     const int c0 = c->cur;
-    const icp::NNCullInputs cull{c->Qs.p, L.matched ? (const int32_t*)c->idx[c0].p : nullptr, c->Qbox.p, c->Qsamp.p};
+    const icp::NNCullInputs cull = make_cull(c, L.matched ? (const int32_t*)c->idx[c0].p : nullptr);
     icp::NNTailArgs ta{};
     ta.metric = L.H.prm.metric;
     ta.keys = (unsigned long long*)c->keys.p;

@@ -442,6 +442,8 @@ struct NNFuse {
     const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
     const float* boxes;      // CULL kernels: per 8-point chunk of the scan copy {lo.xyz, hi.xyz, -, -} (or NULL)
     int sample_groups;       // sparse kernel: at most this many groups of 8 samples are used by the cold start (<= 256)
+    const int32_t* q_perm;   // sparse kernel: the scan copy is spatially sorted; q_perm[sorted j] = model index (NULL: identity)
+    const int32_t* p_perm;   // sparse kernel: slot -> moving point handled there (spatially sorted groups; NULL: identity)
     int store_first;         // resident launch reading a pristine copy: pass 0 stores the cloud to P_out even without a transform
     int resident;            // resident launch: after a pass the block waits for the next message instead of ending
     NNMailbox* relay;        // ... relayed by block 0 to the other blocks through this device-memory copy
@@ -830,13 +832,15 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
 constexpr int SP_NW = 16;                       // waves per block
 constexpr int SP_HCAP = 4096;                   // hit-list entries = chunks per round (SP_NW * 64 * passes <= this)
 constexpr int SP_MAX_PASSES = SP_HCAP / (SP_NW * 64);
+constexpr int SP_STAGE = 40;                    // floats per staged hit: box 8, x 8, y 8, z 8, model indices 8
 
-// one hit chunk against the lane's packed pair; (best, bj) follow the lexicographic (distance, index) rule:
-// the chunk takes a point's minimum if its own minimum is smaller, or equal and the chunk lies below the current
-// winner's; the index inside the chunk (lowest k with d_k == minimum) is worked out only then
+// one hit chunk against the lane's packed pair; (best, bj) follow the lexicographic (distance, MODEL index) rule:
+// the chunk takes a point's minimum if its own minimum is smaller, or equal with a lower model index.  The scan copy
+// may be spatially sorted, so the model index of chunk element k is qo[k] (identity order: ch * 8 + k); it is looked
+// at only on the rare path where the chunk's minimum reaches the running one.
 template <bool QS>
-__device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const float* qyp, const float* qzp, const f2 px,
-                                                     const f2 py, const f2 pz, int ch, float (&best)[2], int (&bj)[2],
+__device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const float* qyp, const float* qzp, const int* qo,
+                                                     const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
                                                      float (&bq)[2][3])
 {
     constexpr int C = 8;
@@ -879,19 +883,23 @@ __device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const flo
         c1 = fmin_(fmin_(c1, d[kk].y), d[kk + 1].y);
         c1 = fmin_(fmin_(c1, d[kk + 2].y), d[kk + 3].y);
     }
-    const bool take0 = (c0 < best[0]) | ((c0 == best[0]) & (ch < (bj[0] >> 3)));  // bj = -1: nothing to tie with
-    const bool take1 = (c1 < best[1]) | ((c1 == best[1]) & (ch < (bj[1] >> 3)));
-    if (__builtin_amdgcn_ballot_w64(take0 | take1) != 0ull) {
-        int k0 = C - 1, k1 = C - 1;
+    const bool cand0 = c0 <= best[0], cand1 = c1 <= best[1];
+    if (__builtin_amdgcn_ballot_w64(cand0 | cand1) != 0ull) {
+        // lowest model index among the chunk elements at the chunk's minimum, and where it sits
+        int o0 = 0x7fffffff, o1 = 0x7fffffff, k0 = 0, k1 = 0;
 #pragma unroll
-        for (int kk = C - 2; kk >= 0; --kk) {
-            k0 = (d[kk].x == c0) ? kk : k0;
-            k1 = (d[kk].y == c1) ? kk : k1;
+        for (int kk = C - 1; kk >= 0; --kk) {
+            const int oj = qo[kk];  // wave-uniform address: one broadcast read
+            const bool e0 = (d[kk].x == c0) & (oj < o0), e1 = (d[kk].y == c1) & (oj < o1);
+            o0 = e0 ? oj : o0; k0 = e0 ? kk : k0;
+            o1 = e1 ? oj : o1; k1 = e1 ? kk : k1;
         }
+        const bool take0 = cand0 & ((c0 < best[0]) | (bj[0] < 0) | (o0 < bj[0]));  // bj < 0: nothing to tie with yet
+        const bool take1 = cand1 & ((c1 < best[1]) | (bj[1] < 0) | (o1 < bj[1]));
         best[0] = take0 ? c0 : best[0];
-        bj[0] = take0 ? ch * C + k0 : bj[0];
+        bj[0] = take0 ? o0 : bj[0];
         best[1] = take1 ? c1 : best[1];
-        bj[1] = take1 ? ch * C + k1 : bj[1];
+        bj[1] = take1 ? o1 : bj[1];
         // the coordinates of the new minimum are at hand (LDS stage): keeping them saves the closing wave a
         // dependent gather from global memory
         if (take0) { bq[0][0] = qxp[k0]; bq[0][1] = qyp[k0]; bq[0][2] = qzp[k0]; }
@@ -931,7 +939,7 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
 // accumulates in fp64, reduces through LDS in lane order and writes the row + completion tag.
 // (qio: the coordinates of the correspondences -- gathered here when `gather`, else supplied by the caller)
 template <int TAIL>
-__device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f2 pz, const int (&j)[2], int lane, int ibase,
+__device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f2 pz, const int (&j)[2], int lane, const int (&pi)[2],
                                                int m_pad, const NNFuse& fuse, const NNTail& tail, double err_row,
                                                unsigned char* lds_raw, float (&qio)[2][3], bool gather, int phase_pass_ = 0)
 {
@@ -943,7 +951,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
     const float* Qg = fuse.Q_gather;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int i = ibase + t * 64;
+        const int i = pi[t];
         if (i < fuse.n) {
             const int jj = j[t];
             tail.idx_out[i] = jj;
@@ -1027,7 +1035,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     constexpr int HITS_BYTES = SP_HCAP * 4, MD_BYTES = SP_NW * 128 * 4;
     constexpr int TR_BYTES = TAIL ? ((TAIL == 2 ? 28 : 18) * 65 + 64) * 8 : 0;
     static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
-    constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * 32 * 4;
+    constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * SP_STAGE * 4;
     constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
     constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x SP_NW x 128
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MQ_OFF + 3 * MD_BYTES];
@@ -1043,8 +1051,11 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ibase = blockIdx.x * 128 + lane;
-    float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * 32);  // per wave: 8 hits x {box 8, x 8, y 8, z 8}
+    const int ibase = blockIdx.x * 128 + lane;   // the block's slots; the moving point in slot s is p_perm[s] (spatially sorted groups)
+    int pi[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) pi[t] = fuse.p_perm ? fuse.p_perm[ibase + t * 64] : ibase + t * 64;
+    float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * SP_STAGE);  // per wave: 8 hits x {box 8, x 8, y 8, z 8, model index 8}
     float* msg = reinterpret_cast<float*>(lds_raw + MSG_OFF);
     float (*seedq)[128] = reinterpret_cast<float (*)[128]>(lds_raw + SEED_OFF);
     float (*mq)[SP_NW][128] = reinterpret_cast<float (*)[SP_NW][128]>(lds_raw + MQ_OFF);
@@ -1070,7 +1081,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     float sq[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int i = ibase + t * 64;
+        const int i = pi[t];
         real[t] = i < fuse.n;
         sok[t] = false;
         sq[t][0] = sq[t][1] = sq[t][2] = 0.f;
@@ -1085,9 +1096,9 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         }
     }
     f2 px, py, pz;
-    px = f2{P[ibase], P[ibase + 64]};
-    py = f2{P[(size_t)n_pad + ibase], P[(size_t)n_pad + ibase + 64]};
-    pz = f2{P[2 * (size_t)n_pad + ibase], P[2 * (size_t)n_pad + ibase + 64]};
+    px = f2{P[pi[0]], P[pi[1]]};
+    py = f2{P[(size_t)n_pad + pi[0]], P[(size_t)n_pad + pi[1]]};
+    pz = f2{P[2 * (size_t)n_pad + pi[0]], P[2 * (size_t)n_pad + pi[1]]};
     // ---- the pass loop: one turn for an ordinary launch, one per ICP pass for a resident one -------------------
     // Armed launch: the kernel was enqueued while the previous pass was still running, so the launch and dispatch
     // latencies are behind it; what it lacks is the (R, t) the host is solving for.  Resident launch: the same,
@@ -1179,7 +1190,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             apply_rt<float>(rt, x, y, z, x, y, z);
             if (t) { px.y = x; py.y = y; pz.y = z; } else { px.x = x; py.x = y; pz.x = z; }
             if (blockIdx.y == 0 && w == 0) {
-                const int i = ibase + t * 64;
+                const int i = pi[t];
                 fuse.P_out[i] = x;
                 fuse.P_out[(size_t)n_pad + i] = y;
                 fuse.P_out[2 * (size_t)n_pad + i] = z;
@@ -1210,7 +1221,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     if (!apply && pass == 0 && fuse.store_first && blockIdx.y == 0 && w == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int i = ibase + t * 64;
+            const int i = pi[t];
             fuse.P_out[i] = t ? px.y : px.x;
             fuse.P_out[(size_t)n_pad + i] = t ? py.y : py.x;
             fuse.P_out[2 * (size_t)n_pad + i] = t ? pz.y : pz.x;
@@ -1341,19 +1352,28 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                         const int chl = hits[h];
                         const float* src = part < 2 ? fuse.boxes + (size_t)chl * 8 + part * 4
                                                     : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)chl * 8 + (part & 1) * 4;
-                        *reinterpret_cast<float4*>(stage + r * 32 + part * 4) = *reinterpret_cast<const float4*>(src);
+                        *reinterpret_cast<float4*>(stage + r * SP_STAGE + part * 4) = *reinterpret_cast<const float4*>(src);
+                    }
+                    // the elements' model indices: the sort permutation, or simply chunk * 8 + k
+                    const int r2 = lane >> 1, half = lane & 1;
+                    const int h2 = hb + r2 * SP_NW + w;
+                    if (lane < 16 && h2 < h1) {
+                        const int chl = hits[h2];
+                        int4 v;
+                        if (fuse.q_perm) v = *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)chl * 8 + half * 4);
+                        else { const int b = chl * 8 + half * 4; v = int4{b, b + 1, b + 2, b + 3}; }
+                        *reinterpret_cast<int4*>(stage + r2 * SP_STAGE + 32 + half * 4) = v;
                     }
                 }
                 lds_same_wave_order();
                 const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
                 const int cnt = mine < 8 ? mine : 8;
                 for (int rr = 0; rr < cnt; ++rr) {
-                    const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * SP_NW + w]);
-                    const float* sb = stage + rr * 32;
+                    const float* sb = stage + rr * SP_STAGE;
                     const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
                     if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull)
                         continue;
-                    scan_chunk_unordered<false>(sb + 8, sb + 16, sb + 24, px, py, pz, ch, best, bj, bq);
+                    scan_chunk_unordered<false>(sb + 8, sb + 16, sb + 24, reinterpret_cast<const int*>(sb + 32), px, py, pz, best, bj, bq);
                 }
                 lds_same_wave_order();
             }
@@ -1407,7 +1427,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     if constexpr (TAIL == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const size_t o = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * 128 + lane + t * 64;
+            const size_t o = (size_t)blockIdx.y * n_pad + (size_t)pi[t];
             part_d[o] = fb[t];
             part_idx[o] = fj[t];
         }
@@ -1430,7 +1450,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             if (ticket != gridDim.y - 1) return;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int i = ibase + t * 64;
+                const int i = ibase + t * 64;  // keys live per slot
                 const unsigned long long key = __hip_atomic_load(&tail.keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 tail.keys[i] = ~0ull;  // ready for the next launch (nobody touches this row again in this one)
                 fj[t] = (int)(unsigned int)(key & 0xffffffffull);
@@ -1445,7 +1465,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         tl.idx_out = (pass & 1) ? tail.idx_out_odd : tail.idx_out;
         // (a row closed over several segment blocks may have been won elsewhere: its coordinates are gathered)
         if (gridDim.y == 1) { ICP_PHASE(6) }
-        tail_close_row<TAIL>(px, py, pz, fj, lane, ibase, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gridDim.y > 1, pass);
+        tail_close_row<TAIL>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gridDim.y > 1, pass);
         ICP_PHASE(9)
         if (!fuse.resident) return;
         // the matches of this pass seed the next one and are what its error is measured against
@@ -2238,7 +2258,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     if (pl.cull && opt && opt->Q_scan) {
         Qscan = opt->Q_scan;
         fuse.seed_idx = opt->seed_idx;
-        fuse.boxes = pl.chunk == 8 ? (const float*)opt->boxes : nullptr;
+        // (the boxes describe the sparse kernel's view of the model: usable here only if that is the model's own order)
+        fuse.boxes = (pl.chunk == 8 && !opt->Q_scan_sorted) ? (const float*)opt->boxes : nullptr;
     }
     if (ft) {
         if (ft->mailbox) {
@@ -2282,6 +2303,9 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         if (pl.m_pad >= (1 << 28)) return hipErrorInvalidValue;  // the in-block merge key carries 28 index bits
         fuse.seed_idx = opt->seed_idx;
         fuse.boxes = (const float*)opt->boxes;
+        fuse.q_perm = opt->Q_scan_sorted ? opt->q_perm : nullptr;
+        fuse.p_perm = opt->p_perm;
+        const void* Qsp = opt->Q_scan_sorted ? opt->Q_scan_sorted : opt->Q_scan;
         static const int env_samples = env_int("ICP_NN_SAMPLES", 1);
         fuse.samples = env_samples ? (const float*)opt->samples : nullptr;
         static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 64);
@@ -2293,7 +2317,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         if (fuse.resident) {
             if (!ta || pl.splits != 1) return hipErrorInvalidValue;
             const float* Pp = (const float*)P;
-            const float* Qp = (const float*)opt->Q_scan;
+            const float* Qp = (const float*)Qsp;
             int n_pad = pl.n_pad, m_pad = pl.m_pad, seg = pl.seg_len;
             float* pd = (float*)part_d;
             void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
@@ -2314,7 +2338,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         }
 #define ICP_LAUNCH_SP(TL)                                                                                          \
     hipLaunchKernelGGL((nn_match_sparse<TL>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,              \
-                       (const float*)opt->Q_scan, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail)
+                       (const float*)Qsp, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail)
         if (!ta) ICP_LAUNCH_SP(0);
         else if (ta->metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_SP(2);
         else ICP_LAUNCH_SP(1);
