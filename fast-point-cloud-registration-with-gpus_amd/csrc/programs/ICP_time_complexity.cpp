@@ -53,8 +53,7 @@ int main(int argc, char** argv)
                 const auto t0 = std::chrono::steady_clock::now();
                 int done = 0;
                 while (!done) {
-                    ICP_CHECK(icp_loop_enqueue(ctx));
-                    const int rc = icp_loop_complete(ctx, &done);
+                    const int rc = icp_loop_run(ctx, 1 << 20, nullptr, &done);   // the library's own loop (resident kernel where it fits)
                     if (rc == ICP_ERR_SINGULAR) break;   // tiny planar grids: the reference's potrf would fail too
                     ICP_CHECK(rc);
                 }
