@@ -75,6 +75,11 @@ def main():
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: ICP_BENCH_ONE_DEVICE=1 puts every rank on device 0 (gloo carries the set-up messages,
+    # RCCL refuses two ranks on one device); never used by the driver
+    one_device = os.environ.get("ICP_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
@@ -94,7 +99,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if one_device else "nccl", rank=rank, world_size=world)
 
     pkg, ranges, enc, alt, az = hall_fixture()
     ctx = pkg.Context(local_rank)          # raises when the HIP library / device is missing
@@ -107,7 +112,18 @@ def main():
     mom = None
     stream_ctx = None
     native_comm = False
-    if use_dist and os.environ.get("ICP_BENCH_COMM", "rccl") != "torch":
+    local_comm = False
+    comm_kind = os.environ.get("ICP_BENCH_COMM", "local")   # local (shared host memory, default) | rccl | torch
+    if use_dist and comm_kind == "local":
+        # one node: the loop's 32-double vector is already in host memory when the rows have been added, so the ranks
+        # exchange it through shared memory (~1 us; a 256-byte RCCL all-reduce costs more than the whole iteration)
+        # and every rank keeps its resident kernel.  torch.distributed only carries the 128-byte segment id.
+        try:
+            pkg.distributed.attach_local_comm(ctx, dist)
+            local_comm = native_comm = True
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] host-memory communicator unavailable ({e}); using RCCL", file=sys.stderr)
+    if use_dist and not native_comm and comm_kind != "torch":
         # preferred: the library issues the all-reduce itself (RCCL bound at run time, icp_comm_init); torch only
         # broadcasts the 128-byte communicator id.  Any failure falls back to the torch.distributed collective.
         try:
@@ -179,7 +195,7 @@ def main():
 
     t_max = dt
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_device else f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_max = float(tt.item())
 
@@ -226,8 +242,10 @@ def main():
                                  "a step = one iteration of such a registration",
                        "registrations_timed": stats["registrations"],
                        "iterations_per_registration": stats["iterations"] / max(1, stats["registrations"]),
-                       "collective": ("1 RCCL all-reduce of 32 doubles per iteration, issued by "
-                                      + ("libicp_mi355x on the loop's stream" if native_comm else "torch.distributed")) if use_dist else "none"},
+                       "collective": (("sum of 32 doubles per iteration over the node's ranks through shared host memory "
+                                       "(icp_comm_init_local), rank order, every rank keeps its resident kernel") if local_comm else
+                                      ("1 RCCL all-reduce of 32 doubles per iteration, issued by "
+                                       + ("libicp_mi355x on the loop's stream" if native_comm else "torch.distributed"))) if use_dist else "none"},
             "roofline": {
                 "kernel": ("nn_match_sparse<1>, resident: ONE cooperative launch per REGISTRATION (%.2f matching passes on average); every "
                            "pass = mailbox message from the host (command, R, t) -> [transform + error of the previous pass] -> "

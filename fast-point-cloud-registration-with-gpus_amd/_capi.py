@@ -78,6 +78,11 @@ SIGNATURES = {
     "icp_comm_unique_id": (_i, [_vp]),
     "icp_comm_init": (_i, [_vp, _vp, _i, _i]),
     "icp_comm_destroy": (_i, [_vp]),
+    "icp_comm_random_id": (_i, [_vp]),
+    "icp_comm_init_local": (_i, [_vp, _vp, _i, _i]),
+    "icp_lcomm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "icp_lcomm_allreduce": (_i, [_vp, _pd, _i]),
+    "icp_lcomm_destroy": (None, [_vp]),
     "icp_solve_point_to_point": (_i, [_pd, _pd, _pd]),
     "icp_solve_point_to_plane": (_i, [_pd, _pd, _pd, _pd]),
     "icp_host_loop_create": (_i, [C.POINTER(icp_params), C.POINTER(_vp)]),

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <unistd.h>
 #include <limits>
 #include <cmath>
 #include <cstdio>
@@ -33,6 +34,7 @@
 
 #include "../../include/icp_mi355x.h"
 #include "icp_comm.h"
+#include "icp_lcomm.h"
 #include "icp_host_loop.h"
 #include "icp_host_math.h"
 #include "icp_kernels.h"
@@ -163,6 +165,7 @@ struct icp_ctx {
     double tr_enqueue = 0, tr_wait = 0, tr_reduce = 0, tr_solve = 0;
     uint64_t tr_n = 0;
     void* comm = nullptr;              // RCCL communicator (icp_comm_init): the loop all-reduces its vector itself
+    icp::LocalComm* lcomm = nullptr;   // host-memory communicator (icp_comm_init_local): the vector is summed over the node's ranks on the host
     bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
     bool arm = true;                   // ICP_ARMED=0: icp_loop_run never enqueues a pass ahead of its (R, t)
     bool resident = true;              // ICP_RESIDENT=0: icp_loop_run never keeps one kernel for a whole registration
@@ -519,6 +522,7 @@ void icp_destroy(icp_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
+    if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
     if (c->phase_log.p && !c->phase_path.empty()) {
         icp::set_phase_log(nullptr, 0);
         std::vector<long long> h(kPhaseSlots);
@@ -568,7 +572,63 @@ int icp_comm_destroy(icp_ctx* c)
     if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
+    if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
     return ICP_OK;
+}
+
+int icp_comm_random_id(void* out_bytes)
+{
+    if (!out_bytes) return fail(ICP_ERR_INVALID, "out == NULL");
+    std::memset(out_bytes, 0, ICP_COMM_ID_BYTES);
+    FILE* f = std::fopen("/dev/urandom", "rb");
+    size_t got = f ? std::fread(out_bytes, 1, 16, f) : 0;
+    if (f) std::fclose(f);
+    if (got != 16) {  // fall back to clock + pid: unique enough for a segment name on one node
+        const uint64_t a = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count(), b = (uint64_t)getpid();
+        std::memcpy(out_bytes, &a, 8);
+        std::memcpy((char*)out_bytes + 8, &b, 8);
+    }
+    return ICP_OK;
+}
+
+int icp_comm_init_local(icp_ctx* c, const void* id_bytes, int rank, int world)
+{
+    if (int rc = use(c)) return rc;
+    if (!id_bytes || world < 1 || rank < 0 || rank >= world) return fail(ICP_ERR_INVALID, "bad communicator arguments");
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    if (c->comm) return fail(ICP_ERR_STATE, "a device communicator is attached: destroy it first");
+    if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
+    std::string err;
+    const int rc = icp::lcomm_create(id_bytes, rank, world, &c->lcomm, err);
+    return rc == ICP_OK ? ICP_OK : fail(rc, err);
+}
+
+struct icp_lcomm { icp::LocalComm* p; };
+
+int icp_lcomm_create(const void* id_bytes, int rank, int world, icp_lcomm** out)
+{
+    if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    std::string err;
+    icp::LocalComm* p = nullptr;
+    if (int rc = icp::lcomm_create(id_bytes, rank, world, &p, err)) return fail(rc, err);
+    *out = new icp_lcomm{p};
+    return ICP_OK;
+}
+
+int icp_lcomm_allreduce(icp_lcomm* h, double* v, int count)
+{
+    if (!h) return fail(ICP_ERR_INVALID, "null communicator");
+    std::string err;
+    const int rc = icp::lcomm_allreduce_sum_f64(h->p, v, count, err);
+    return rc == ICP_OK ? ICP_OK : fail(rc, err);
+}
+
+void icp_lcomm_destroy(icp_lcomm* h)
+{
+    if (!h) return;
+    icp::lcomm_destroy(h->p);
+    delete h;
 }
 
 int icp_set_stream(icp_ctx* c, void* hip_stream)
@@ -1063,6 +1123,10 @@ int icp_loop_complete(icp_ctx* c, int* done)
         c->prof_seconds_nn += 1e-3 * ms;
         c->prof_nn_launches += 1;
         c->prof_nn_passes += 1;
+    }
+    if (c->lcomm && L.host_reduce) {  // the node's ranks exchange their sums (rank order: identical on every rank)
+        std::string err;
+        if (int rc = icp::lcomm_allreduce_sum_f64(c->lcomm, c->h_mom, ICP_NMOM, err)) return fail(rc, err);
     }
     const int adv = L.H.advance(c->h_mom);
     if (adv != ICP_OK) {

@@ -87,6 +87,40 @@ def attach_native_comm(ctx, dist):
     ctx.comm_init(box[0], rank, world)
 
 
+def attach_local_comm(ctx, dist):
+    """Ranks of ONE node: give `ctx` the host-memory communicator (icp_comm_init_local).  The loop's 32-double vector is
+    summed over the ranks through shared memory (~1 us) and icp_loop_run keeps its resident kernel."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [ctx.comm_random_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init_local(box[0], rank, world)
+
+
+def run_sharded_local(ctx, P_shard, Q, dist, metric=capi.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6,
+                      fixed_iterations=False, normals=None):
+    """Single-node driver: every rank runs the library's own loop (resident kernel) on its shard, the ranks meet in
+    shared host memory once per iteration."""
+    ctx.set_model(Q)
+    if metric == capi.ICP_POINT_TO_PLANE:
+        if normals is not None:
+            ctx.set_model_normals(normals)
+        else:
+            ctx.estimate_normals()
+    ctx.set_moving(P_shard)
+    attach_local_comm(ctx, dist)
+    try:
+        ctx.loop_begin(metric, max_iter=max_iter, tol=tol, fixed_iterations=fixed_iterations)
+        done = False
+        while not done:
+            _, done = ctx.loop_run(1 << 20)
+        st = ctx.loop_state()
+        st["idx"] = ctx.loop_indices()
+        st["moved"] = ctx.get_moving()
+        return st
+    finally:
+        ctx.comm_destroy()
+
+
 def run_sharded_native(ctx, P_shard, Q, dist, metric=capi.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6,
                        fixed_iterations=False, normals=None):
     """Device driver with the collective issued by the library (no Python between the kernels and RCCL)."""

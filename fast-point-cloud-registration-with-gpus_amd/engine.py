@@ -97,6 +97,17 @@ class Context:
     def comm_destroy(self):
         capi.check(self._lib.icp_comm_destroy(self._h), "icp_comm_destroy")
 
+    @staticmethod
+    def comm_random_id():
+        buf = (C.c_ubyte * 128)()
+        capi.check(capi.load().icp_comm_random_id(buf), "icp_comm_random_id")
+        return bytes(buf)
+
+    def comm_init_local(self, id_bytes, rank, world):
+        """ranks of ONE node: the loop's vector is exchanged through shared host memory (the resident loop stays on)"""
+        buf = (C.c_ubyte * 128).from_buffer_copy(id_bytes)
+        capi.check(self._lib.icp_comm_init_local(self._h, buf, int(rank), int(world)), "icp_comm_init_local")
+
     # ---- matching seam -------------------------------------------------------------------------
     def Matching(self, P, Q):
         """idx[i] = argmin_j |P_i - Q_j|^2, lowest j on ties (reference `Matching` kernel)."""
@@ -306,3 +317,30 @@ def eigh3(A):
     pd = C.POINTER(C.c_double)
     capi.check(lib.icp_eigh3(A.ctypes.data_as(pd), w.ctypes.data_as(pd), Z.ctypes.data_as(pd)), "icp_eigh3")
     return w, Z.reshape(3, 3)
+
+
+class LocalComm:
+    """icp_lcomm_*: the host-memory communicator on its own (no device): sum of <= 32 doubles over the ranks of a node,
+    added in rank order on every rank."""
+
+    def __init__(self, id_bytes, rank, world):
+        self._lib = capi.load()
+        self._h = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(id_bytes)
+        capi.check(self._lib.icp_lcomm_create(buf, int(rank), int(world), C.byref(self._h)), "icp_lcomm_create")
+
+    def allreduce(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).copy()
+        capi.check(self._lib.icp_lcomm_allreduce(self._h, v.ctypes.data_as(C.POINTER(C.c_double)), int(v.size)), "icp_lcomm_allreduce")
+        return v
+
+    def close(self):
+        if self._h:
+            self._lib.icp_lcomm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -179,6 +179,19 @@ int icp_loop_indices(icp_ctx* ctx, int32_t* idx_out);
 int icp_comm_unique_id(void* out_id_bytes);
 int icp_comm_init(icp_ctx* ctx, const void* id_bytes, int rank, int world);
 int icp_comm_destroy(icp_ctx* ctx);
+/* The same exchange for ranks on ONE node, through POSIX shared memory instead of a device collective: in the
+ * single-node fast path the loop's vector is already in host memory when the rows have been added, and 256 bytes
+ * between processes of a node take ~1 us (RCCL: ~15-20 us, more than the iteration).  Every rank adds the ranks'
+ * vectors in rank order, so all ranks continue from bit-identical sums; the resident-kernel loop stays available.
+ * id_bytes: ICP_COMM_ID_BYTES random bytes from rank 0 (icp_comm_random_id), distributed by the application. */
+int icp_comm_random_id(void* out_id_bytes);
+int icp_comm_init_local(icp_ctx* ctx, const void* id_bytes, int rank, int world);
+/* the host-memory communicator on its own (no device needed: multi-process CPU tests, custom drivers);
+ * icp_lcomm_allreduce: v[0..count) <- sum over ranks in rank order, count <= ICP_NMOM */
+typedef struct icp_lcomm icp_lcomm;
+int icp_lcomm_create(const void* id_bytes, int rank, int world, icp_lcomm** out);
+int icp_lcomm_allreduce(icp_lcomm* comm, double* v, int count);
+void icp_lcomm_destroy(icp_lcomm* comm);
 
 /* ---- host-only pieces (no device needed; exercised by the CPU test-suite) ------------------- */
 /* 3x3 cross-covariance solve from raw moments: replaces cublasSgemm + cusolverDnSgesvd + 2 gemm

@@ -133,3 +133,46 @@ def test_host_loop_stop_rule_and_limits(pkg):
     assert k == 3 and hl.state()["iterations"] == 3
     with pytest.raises(pkg.IcpError):
         HL(max_iter=0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the host-memory communicator (icp_lcomm_*): what the single-node resident loop exchanges its vector through
+# ---------------------------------------------------------------------------------------------------
+def _lcomm_worker(rank, world, id_hex, n_pts, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    orc = oracle_lib.Oracle()
+    W = int(round(n_pts ** 0.5))
+    D = pkg.datasets.synthetic_grid(W, np.float32)[:n_pts]
+    M = pkg.datasets.make_model_gpu(pkg.datasets.synthetic_grid(W, np.float32), *pkg.datasets.P2P_GPU)
+    Ps, begin = pkg.distributed.shard(D, rank, world)
+    with pkg.LocalComm(bytes.fromhex(id_hex), rank, world) as comm:
+        # raw exchanges first: rank-dependent vectors, several rounds back to back (sequence parity, no overwrites)
+        sums = [comm.allreduce(np.arange(32, dtype=np.float64) * (rank + 1) + k) for k in range(50)]
+
+        def allreduce(vec):
+            vec[:] = comm.allreduce(vec)
+
+        ops = OracleShard(orc, Ps, M)
+        hl = pkg.distributed.HostLoop(pkg.ICP_POINT_TO_POINT, max_iter=40, tol=1e-6, precision=pkg.ICP_F32)
+        st = pkg.distributed.drive(ops, hl, allreduce)
+    np.savez(os.path.join(out_dir, f"lrank{rank}.npz"), T=st["T"], err=st["err"], iterations=st["iterations"], sums=np.array(sums))
+
+
+def test_local_communicator_three_ranks(tmp_path, pkg, orc):
+    import torch.multiprocessing as mp
+    world, n_pts = 3, 31 * 31 - 5
+    id_hex = pkg.Context.comm_random_id().hex()
+    mp.spawn(_lcomm_worker, args=(world, id_hex, n_pts, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"lrank{k}.npz") for k in range(world)]
+    want = np.array([sum(np.arange(32, dtype=np.float64) * (q + 1) + k for q in range(world)) for k in range(50)])
+    for k in range(world):
+        assert np.array_equal(r[k]["sums"], want)
+        assert np.array_equal(r[k]["T"], r[0]["T"]) and np.array_equal(r[k]["err"], r[0]["err"])   # bit-identical on every rank
+    D = pkg.datasets.synthetic_grid(31, np.float32)[:n_pts]
+    M = pkg.datasets.make_model_gpu(pkg.datasets.synthetic_grid(31, np.float32), *pkg.datasets.P2P_GPU)
+    ref = orc.icp_p2p_f32x(D, M, 40, 1e-6)
+    assert int(r[0]["iterations"]) == ref["iterations"] and np.abs(ref["T"] - r[0]["T"]).max() < 1e-9

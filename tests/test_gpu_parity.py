@@ -451,3 +451,42 @@ def test_moving_cloud_too_large_for_a_resident_kernel(ctx, pkg, orc):
     want = orc.icp_p2p_f32x(D, M, 4, 1e-6)
     assert res.iterations == want["iterations"] and np.array_equal(res.idx, want["idx"])
     assert rel(res.T, want["T"]) < TOL_T
+
+
+def test_two_ranks_one_node_local_communicator(pkg, orc, golden):
+    """two processes, each with a shard of the hall scan and its own resident kernel (both on cuda:0 here), meet once per
+    iteration in shared host memory (icp_comm_init_local): both ranks end with the same bits, and with the run of one
+    rank holding the whole cloud up to the association of the fp64 sums"""
+    import subprocess, sys, json
+    code = (
+        "import sys, os, json, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))\n"
+        "from __graft_entry__ import load_package\n"
+        "import oracle_lib\n"
+        "pkg = load_package(); orc = oracle_lib.Oracle()\n"
+        "rank, world, idh = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]\n"
+        f"P, Q = orc.hall_clouds({golden!r})\n"
+        "Ps, begin = pkg.distributed.shard(P, rank, world)\n"
+        "with pkg.Context(0) as ctx:\n"
+        "    ctx.set_model(Q); ctx.set_moving(Ps)\n"
+        "    ctx.comm_init_local(bytes.fromhex(idh), rank, world)\n"
+        "    ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=100, tol=1e-6)\n"
+        "    done = False\n"
+        "    while not done:\n"
+        "        _, done = ctx.loop_run(1 << 20)\n"
+        "    st = ctx.loop_state(); idx = ctx.loop_indices()\n"
+        "    ctx.comm_destroy()\n"
+        "print(json.dumps(dict(it=st['iterations'], T=st['T'].tolist(), err=st['err'].tolist(), begin=int(begin), idx=idx.tolist())))\n")
+    idh = pkg.Context.comm_random_id().hex()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", idh], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    got = [json.loads(o.strip().splitlines()[-1]) for o, _ in outs]
+    assert got[0]["it"] == got[1]["it"] and got[0]["T"] == got[1]["T"] and got[0]["err"] == got[1]["err"]
+    P, Q = orc.hall_clouds(golden)
+    want = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
+    assert_same_run(got[0]["it"], np.array(got[0]["err"]), np.array(got[0]["T"]), want, 1e-6, fp32=True)
+    if got[0]["it"] == want["iterations"]:
+        assert np.array_equal(np.concatenate([got[0]["idx"], got[1]["idx"]]), want["idx"])
