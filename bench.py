@@ -253,9 +253,11 @@ def main():
                            "to the host.  The duration INCLUDES the host round trips between the passes (the kernel waits for every solve)."
                            % passes_per_launch) if passes_per_launch > 1.5 else
                           "nn_match_sparse<1>: one launch per iteration = [transform + error of the previous pass] + matching + moment rows",
-                "bound": "valu",
-                "bound_note": "brute-force NN is 4681 flop/B on this cloud (ridge ~20): VALU-bound, not HBM-bound; fp32 vector peak == fp32 MFMA "
-                              "peak on gfx950.  'achieved' counts the ALGORITHMIC 8*N*M flop of every pass; the kernel skips most of them "
+                "bound": "mfma",
+                "bound_detail": "compute roof, fp32 dense peak 157.3 TFLOP/s -- on gfx950 the same figure for MFMA and for packed vector FMA.  "
+                                "The kernel issues packed VALU ops (v_pk_add/mul_f32): MFMA cannot evaluate (dx*dx + dy*dy) + dz*dz "
+                                "bit-exactly, and the contract forbids FMA, which caps EXECUTED arithmetic at 0.5 of that roof.",
+                "bound_note": "brute-force NN is 4681 flop/B on this cloud (ridge ~20): compute-bound, not HBM-bound.  'achieved' counts the ALGORITHMIC 8*N*M flop of every pass; the kernel skips most of them "
                               "(exactly: results are bit-identical to the full scan), so frac measures time-to-solution against the "
                               "brute-force roofline, not executed instructions.",
                 "achieved": flops / nn_avg_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

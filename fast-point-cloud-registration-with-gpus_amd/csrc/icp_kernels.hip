@@ -462,8 +462,7 @@ struct NNFuse {
         if (slot_ < fuse.tlog_cap) fuse.tlog[slot_] = (long long)wall_clock64();                                   \
     }
 
-template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/, int CULL /*0: plain; 1: seeded bound + box/xy early-out over LDS tiles;
-            2: sparse -- lane-parallel box test picks the chunks, q through the scalar cache, no tile*/, int TAIL = 0>
+template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/, int CULL /*0: plain; 1: seeded bound + box/xy early-out over LDS tiles*/, int TAIL = 0>
 __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(const float* __restrict__ P, int n_pad,
                                                                const float* __restrict__ Q, int m_pad, int seg_len,
                                                                float* __restrict__ part_d,
@@ -471,9 +470,8 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
                                                                NNFuse fuse, NNTail tail)
 {
     constexpr int TP = T / 2;  // packed pairs of moving points per lane
-    static_assert(CULL != 2 || (T == 2 && C == 8), "the sparse scan is written for one packed pair per lane and 8-point chunks");
     // one raw LDS block, carved by hand: the tail's transpose buffer overlays the tile + merge scratch
-    constexpr int SQ_BYTES = CULL == 2 ? 0 : 4 * 3 * NN2_TQW * 4, MD_BYTES = 4 * 64 * T * 4;
+    constexpr int SQ_BYTES = 4 * 3 * NN2_TQW * 4, MD_BYTES = 4 * 64 * T * 4;
     constexpr int TR_BYTES = TAIL ? (TAIL == 2 ? 28 : 18) * 65 * 8 : 0;
     constexpr int LDS_BYTES = (SQ_BYTES + 2 * MD_BYTES + 16) > TR_BYTES ? (SQ_BYTES + 2 * MD_BYTES + 16) : TR_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -569,56 +567,7 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
     }
 
     ICP_PHASE(2)
-    if constexpr (CULL == 2) {
-        // Sparse scan.  The wave's 128 moving points have a bounding box G and a largest running bound B; a chunk
-        // whose box lies at least B away from G cannot lower any lane's minimum.  That test does not involve the
-        // individual points, so it runs LANE-PARALLEL -- lane l tests chunk l, 64 chunks for ~25 VALU ops instead
-        // of 64 x 20 -- and its ballot is the list of chunks worth visiting.  The few survivors go through the
-        // per-point box test and the xy early-out as before; their coordinates arrive through the scalar cache
-        // (wave-uniform address), so this variant has no LDS tile, no fill and no barrier before the merge.
-        float glo[3], ghi[3];
-        glo[0] = wave_minmax<false>(__builtin_fminf(px[0].x, px[0].y)); ghi[0] = wave_minmax<true>(__builtin_fmaxf(px[0].x, px[0].y));
-        glo[1] = wave_minmax<false>(__builtin_fminf(py[0].x, py[0].y)); ghi[1] = wave_minmax<true>(__builtin_fmaxf(py[0].x, py[0].y));
-        glo[2] = wave_minmax<false>(__builtin_fminf(pz[0].x, pz[0].y)); ghi[2] = wave_minmax<true>(__builtin_fmaxf(pz[0].x, pz[0].y));
-        const int cb0 = my0 / C;
-        const int nch = (my1 - my0) / C;  // <= 0 for an empty range
-        for (int cbase = 0; cbase < nch; cbase += 64) {
-            // B only shrinks while the wave works: refreshed once per 64 chunks
-            const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
-            const bool valid = cbase + lane < nch;
-            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cb0 + (valid ? cbase + lane : 0)) * 8);
-            const float4 b0 = bp[0], b1 = bp[1];  // lo.xyz hi.x | hi.yz - -
-            const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - ghi[0], glo[0] - b0.w), 0.f);
-            const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - ghi[1], glo[1] - b1.x), 0.f);
-            const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - ghi[2], glo[2] - b1.y), 0.f);
-            const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;
-            unsigned long long todo = __builtin_amdgcn_ballot_w64(valid && L < B);
-            while (todo != 0ull) {
-                const int bsel = __builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const int ch = cb0 + cbase + bsel;  // wave-uniform
-                const float lox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0.x), bsel));
-                const float loy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0.y), bsel));
-                const float loz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0.z), bsel));
-                const float hix = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0.w), bsel));
-                const float hiy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1.x), bsel));
-                const float hiz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1.y), bsel));
-                if (__builtin_amdgcn_ballot_w64(box_may_improve<TP>(lox, loy, loz, hix, hiy, hiz, px, py, pz, best)) == 0ull) continue;
-                float bo[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) bo[t] = best[t];
-                const float* qc = Q + (size_t)ch * C;
-                scan_chunk_xy_cull<TP, C, true>(qc, qc + m_pad, qc + 2 * (size_t)m_pad, px, py, pz, best);
-                bool any = false;
-#pragma unroll
-                for (int t = 0; t < T; ++t) any |= best[t] < bo[t];
-                if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-#pragma unroll
-                    for (int t = 0; t < T; ++t) cst[t] = (best[t] < bo[t]) ? ch : cst[t];
-                }
-            }
-        }
-    } else {
+    {
     const int ntile = (wseg + NN2_TQW - 1) / NN2_TQW;
     for (int k = 0; k < ntile; ++k) {
         __syncthreads();
@@ -2329,11 +2278,16 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
             static const int env_coop = env_int("ICP_COOP", 0);
             if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
-            int per_cu = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-                return hipErrorCooperativeLaunchTooLarge;
-            if ((long long)grid.x * grid.y > (long long)per_cu * cus) return hipErrorCooperativeLaunchTooLarge;
+            static long long capacity[2] = {-1, -1};   // blocks the machine holds at once, per kernel variant (asked once)
+            long long& cap = capacity[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0];
+            if (cap < 0) {
+                int per_cu = 0, dev = 0, cus = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                    return hipErrorCooperativeLaunchTooLarge;
+                cap = (long long)per_cu * cus;
+            }
+            if ((long long)grid.x * grid.y > cap) return hipErrorCooperativeLaunchTooLarge;
             return hipLaunchKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
         }
 #define ICP_LAUNCH_SP(TL)                                                                                          \
@@ -2349,18 +2303,12 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     // packed kernel on every cloud (its bound starts at +inf), with one it wins on every cloud
     const bool cull = pl.cull && Qscan != Q && fuse.seed_idx != nullptr;
     if (!cull) { Qscan = Q; fuse.seed_idx = nullptr; fuse.boxes = nullptr; }
-    // with chunk boxes the sparse scan (lane-parallel box test, no LDS tile) replaces the tiled one
-    static const int env_sparse = env_int("ICP_NN_SPARSE", 1);
-    const bool sparse = cull && fuse.boxes != nullptr && pl.chunk == 8 && env_sparse;
     if (ta) {
         const bool plane = ta->metric == ICP_POINT_TO_PLANE;
-        if (sparse) { if (plane) ICP_LAUNCH_NN2T(2, 2); else ICP_LAUNCH_NN2T(2, 1); }
-        else if (cull) { if (plane) ICP_LAUNCH_NN2T(1, 2); else ICP_LAUNCH_NN2T(1, 1); }
+        if (cull) { if (plane) ICP_LAUNCH_NN2T(1, 2); else ICP_LAUNCH_NN2T(1, 1); }
         else { if (plane) ICP_LAUNCH_NN2T(0, 2); else ICP_LAUNCH_NN2T(0, 1); }
     } else if (pl.pts_per_thread == 4) {
         if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8, 0); else ICP_LAUNCH_NN2(4, 16, 0);
-    } else if (sparse) {
-        ICP_LAUNCH_NN2(2, 8, 2);
     } else if (cull) {
         if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, 1); else ICP_LAUNCH_NN2(2, 16, 1);
     } else {
