@@ -130,6 +130,9 @@ struct icp_ctx {
     DevBuf Qperm; // ... and its permutation: sorted position -> model index
     DevBuf Pperm; // slot -> moving point (Morton order of the initial positions), when the cloud's own order has no locality
     bool model_sorted = false, moving_sorted = false;
+    // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
+    DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
+    struct PrepSmall { float box[4]; double totals[2]; int voided; int pad_; };
     DevBuf phase_log;        // ICP_NN_PHASES diagnostic
     std::string phase_path;
     DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
@@ -264,119 +267,48 @@ int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision,
     return ICP_OK;
 }
 
-// AoS in (m points) -> AoS out (m_pad points): a point whose (x, y, z) equals that of a LOWER index is
-// replaced by (+inf, +inf, +inf), and so is the padding.  -0 and +0 compare equal (they give identical
-// distances); NaN coordinates are never treated as duplicates.  O(m log m), once per model.
-int void_duplicate_points(const float* in, int m, int m_pad, float* out)
-{
-    std::vector<int> order((size_t)m);
-    for (int i = 0; i < m; ++i) order[i] = i;
-    auto key = [&](int i, int a) -> uint32_t {
-        float v = in[3 * (size_t)i + a];
-        if (v == 0.0f) v = 0.0f;  // canonical zero
-        uint32_t b;
-        std::memcpy(&b, &v, 4);
-        return b;
-    };
-    std::sort(order.begin(), order.end(), [&](int a, int b) {
-        for (int k = 0; k < 3; ++k) {
-            const uint32_t ka = key(a, k), kb = key(b, k);
-            if (ka != kb) return ka < kb;
-        }
-        return a < b;
-    });
-    const float inf = std::numeric_limits<float>::infinity();
-    std::memcpy(out, in, 3 * (size_t)m * sizeof(float));
-    int voided = 0;
-    for (int s = 1; s < m; ++s) {
-        const int a = order[s - 1], b = order[s];
-        const bool same = key(a, 0) == key(b, 0) && key(a, 1) == key(b, 1) && key(a, 2) == key(b, 2);
-        const bool nan = in[3 * (size_t)b] != in[3 * (size_t)b] || in[3 * (size_t)b + 1] != in[3 * (size_t)b + 1] ||
-                         in[3 * (size_t)b + 2] != in[3 * (size_t)b + 2];
-        if (same && !nan) {  // b has a lower-index twin (runs are index-ascending inside equal keys)
-            out[3 * (size_t)b] = out[3 * (size_t)b + 1] = out[3 * (size_t)b + 2] = inf;
-            ++voided;
-        }
-    }
-    for (size_t i = 3 * (size_t)m; i < 3 * (size_t)m_pad; ++i) out[i] = inf;
-    return voided;
-}
-
-// ---- spatial order -------------------------------------------------------------------------------------------
+// ---- spatial order and duplicate flags, on the device ---------------------------------------------------------------
 // The sparse matching kernel prunes by bounding boxes of 8 consecutive model points and of 128 consecutive moving
 // points: it needs clouds whose index order has spatial locality.  A LiDAR scan has it; a mesh's vertex list
 // (Bunny) does not.  Where Morton order makes the groups clearly tighter than the given order, the kernel works
-// on a Morton-ordered view (a permutation, the clouds at the ABI and every index it returns stay in user order).
-static void morton_order(const float* xyz, int n, std::vector<int32_t>& perm)
+// on a Morton-ordered view (a permutation: the clouds at the ABI and every index it returns stay in user order).
+// Sorting and the extent test run on the device (rocPRIM radix sorts, fixed-order reductions): a few dozen
+// microseconds per cloud instead of milliseconds of std::sort on the host.
+static int prep_buffers(icp_ctx* c, int count, icp::PrepBuffers& b)
 {
-    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    bool any = false;
-    for (int i = 0; i < n; ++i) {
-        const float* p = xyz + 3 * (size_t)i;
-        if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = any ? std::min(lo[a], p[a]) : p[a];
-            hi[a] = any ? std::max(hi[a], p[a]) : p[a];
-        }
-        any = true;
+    const size_t tb = icp::prep_sort_temp_bytes(count);
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(c->prep_keys[k].ensure((size_t)count * sizeof(unsigned int)));
+        HIP_TRY(c->prep_vals[k].ensure((size_t)count * sizeof(int32_t)));
     }
-    float ext = 0.f;
-    for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
-    const double scale = ext > 0.f ? 1023.0 / ext : 0.0;   // one cube for all axes: cells stay cubic
-    auto spread = [](uint32_t v) {                          // 10 bits -> every third bit
-        v &= 1023u;
-        v = (v | (v << 16)) & 0x030000FFu;
-        v = (v | (v << 8)) & 0x0300F00Fu;
-        v = (v | (v << 4)) & 0x030C30C3u;
-        v = (v | (v << 2)) & 0x09249249u;
-        return v;
-    };
-    std::vector<uint64_t> key((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const float* p = xyz + 3 * (size_t)i;
-        uint32_t code = 0x7fffffffu;  // non-finite points go last
-        if (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])) {
-            uint32_t q[3];
-            for (int a = 0; a < 3; ++a) q[a] = (uint32_t)std::min(1023.0, std::max(0.0, ((double)p[a] - lo[a]) * scale));
-            code = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
-        }
-        key[i] = ((uint64_t)code << 32) | (uint32_t)i;      // ties keep index order
-    }
-    std::sort(key.begin(), key.end());
-    perm.resize((size_t)n);
-    for (int i = 0; i < n; ++i) perm[i] = (int32_t)(uint32_t)key[i];
+    HIP_TRY(c->prep_tmp.ensure(tb));
+    HIP_TRY(c->prep_small.ensure(sizeof(icp_ctx::PrepSmall)));
+    HIP_TRY(c->prep_ext.ensure((size_t)((count + 7) / 8) * sizeof(double)));
+    HIP_TRY(c->prep_voided.ensure((size_t)icp::round_up(count, 16) + 16));
+    HIP_TRY(c->prep_perm.ensure((size_t)count * sizeof(int32_t)));
+    b.keys[0] = (unsigned int*)c->prep_keys[0].p; b.keys[1] = (unsigned int*)c->prep_keys[1].p;
+    b.vals[0] = (int32_t*)c->prep_vals[0].p; b.vals[1] = (int32_t*)c->prep_vals[1].p;
+    b.temp = c->prep_tmp.p;
+    b.temp_bytes = tb;
+    b.box = (float*)c->prep_small.p;
+    b.ext = (double*)c->prep_ext.p;
+    HIP_TRY(hipMemsetAsync(c->prep_small.p, 0, sizeof(icp_ctx::PrepSmall), c->stream));
+    return ICP_OK;
 }
 
-// sum over groups of `group` consecutive points (in the given order) of the group's bounding-box extent dx + dy + dz
-static double grouped_extent(const float* xyz, const int32_t* perm, int n, int group)
+// reads the extent totals back and decides: true when Morton order makes the groups at least 30 % tighter
+static int morton_decision(icp_ctx* c, int count, int group, bool* use_sorted, int* voided_out)
 {
-    double total = 0.0;
-    for (int g0 = 0; g0 < n; g0 += group) {
-        float lo[3], hi[3];
-        bool any = false;
-        for (int k = g0; k < std::min(n, g0 + group); ++k) {
-            const float* p = xyz + 3 * (size_t)(perm ? perm[k] : k);
-            if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = any ? std::min(lo[a], p[a]) : p[a];
-                hi[a] = any ? std::max(hi[a], p[a]) : p[a];
-            }
-            any = true;
-        }
-        if (any) total += (double)(hi[0] - lo[0]) + (double)(hi[1] - lo[1]) + (double)(hi[2] - lo[2]);
-    }
-    return total;
-}
-
-// true (and perm filled) when Morton order makes the groups at least 30 % tighter than the cloud's own order
-static bool morton_is_tighter(const float* xyz, int n, int group, std::vector<int32_t>& perm)
-{
+    icp_ctx::PrepSmall h{};
+    HIP_TRY(hipMemcpyAsync(&h, c->prep_small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (voided_out) *voided_out = h.voided;
     static const char* force = std::getenv("ICP_SORT");   // ICP_SORT=0 never, =1 always (A/B runs)
-    if (force && force[0] == '0') return false;
-    if (n <= group) return false;
-    morton_order(xyz, n, perm);
-    if (force && force[0] == '1') return true;
-    return grouped_extent(xyz, perm.data(), n, group) < 0.7 * grouped_extent(xyz, nullptr, n, group);
+    if (force && force[0] == '0') *use_sorted = false;
+    else if (count <= group) *use_sorted = false;
+    else if (force && force[0] == '1') *use_sorted = true;
+    else *use_sorted = h.totals[1] < 0.7 * h.totals[0];
+    return ICP_OK;
 }
 
 int check_precision(int precision)
@@ -531,7 +463,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -664,25 +596,25 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
     if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q)) return rc;
     c->have_scan_copy = false;
     if (precision == ICP_F32 && m > 0) {
-        // scan copy for the early-out matching kernel: exact duplicates of a lower-index point (and the
-        // padding) voided to +inf -- they can never be the lowest-index minimum (see NNCullInputs)
+        // scan copy for the early-out matching kernels: exact duplicates of a lower-index point (and the padding)
+        // voided to +inf -- they can never be the lowest-index minimum (see NNCullInputs).  Flags, Morton order and
+        // the extent test are computed on the device from the uploaded cloud.
         const int m_pad = icp::pad_model(m);
-        std::vector<float> scan(3 * (size_t)m_pad);
-        c->voided = void_duplicate_points((const float*)xyz, m, m_pad, scan.data());
-        if (int rc = upload_cloud(c, scan.data(), m_pad, m_pad, precision, c->Qs)) return rc;
+        icp::PrepBuffers pb{};
+        if (int rc = prep_buffers(c, m, pb)) return rc;
+        icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
+        HIP_TRY(c->Qs.ensure(3 * (size_t)m_pad * sizeof(float)));
+        HIP_TRY(icp::launch_duplicates_and_scan_copy(pb, (const float*)c->Q.p, m, m_pad, (unsigned char*)c->prep_voided.p, &small->voided,
+                                                     (float*)c->Qs.p, c->stream));
+        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->Q.p, m, m_pad, 8, (int32_t*)c->prep_perm.p, small->totals, c->stream));
+        if (int rc = morton_decision(c, m, 8, &c->model_sorted, &c->voided)) return rc;
         // the sparse kernel's view: the same voided copy, in Morton order if the model's own order has no locality
-        std::vector<int32_t> perm;
-        c->model_sorted = morton_is_tighter((const float*)xyz, m, 8, perm);
         const void* view = c->Qs.p;
         if (c->model_sorted) {
-            std::vector<float> sorted(3 * (size_t)m_pad, std::numeric_limits<float>::infinity());
-            for (int k = 0; k < m; ++k)
-                for (int a = 0; a < 3; ++a) sorted[3 * (size_t)k + a] = scan[3 * (size_t)perm[k] + a];
-            perm.resize((size_t)m_pad, 0x7fffffff);
-            if (int rc = upload_cloud(c, sorted.data(), m_pad, m_pad, precision, c->Qss)) return rc;
+            HIP_TRY(c->Qss.ensure(3 * (size_t)m_pad * sizeof(float)));
             HIP_TRY(c->Qperm.ensure((size_t)m_pad * sizeof(int32_t)));
-            HIP_TRY(hipMemcpyAsync(c->Qperm.p, perm.data(), (size_t)m_pad * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));  // perm is a local
+            HIP_TRY(icp::launch_gather_sorted((const float*)c->Qs.p, m, m_pad, (const int32_t*)c->prep_perm.p, (float*)c->Qss.p,
+                                              (int32_t*)c->Qperm.p, c->stream));
             view = c->Qss.p;
         }
         // bounding boxes of its 8-point chunks (the first, cheapest level of the early-out) and one point per chunk
@@ -714,16 +646,16 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
         HIP_TRY(hipMemcpyAsync(c->P0.p, c->P.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     }
     c->moving_sorted = false;
-    if (precision == ICP_F32 && n > 0) {
-        std::vector<int32_t> perm;
-        if (morton_is_tighter((const float*)xyz, n, 128, perm)) {
-            const int n_pad = icp::pad_moving(n);
-            perm.resize((size_t)n_pad);
-            for (int k = n; k < n_pad; ++k) perm[k] = k;   // padding slots keep themselves
+    if (precision == ICP_F32 && n > 128) {
+        const int n_pad = icp::pad_moving(n);
+        icp::PrepBuffers pb{};
+        if (int rc = prep_buffers(c, n, pb)) return rc;
+        icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
+        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->P.p, n, n_pad, 128, (int32_t*)c->prep_perm.p, small->totals, c->stream));
+        if (int rc = morton_decision(c, n, 128, &c->moving_sorted, nullptr)) return rc;
+        if (c->moving_sorted) {
             HIP_TRY(c->Pperm.ensure((size_t)n_pad * sizeof(int32_t)));
-            HIP_TRY(hipMemcpyAsync(c->Pperm.p, perm.data(), (size_t)n_pad * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            c->moving_sorted = true;
+            HIP_TRY(icp::launch_slot_map((const int32_t*)c->prep_perm.p, n, n_pad, (int32_t*)c->Pperm.p, c->stream));
         }
     }
     c->have_moving = true;

@@ -84,6 +84,22 @@ struct NNCullInputs {
     const int32_t* q_perm = nullptr;
     const int32_t* p_perm = nullptr;
 };
+// device-side preparation of the sparse kernel's views (icp_set_model / icp_set_moving): scratch owned by the caller
+struct PrepBuffers {
+    unsigned int* keys[2];   // >= count each
+    int32_t* vals[2];        // >= count each
+    void* temp;              // rocPRIM radix-sort scratch, prep_sort_temp_bytes(count)
+    size_t temp_bytes;
+    float* box;              // 4 floats
+    double* ext;             // >= ceil(count / smallest group) doubles
+};
+size_t prep_sort_temp_bytes(int count);
+hipError_t launch_duplicates_and_scan_copy(const PrepBuffers& b, const float* X_soa, int n, int n_pad, unsigned char* voided, int* count_dev,
+                                           float* scan_out_soa, hipStream_t st);
+hipError_t launch_morton_order(const PrepBuffers& b, const float* X_soa, int n, int n_pad, int group, int32_t* perm_out, double* totals_dev,
+                               hipStream_t st);
+hipError_t launch_gather_sorted(const float* Qs_soa, int m, int m_pad, const int32_t* perm, float* out_soa, int32_t* perm_pad, hipStream_t st);
+hipError_t launch_slot_map(const int32_t* perm, int n, int n_pad, int32_t* out, hipStream_t st);
 size_t model_samples_bytes(int m_pad);
 hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, hipStream_t st);
 // diagnostic: per-wave phase stamps (s_memrealtime, 100 MHz) of the packed matching kernel, 10 slots per wave indexed
@@ -111,8 +127,6 @@ bool nn_can_fuse_tail(const NNPlan& pl);
 // `opt` (optional) = early-out inputs, `ta` (optional) = fused tail (then no partials are written).
 hipError_t launch_nn(const NNPlan& pl, const void* P_soa, const void* Q_soa, void* part_d, int32_t* part_idx,
                      const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st);
-// void the exact duplicates of a padded SoA model (host side, O(m) hash); returns how many were voided
-int void_duplicate_points_f32(const float* Q_soa_host, int m, int m_pad, float* out_soa_host);
 // stand-alone merge of the segment partials into idx (icp_nn_match_* only; the ICP loop merges
 // inside the moments kernel)
 hipError_t launch_merge(const NNPlan& pl, const void* part_d, const int32_t* part_idx, int32_t* idx, hipStream_t st);

@@ -19,6 +19,8 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #pragma clang fp contract(off)
 
@@ -1444,6 +1446,240 @@ __global__ void mailbox_selftest_kernel(const NNMailbox* mb, double* ack)
 hipError_t launch_mailbox_selftest(const NNMailbox* mb, double* ack, hipStream_t st)
 {
     hipLaunchKernelGGL(mailbox_selftest_kernel, dim3(1), dim3(64), 0, st, mb, ack);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// preparation of a cloud for the sparse kernel, on the device (once per icp_set_model / icp_set_moving):
+// exact-duplicate flags (lexicographic order of the raw coordinate bits: three stable radix passes),
+// Morton order, and the grouped-extent test that decides whether the Morton-ordered view is used.
+// Everything is deterministic (fixed-order reductions): the decision must not change from run to run.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int canon_bits(float v) { return __float_as_uint(v == 0.0f ? 0.0f : v); }
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+    return x - x == 0.f && y - y == 0.f && z - z == 0.f;   // false for NaN and +-inf
+}
+
+// keys[s] = raw bits of coordinate `axis` of point order[s] (order == NULL: identity, and vals is initialised)
+__global__ void prep_axis_keys_kernel(const float* __restrict__ X, int n, int n_pad, int axis, const int32_t* __restrict__ order,
+                                      unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = order ? order[s] : s;
+    keys[s] = canon_bits(X[(size_t)axis * n_pad + i]);
+    if (!order) vals[s] = s;
+}
+
+// lex[s] ascending in (x, y, z, index): a point equal to its predecessor has a lower-index twin
+__global__ void prep_mark_duplicates_kernel(const float* __restrict__ X, int n, int n_pad, const int32_t* __restrict__ lex,
+                                            unsigned char* __restrict__ voided, int* __restrict__ count)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    bool v = false;
+    if (s > 0) {
+        const int a = lex[s - 1], b = lex[s];
+        const float bx = X[b], by = X[(size_t)n_pad + b], bz = X[2 * (size_t)n_pad + b];
+        const bool same = canon_bits(X[a]) == canon_bits(bx) && canon_bits(X[(size_t)n_pad + a]) == canon_bits(by) &&
+                          canon_bits(X[2 * (size_t)n_pad + a]) == canon_bits(bz);
+        const bool nan = bx != bx || by != by || bz != bz;
+        v = same && !nan;
+    }
+    voided[lex[s]] = v ? 1 : 0;
+    if (v) atomicAdd(count, 1);
+}
+
+// scan copy: the cloud with its flagged points (and the padding) voided to +inf
+__global__ void prep_scan_copy_kernel(const float* __restrict__ X, int n, int n_pad, const unsigned char* __restrict__ voided,
+                                      float* __restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    const bool keep = j < n && !voided[j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out[(size_t)a * n_pad + j] = keep ? X[(size_t)a * n_pad + j] : inf_<float>();
+}
+
+// bounding cube of the finite points: box[0..2] = lo, box[3] = largest extent (one block, fixed order)
+__global__ __launch_bounds__(1024) void prep_bbox_kernel(const float* __restrict__ X, int n, int n_pad, float* __restrict__ box)
+{
+    __shared__ float red[6][1024];
+    float lo[3] = {inf_<float>(), inf_<float>(), inf_<float>()}, hi[3] = {-inf_<float>(), -inf_<float>(), -inf_<float>()};
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float x = X[i], y = X[(size_t)n_pad + i], z = X[2 * (size_t)n_pad + i];
+        if (!finite3(x, y, z)) continue;
+        lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+        hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+    }
+    for (int a = 0; a < 3; ++a) { red[a][threadIdx.x] = lo[a]; red[3 + a][threadIdx.x] = hi[a]; }
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int a = 0; a < 3; ++a) {
+                red[a][threadIdx.x] = fminf(red[a][threadIdx.x], red[a][threadIdx.x + w]);
+                red[3 + a][threadIdx.x] = fmaxf(red[3 + a][threadIdx.x], red[3 + a][threadIdx.x + w]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float ext = 0.f;
+        for (int a = 0; a < 3; ++a) { box[a] = red[a][0]; ext = fmaxf(ext, red[3 + a][0] - red[a][0]); }
+        box[3] = ext;   // -inf / NaN when there is no finite point: the codes below then all take the "last" value
+    }
+}
+
+__device__ __forceinline__ unsigned int spread10(unsigned int v)
+{
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// 30-bit Morton codes in one cube for all axes (cells stay cubic); non-finite points go last
+__global__ void prep_morton_keys_kernel(const float* __restrict__ X, int n, int n_pad, const float* __restrict__ box,
+                                        unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = X[i], y = X[(size_t)n_pad + i], z = X[2 * (size_t)n_pad + i];
+    unsigned int code = 0x7fffffffu;
+    const float ext = box[3];
+    if (finite3(x, y, z) && ext >= 0.f) {
+        const double scale = ext > 0.f ? 1023.0 / (double)ext : 0.0;
+        const unsigned int qx = (unsigned int)fmin(1023.0, fmax(0.0, ((double)x - (double)box[0]) * scale));
+        const unsigned int qy = (unsigned int)fmin(1023.0, fmax(0.0, ((double)y - (double)box[1]) * scale));
+        const unsigned int qz = (unsigned int)fmin(1023.0, fmax(0.0, ((double)z - (double)box[2]) * scale));
+        code = spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2);
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
+// per group of `group` consecutive entries of an order (NULL: the cloud's own): extent dx + dy + dz of its finite points
+__global__ void prep_group_extent_kernel(const float* __restrict__ X, int n, int n_pad, const int32_t* __restrict__ order, int group,
+                                         double* __restrict__ ext)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g0 = g * group;
+    if (g0 >= n) return;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool any = false;
+    for (int k = g0; k < min(n, g0 + group); ++k) {
+        const int i = order ? order[k] : k;
+        const float p[3] = {X[i], X[(size_t)n_pad + i], X[2 * (size_t)n_pad + i]};
+        if (!finite3(p[0], p[1], p[2])) continue;
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = any ? fminf(lo[a], p[a]) : p[a];
+            hi[a] = any ? fmaxf(hi[a], p[a]) : p[a];
+        }
+        any = true;
+    }
+    ext[g] = any ? (double)(hi[0] - lo[0]) + (double)(hi[1] - lo[1]) + (double)(hi[2] - lo[2]) : 0.0;
+}
+
+// out[which] = sum of ext[0..groups) in a fixed order (one block)
+__global__ __launch_bounds__(256) void prep_sum_kernel(const double* __restrict__ ext, int groups, double* __restrict__ out, int which)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int g = threadIdx.x; g < groups; g += 256) s += ext[g];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[which] = red[0];
+}
+
+// Morton-ordered view of a scan copy + its permutation, padded (+inf / 0x7fffffff)
+__global__ void prep_gather_sorted_kernel(const float* __restrict__ Qs, int m, int m_pad, const int32_t* __restrict__ perm,
+                                          float* __restrict__ out, int32_t* __restrict__ perm_pad)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m_pad) return;
+    const int j = k < m ? perm[k] : -1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out[(size_t)a * m_pad + k] = j >= 0 ? Qs[(size_t)a * m_pad + j] : inf_<float>();
+    perm_pad[k] = j >= 0 ? j : 0x7fffffff;
+}
+
+// slot -> point map of the moving cloud: the Morton order, padding slots keep themselves
+__global__ void prep_slot_map_kernel(const int32_t* __restrict__ perm, int n, int n_pad, int32_t* __restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_pad) out[k] = k < n ? perm[k] : k;
+}
+
+size_t prep_sort_temp_bytes(int count)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned int*)nullptr, (unsigned int*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                    (unsigned int)(count > 0 ? count : 1));
+    return bytes;
+}
+
+static hipError_t sort_pairs(const PrepBuffers& b, int count, int from, int end_bit, hipStream_t st)
+{
+    size_t bytes = b.temp_bytes;
+    return rocprim::radix_sort_pairs(b.temp, bytes, b.keys[from], b.keys[from ^ 1], b.vals[from], b.vals[from ^ 1], (unsigned int)count, 0,
+                                     (unsigned int)end_bit, st);
+}
+
+// voided[j] = 1 for every point with an exact lower-index twin, *count_dev += their number; then the scan copy
+hipError_t launch_duplicates_and_scan_copy(const PrepBuffers& b, const float* X, int n, int n_pad, unsigned char* voided, int* count_dev,
+                                           float* scan_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const dim3 blk(256), grd((n + 255) / 256);
+    int cur = 0;
+    for (int axis = 2; axis >= 0; --axis) {   // least significant key first, stable passes
+        hipLaunchKernelGGL(prep_axis_keys_kernel, grd, blk, 0, st, X, n, n_pad, axis, axis == 2 ? (const int32_t*)nullptr : b.vals[cur],
+                           b.keys[cur], b.vals[cur]);
+        if (hipError_t e = sort_pairs(b, n, cur, 32, st)) return e;
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(prep_mark_duplicates_kernel, grd, blk, 0, st, X, n, n_pad, b.vals[cur], voided, count_dev);
+    hipLaunchKernelGGL(prep_scan_copy_kernel, dim3((n_pad + 255) / 256), blk, 0, st, X, n, n_pad, voided, scan_out);
+    return hipGetLastError();
+}
+
+// perm_out[k] = k-th point in Morton order; totals[0] / totals[1] = summed group extents of the given / the Morton order
+hipError_t launch_morton_order(const PrepBuffers& b, const float* X, int n, int n_pad, int group, int32_t* perm_out, double* totals,
+                               hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const dim3 blk(256), grd((n + 255) / 256);
+    hipLaunchKernelGGL(prep_bbox_kernel, dim3(1), dim3(1024), 0, st, X, n, n_pad, b.box);
+    hipLaunchKernelGGL(prep_morton_keys_kernel, grd, blk, 0, st, X, n, n_pad, b.box, b.keys[0], b.vals[0]);
+    if (hipError_t e = sort_pairs(b, n, 0, 31, st)) return e;
+    if (hipError_t e = hipMemcpyAsync(perm_out, b.vals[1], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st)) return e;
+    const int groups = (n + group - 1) / group;
+    const dim3 ggrd((groups + 255) / 256);
+    hipLaunchKernelGGL(prep_group_extent_kernel, ggrd, blk, 0, st, X, n, n_pad, (const int32_t*)nullptr, group, b.ext);
+    hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups, totals, 0);
+    hipLaunchKernelGGL(prep_group_extent_kernel, ggrd, blk, 0, st, X, n, n_pad, (const int32_t*)perm_out, group, b.ext);
+    hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups, totals, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_sorted(const float* Qs, int m, int m_pad, const int32_t* perm, float* out, int32_t* perm_pad, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_gather_sorted_kernel, dim3((m_pad + 255) / 256), dim3(256), 0, st, Qs, m, m_pad, perm, out, perm_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_slot_map(const int32_t* perm, int n, int n_pad, int32_t* out, hipStream_t st)
+{
+    if (n_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_slot_map_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, perm, n, n_pad, out);
     return hipGetLastError();
 }
 
