@@ -5,19 +5,23 @@
 
 Workload (BASELINE.json `metric`, configs[2]): point-to-point ICP on the hall LiDAR scan, 16 384 moving x
 16 384 model points, fp32, clouds resident in HBM.  A *step* is one full ICP iteration of the loop in
-libicp_mi355x.so: [transform + error of the previous pass] -> brute-force matching -> fused
-gather/moments (rows into pinned host memory) -> host: tag poll, fixed-order row sum, 3x3 SVD.  The K timed steps are the
-iterations of back-to-back REAL registrations of the pair (tol 1e-6, MAX_ITER 100 as in
-src/CUDA/GPU_point_to_point_real.cu): each one restarts from the pristine moving cloud, pays its cold first
-matching pass and stops by the reference's rule -- not K iterations of an already converged pose.
+libicp_mi355x.so (icp_loop_run): ONE resident kernel per registration; per iteration the host sends a mailbox
+message (command, R, t), the kernel does [transform + error of the previous pass] -> matching (exact, sparse) ->
+moment rows into pinned host memory, the host adds the rows in fixed order as they arrive and solves the 3x3 SVD.
+The K timed steps are the iterations of back-to-back REAL registrations of the pair (tol 1e-6, MAX_ITER 100 as in
+src/CUDA/GPU_point_to_point_real.cu): each one restarts from the pristine moving cloud, pays its kernel launch and
+its cold first matching pass and stops by the reference's rule -- not K iterations of an already converged pose.
 
 N > 1 (weak scaling): every rank holds a hall-sized shard of the moving cloud (the global moving cloud is
-N x 16 384 points) and the full model; the only data that crosses ranks is the 32-double moment vector,
-summed by ONE all-reduce (RCCL through torch.distributed) per iteration, in place, between the enqueue
-and the host solve.  `value` = (N x K shard-iterations) / max-over-ranks time.
+N x 16 384 points) and the full model; the only data that crosses ranks is the 32-double moment vector, summed once
+per iteration -- by default through shared host memory (icp_comm_init_local: the vector is already on the host, the
+ranks of one node exchange 256 bytes in ~1 us and keep their resident kernels); ICP_BENCH_COMM=rccl uses ONE RCCL
+all-reduce issued by the library on the loop's stream (one kernel launch per pass), ICP_BENCH_COMM=torch the same
+through torch.distributed.  `value` = (N x K shard-iterations) / max-over-ranks time.
 
-One JSON line on stdout (rank 0).  Extra objects: `roofline` (the matching kernel, timed with HIP events
-inside the timed region), `cpu_baseline` (the CPU oracle on this box's host cores, bounded sample).
+One JSON line on stdout (rank 0).  Extra objects: `roofline` (the loop's kernel timed with HIP events inside the
+timed region + the stand-alone matching kernel), `cpu_baseline` (the CPU oracle on this box's host cores, bounded
+sample).
 """
 import argparse
 import json
