@@ -285,6 +285,10 @@ __device__ __forceinline__ f2 pk_sub_q(f2 q, f2 p)
 // drain the wave's global stores (s_waitcnt vmcnt(0)) -- ~1 us of idle time in the matching kernel's tail.
 __device__ __forceinline__ void lds_same_wave_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// An index the compiler must treat as new: keeps it from hoisting the per-lane 64-bit addresses derived from a
+// loop-invariant index out of the resident kernel's pass loop (a dozen register pairs held for nothing -- it spilled).
+__device__ __forceinline__ int fresh(int i) { asm volatile("" : "+v"(i)); return i; }
+
 // wave-wide min / max of a float by DPP (no LDS): row_shr 1,2,4,8 leave each row's result in its lane 15
 // (min/max are idempotent, overlapping windows are harmless), row_bcast15/31 carry it to lane 63.
 template <bool MAX>
@@ -303,6 +307,28 @@ __device__ __forceinline__ float wave_minmax(float v)
     ICP_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
 #undef ICP_DPP_STEP
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// bounding box of the wave's values: three minima and three maxima reduced together, so that the six dependent DPP
+// chains overlap (every DPP reads a register written six instructions earlier: no wait states except the first)
+__device__ __forceinline__ void wave_box(float (&lo)[3], float (&hi)[3])
+{
+#define ICP_BOX_STEP(CTRL)                                                                                      \
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL "\n\tv_min_f32_dpp %1, %1, %1 " CTRL "\n\tv_min_f32_dpp %2, %2, %2 " CTRL \
+                 "\n\tv_max_f32_dpp %3, %3, %3 " CTRL "\n\tv_max_f32_dpp %4, %4, %4 " CTRL "\n\tv_max_f32_dpp %5, %5, %5 " CTRL        \
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]));
+    ICP_BOX_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+    ICP_BOX_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+    ICP_BOX_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+    ICP_BOX_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+    ICP_BOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    ICP_BOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef ICP_BOX_STEP
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo[a]), 63));
+        hi[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi[a]), 63));
+    }
 }
 
 constexpr int NN2_TQW = 256;  // model points per wave per LDS tile step
@@ -459,8 +485,8 @@ struct NNFuse {
 
 // phase stamp of the diagnostic log: one scalar branch when the log is off
 #define ICP_PHASE(PH)                                                                                              \
-    if (fuse.tlog != nullptr && lane == 0 && (fuse.tlog_pass < 0 || fuse.tlog_pass == phase_pass_)) {                                                                       \
-        const long long slot_ = (((long long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + w) * 10 + (PH);            \
+    if constexpr (phase_diag_) if (fuse.tlog != nullptr && lane == 0 && (fuse.tlog_pass < 0 || fuse.tlog_pass == phase_pass_)) {                                                                       \
+        const long long slot_ = (((long long)blockIdx.y * gridDim.x + blockIdx.x) * phase_nw_ + w) * 10 + (PH);                     \
         if (slot_ < fuse.tlog_cap) fuse.tlog[slot_] = (long long)wall_clock64();                                   \
     }
 
@@ -486,7 +512,8 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
     // the wave id as a SCALAR: everything derived from it (ranges, loop bounds, the box addresses) then lives in
     // SGPRs, the loops are scalar loops and the per-chunk boxes arrive through the scalar cache
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int phase_pass_ = 0;  // (phase log)
+    constexpr int phase_pass_ = 0, phase_nw_ = 4;  // (phase log)
+    constexpr bool phase_diag_ = true;
     const int wseg = seg_len >> 2;              // model points per wave (multiple of C)
     const int q0 = blockIdx.y * seg_len;
     const int my0 = q0 + w * wseg;
@@ -787,30 +814,43 @@ constexpr int SP_STAGE = 40;                    // floats per staged hit: box 8,
 
 // one hit chunk against the lane's packed pair; (best, bj) follow the lexicographic (distance, MODEL index) rule:
 // the chunk takes a point's minimum if its own minimum is smaller, or equal with a lower model index.  The scan copy
-// may be spatially sorted, so the model index of chunk element k is qo[k] (identity order: ch * 8 + k); it is looked
-// at only on the rare path where the chunk's minimum reaches the running one.
-template <bool QS>
-__device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const float* qyp, const float* qzp, const int* qo,
-                                                     const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
-                                                     float (&bq)[2][3])
+// may be spatially sorted, so the model index of chunk element k is a staged value (identity order: chunk * 8 + k); it
+// is looked at only on the rare path where the chunk's minimum reaches the running one.
+// `sb` is the hit's LDS stage {box 8, x 8, y 8, z 8, model index 8}.  Everything is read up front -- one LDS round trip
+// per hit instead of one per pruning level: the wave works through its hits alone, so latency is what it pays for.
+// PERM: the scan copy is a sorted view, element k of the chunk is model point qo[k]; else it is point ch * 8 + k and
+// "lowest model index" is simply "lowest k".
+template <bool PERM>
+__device__ __forceinline__ void scan_hit(const float* sb, int ch, const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
+                                         float (&bq)[2][3])
 {
     constexpr int C = 8;
+    const float4 b0 = *reinterpret_cast<const float4*>(sb), b1 = *reinterpret_cast<const float4*>(sb + 4);
+    const float4 qx4[2] = {*reinterpret_cast<const float4*>(sb + 8), *reinterpret_cast<const float4*>(sb + 12)};
+    const float4 qy4[2] = {*reinterpret_cast<const float4*>(sb + 16), *reinterpret_cast<const float4*>(sb + 20)};
+    const float4 qz4[2] = {*reinterpret_cast<const float4*>(sb + 24), *reinterpret_cast<const float4*>(sb + 28)};
+    int4 qo4[2] = {int4{0, 0, 0, 0}, int4{0, 0, 0, 0}};
+    if constexpr (PERM) { qo4[0] = *reinterpret_cast<const int4*>(sb + 32); qo4[1] = *reinterpret_cast<const int4*>(sb + 36); }
+    {
+        // level 0: the chunk's bounding box against each of the lane's points (ties pass: the hits are unordered)
+        const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
+        if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, pxa, pya, pza, best)) == 0ull) return;
+    }
     f2 d[C];  // first dx*dx + dy*dy (the inner sum of the reference's association), then the distances
     float mxy0 = inf_<float>(), mxy1 = inf_<float>();
 #pragma unroll
-    for (int kk = 0; kk < C; kk += 4) {
-        const float4 qx4 = *reinterpret_cast<const float4*>(qxp + kk);
-        const float4 qy4 = *reinterpret_cast<const float4*>(qyp + kk);
-        const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
-        const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+    for (int h = 0; h < 2; ++h) {
+        const int kk = 4 * h;
+        const f2 qxa = f2{qx4[h].x, qx4[h].y}, qxb = f2{qx4[h].z, qx4[h].w};
+        const f2 qya = f2{qy4[h].x, qy4[h].y}, qyb = f2{qy4[h].z, qy4[h].w};
         f2 ax, ay;
-        ax = pk_sub_q<0, QS>(qxa, px); ay = pk_sub_q<0, QS>(qya, py);
+        ax = pk_sub_bcast<0>(qxa, px); ay = pk_sub_bcast<0>(qya, py);
         d[kk + 0] = ax * ax + ay * ay;
-        ax = pk_sub_q<1, QS>(qxa, px); ay = pk_sub_q<1, QS>(qya, py);
+        ax = pk_sub_bcast<1>(qxa, px); ay = pk_sub_bcast<1>(qya, py);
         d[kk + 1] = ax * ax + ay * ay;
-        ax = pk_sub_q<0, QS>(qxb, px); ay = pk_sub_q<0, QS>(qyb, py);
+        ax = pk_sub_bcast<0>(qxb, px); ay = pk_sub_bcast<0>(qyb, py);
         d[kk + 2] = ax * ax + ay * ay;
-        ax = pk_sub_q<1, QS>(qxb, px); ay = pk_sub_q<1, QS>(qyb, py);
+        ax = pk_sub_bcast<1>(qxb, px); ay = pk_sub_bcast<1>(qyb, py);
         d[kk + 3] = ax * ax + ay * ay;
         mxy0 = fmin_(fmin_(mxy0, d[kk].x), d[kk + 1].x);
         mxy0 = fmin_(fmin_(mxy0, d[kk + 2].x), d[kk + 3].x);
@@ -821,14 +861,14 @@ __device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const flo
     if (__builtin_amdgcn_ballot_w64((mxy0 <= best[0]) | (mxy1 <= best[1])) == 0ull) return;
     float c0 = inf_<float>(), c1 = inf_<float>();  // the chunk's own minima
 #pragma unroll
-    for (int kk = 0; kk < C; kk += 4) {
-        const float4 qz4 = *reinterpret_cast<const float4*>(qzp + kk);
-        const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+    for (int h = 0; h < 2; ++h) {
+        const int kk = 4 * h;
+        const f2 qza = f2{qz4[h].x, qz4[h].y}, qzb = f2{qz4[h].z, qz4[h].w};
         f2 az;
-        az = pk_sub_q<0, QS>(qza, pz); d[kk + 0] = d[kk + 0] + az * az;
-        az = pk_sub_q<1, QS>(qza, pz); d[kk + 1] = d[kk + 1] + az * az;
-        az = pk_sub_q<0, QS>(qzb, pz); d[kk + 2] = d[kk + 2] + az * az;
-        az = pk_sub_q<1, QS>(qzb, pz); d[kk + 3] = d[kk + 3] + az * az;
+        az = pk_sub_bcast<0>(qza, pz); d[kk + 0] = d[kk + 0] + az * az;
+        az = pk_sub_bcast<1>(qza, pz); d[kk + 1] = d[kk + 1] + az * az;
+        az = pk_sub_bcast<0>(qzb, pz); d[kk + 2] = d[kk + 2] + az * az;
+        az = pk_sub_bcast<1>(qzb, pz); d[kk + 3] = d[kk + 3] + az * az;
         c0 = fmin_(fmin_(c0, d[kk].x), d[kk + 1].x);
         c0 = fmin_(fmin_(c0, d[kk + 2].x), d[kk + 3].x);
         c1 = fmin_(fmin_(c1, d[kk].y), d[kk + 1].y);
@@ -838,12 +878,23 @@ __device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const flo
     if (__builtin_amdgcn_ballot_w64(cand0 | cand1) != 0ull) {
         // lowest model index among the chunk elements at the chunk's minimum, and where it sits
         int o0 = 0x7fffffff, o1 = 0x7fffffff, k0 = 0, k1 = 0;
+        if constexpr (PERM) {
+            const int qo[C] = {qo4[0].x, qo4[0].y, qo4[0].z, qo4[0].w, qo4[1].x, qo4[1].y, qo4[1].z, qo4[1].w};
 #pragma unroll
-        for (int kk = C - 1; kk >= 0; --kk) {
-            const int oj = qo[kk];  // wave-uniform address: one broadcast read
-            const bool e0 = (d[kk].x == c0) & (oj < o0), e1 = (d[kk].y == c1) & (oj < o1);
-            o0 = e0 ? oj : o0; k0 = e0 ? kk : k0;
-            o1 = e1 ? oj : o1; k1 = e1 ? kk : k1;
+            for (int kk = C - 1; kk >= 0; --kk) {
+                const bool e0 = (d[kk].x == c0) & (qo[kk] < o0), e1 = (d[kk].y == c1) & (qo[kk] < o1);
+                o0 = e0 ? qo[kk] : o0; k0 = e0 ? kk : k0;
+                o1 = e1 ? qo[kk] : o1; k1 = e1 ? kk : k1;
+            }
+        } else {
+            k0 = k1 = C - 1;
+#pragma unroll
+            for (int kk = C - 2; kk >= 0; --kk) {
+                k0 = (d[kk].x == c0) ? kk : k0;
+                k1 = (d[kk].y == c1) ? kk : k1;
+            }
+            o0 = ch * C + k0;
+            o1 = ch * C + k1;
         }
         const bool take0 = cand0 & ((c0 < best[0]) | (bj[0] < 0) | (o0 < bj[0]));  // bj < 0: nothing to tie with yet
         const bool take1 = cand1 & ((c1 < best[1]) | (bj[1] < 0) | (o1 < bj[1]));
@@ -853,8 +904,8 @@ __device__ __forceinline__ void scan_chunk_unordered(const float* qxp, const flo
         bj[1] = take1 ? o1 : bj[1];
         // the coordinates of the new minimum are at hand (LDS stage): keeping them saves the closing wave a
         // dependent gather from global memory
-        if (take0) { bq[0][0] = qxp[k0]; bq[0][1] = qyp[k0]; bq[0][2] = qzp[k0]; }
-        if (take1) { bq[1][0] = qxp[k1]; bq[1][1] = qyp[k1]; bq[1][2] = qzp[k1]; }
+        if (take0) { bq[0][0] = sb[8 + k0]; bq[0][1] = sb[16 + k0]; bq[0][2] = sb[24 + k0]; }
+        if (take1) { bq[1][0] = sb[8 + k1]; bq[1][1] = sb[16 + k1]; bq[1][2] = sb[24 + k1]; }
     }
 }
 
@@ -889,12 +940,12 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
 // px.y = point lane + 64) with their final correspondences j[]: stores idx, gathers q (and the normal),
 // accumulates in fp64, reduces through LDS in lane order and writes the row + completion tag.
 // (qio: the coordinates of the correspondences -- gathered here when `gather`, else supplied by the caller)
-template <int TAIL>
+template <int TAIL, bool phase_diag_>
 __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f2 pz, const int (&j)[2], int lane, const int (&pi)[2],
                                                int m_pad, const NNFuse& fuse, const NNTail& tail, double err_row,
                                                unsigned char* lds_raw, float (&qio)[2][3], bool gather, int phase_pass_ = 0)
 {
-    constexpr int w = 0;  // (phase log) the closing wave
+    constexpr int w = 0, phase_nw_ = SP_NW;  // (phase log) the closing wave of a sparse-kernel block
     constexpr int NACC = TAIL == 2 ? 28 : 18;
     double acc[NACC];
 #pragma unroll
@@ -902,7 +953,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
     const float* Qg = fuse.Q_gather;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int i = pi[t];
+        const int i = fresh(pi[t]);
         if (i < fuse.n) {
             const int jj = j[t];
             tail.idx_out[i] = jj;
@@ -951,7 +1002,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
     {
         const int slot = lane % NACC, part = lane / NACC;
         if (part < PARTS) {
-            double v[PER];
+            double v[PER];   // all loads first, then the adds: one LDS latency instead of PER
 #pragma unroll
             for (int l = 0; l < PER; ++l) v[l] = (part * PER + l < 64) ? tr[slot][part * PER + l] : 0.0;
             double sum = 0.0;
@@ -976,7 +1027,9 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
     if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], tail.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int TAIL>
+// DIAG: the phase-stamp instrumentation (ICP_NN_PHASES) is compiled into its own instantiation -- its pointers and
+// branches cost the production kernel scalar registers it does not have to spare
+template <int TAIL, bool DIAG>
 __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __restrict__ P, int n_pad,
                                                               const float* __restrict__ Q, int m_pad, int seg_len,
                                                               int round_passes, float* __restrict__ part_d,
@@ -1011,28 +1064,21 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     float (*seedq)[128] = reinterpret_cast<float (*)[128]>(lds_raw + SEED_OFF);
     float (*mq)[SP_NW][128] = reinterpret_cast<float (*)[SP_NW][128]>(lds_raw + MQ_OFF);
     int phase_pass_ = 0;  // (phase log)
+    constexpr int phase_nw_ = SP_NW;
+    constexpr bool phase_diag_ = DIAG;
     ICP_PHASE(0)
-    // issued first, with everything else that does not depend on the points: the chunk boxes of the wave's first
-    // two find passes ...
     const int q0 = blockIdx.y * seg_len;
     const int c_lo = q0 / 8, c_hi = min(q0 + seg_len, m_pad) / 8;
     constexpr int PRE = 2;
-    float4 pb[PRE][2];
-#pragma unroll
-    for (int r = 0; r < PRE; ++r) {
-        const int cidx = c_lo + (r * SP_NW + w) * 64 + lane;
-        const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cidx < c_hi ? cidx : 0) * 8);
-        pb[r][0] = bp[0];
-        pb[r][1] = bp[1];
-    }
-    // ... and the seed gather does not depend on the points (the compiler cannot move these loads above the
+    // issued first, with everything else that does not depend on the points:
+    // the seed gather does not depend on the points (the compiler cannot move these loads above the
     // stores to P_out itself), and when the seeds are the correspondences the fused transform came from -- the
     // ordinary loop -- the same gathered q serves the error of that pass
     bool real[2], sok[2];
     float sq[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int i = pi[t];
+        const int i = fresh(pi[t]);
         real[t] = i < fuse.n;
         sok[t] = false;
         sq[t][0] = sq[t][1] = sq[t][2] = 0.f;
@@ -1058,6 +1104,16 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     // host: no launch, no dispatch, no kernel boundary between two passes.
     // Wave 0 of every block waits for the message (see below), the other waves sleep at the barrier.  The poll budget
     // (a few seconds) is the exit every wave reaches if the host never answers.
+    // the chunk boxes of the wave's first two find passes: fetched once (a resident kernel keeps them in registers: the model
+    // does not change)
+    float4 pb[PRE][2];
+#pragma unroll
+    for (int r = 0; r < PRE; ++r) {
+        const int cidx = c_lo + (r * SP_NW + w) * 64 + lane;
+        const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cidx < c_hi ? cidx : 0) * 8);
+        pb[r][0] = bp[0];
+        pb[r][1] = bp[1];
+    }
     for (int pass = 0;; ++pass) {
     phase_pass_ = pass;
     double err_row = 0.0;
@@ -1141,7 +1197,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             apply_rt<float>(rt, x, y, z, x, y, z);
             if (t) { px.y = x; py.y = y; pz.y = z; } else { px.x = x; py.x = y; pz.x = z; }
             if (blockIdx.y == 0 && w == 0) {
-                const int i = pi[t];
+                const int i = fresh(pi[t]);
                 fuse.P_out[i] = x;
                 fuse.P_out[(size_t)n_pad + i] = y;
                 fuse.P_out[2 * (size_t)n_pad + i] = z;
@@ -1172,7 +1228,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     if (!apply && pass == 0 && fuse.store_first && blockIdx.y == 0 && w == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int i = pi[t];
+            const int i = fresh(pi[t]);
             fuse.P_out[i] = t ? px.y : px.x;
             fuse.P_out[(size_t)n_pad + i] = t ? py.y : py.x;
             fuse.P_out[2 * (size_t)n_pad + i] = t ? pz.y : pz.x;
@@ -1246,10 +1302,9 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     ICP_PHASE(2)
 
     // bounding box of the block's 128 moving points (every wave derives the same one)
-    float glo[3], ghi[3];
-    glo[0] = wave_minmax<false>(__builtin_fminf(px.x, px.y)); ghi[0] = wave_minmax<true>(__builtin_fmaxf(px.x, px.y));
-    glo[1] = wave_minmax<false>(__builtin_fminf(py.x, py.y)); ghi[1] = wave_minmax<true>(__builtin_fmaxf(py.x, py.y));
-    glo[2] = wave_minmax<false>(__builtin_fminf(pz.x, pz.y)); ghi[2] = wave_minmax<true>(__builtin_fmaxf(pz.x, pz.y));
+    float glo[3] = {__builtin_fminf(px.x, px.y), __builtin_fminf(py.x, py.y), __builtin_fminf(pz.x, pz.y)};
+    float ghi[3] = {__builtin_fmaxf(px.x, px.y), __builtin_fmaxf(py.x, py.y), __builtin_fmaxf(pz.x, pz.y)};
+    wave_box(glo, ghi);
 
     const int round_chunks = SP_NW * 64 * round_passes;
     // one find pass: lane l tests chunk c0 + l (box b0 = lo.xyz hi.x, b1 = hi.yz - -) and appends it to the hit list
@@ -1305,26 +1360,24 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                                                     : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)chl * 8 + (part & 1) * 4;
                         *reinterpret_cast<float4*>(stage + r * SP_STAGE + part * 4) = *reinterpret_cast<const float4*>(src);
                     }
-                    // the elements' model indices: the sort permutation, or simply chunk * 8 + k
+                    // a sorted view: the elements' model indices (the sort permutation) are staged too
                     const int r2 = lane >> 1, half = lane & 1;
                     const int h2 = hb + r2 * SP_NW + w;
-                    if (lane < 16 && h2 < h1) {
-                        const int chl = hits[h2];
-                        int4 v;
-                        if (fuse.q_perm) v = *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)chl * 8 + half * 4);
-                        else { const int b = chl * 8 + half * 4; v = int4{b, b + 1, b + 2, b + 3}; }
-                        *reinterpret_cast<int4*>(stage + r2 * SP_STAGE + 32 + half * 4) = v;
-                    }
+                    if (fuse.q_perm && lane < 16 && h2 < h1)
+                        *reinterpret_cast<int4*>(stage + r2 * SP_STAGE + 32 + half * 4) =
+                            *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)hits[h2] * 8 + half * 4);
                 }
                 lds_same_wave_order();
                 const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
                 const int cnt = mine < 8 ? mine : 8;
+#pragma unroll 1
                 for (int rr = 0; rr < cnt; ++rr) {
-                    const float* sb = stage + rr * SP_STAGE;
-                    const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
-                    if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull)
-                        continue;
-                    scan_chunk_unordered<false>(sb + 8, sb + 16, sb + 24, reinterpret_cast<const int*>(sb + 32), px, py, pz, best, bj, bq);
+                    if (fuse.q_perm) {
+                        scan_hit<true>(stage + rr * SP_STAGE, 0, px, py, pz, best, bj, bq);
+                    } else {
+                        const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * SP_NW + w]);
+                        scan_hit<false>(stage + rr * SP_STAGE, ch, px, py, pz, best, bj, bq);
+                    }
                 }
                 lds_same_wave_order();
             }
@@ -1416,7 +1469,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         tl.idx_out = (pass & 1) ? tail.idx_out_odd : tail.idx_out;
         // (a row closed over several segment blocks may have been won elsewhere: its coordinates are gathered)
         if (gridDim.y == 1) { ICP_PHASE(6) }
-        tail_close_row<TAIL>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gridDim.y > 1, pass);
+        tail_close_row<TAIL, DIAG>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gridDim.y > 1, pass);
         ICP_PHASE(9)
         if (!fuse.resident) return;
         // the matches of this pass seed the next one and are what its error is measured against
@@ -2506,7 +2559,9 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             int n_pad = pl.n_pad, m_pad = pl.m_pad, seg = pl.seg_len;
             float* pd = (float*)part_d;
             void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
-            const void* fn = ta->metric == ICP_POINT_TO_PLANE ? (const void*)nn_match_sparse<2> : (const void*)nn_match_sparse<1>;
+            const bool diag = fuse.tlog != nullptr;
+            const void* fn = ta->metric == ICP_POINT_TO_PLANE ? (diag ? (const void*)nn_match_sparse<2, true> : (const void*)nn_match_sparse<2, false>)
+                                                              : (diag ? (const void*)nn_match_sparse<1, true> : (const void*)nn_match_sparse<1, false>);
             // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
             // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
             // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that
@@ -2515,7 +2570,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             static const int env_coop = env_int("ICP_COOP", 0);
             if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
             static long long capacity[2] = {-1, -1};   // blocks the machine holds at once, per kernel variant (asked once)
-            long long& cap = capacity[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0];
+            static long long capacity_diag[2] = {-1, -1};
+            long long& cap = (diag ? capacity_diag : capacity)[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0];
             if (cap < 0) {
                 int per_cu = 0, dev = 0, cus = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
@@ -2527,7 +2583,11 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             return hipLaunchKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
         }
 #define ICP_LAUNCH_SP(TL)                                                                                          \
-    hipLaunchKernelGGL((nn_match_sparse<TL>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,              \
+    if (fuse.tlog != nullptr)                                                                                      \
+        hipLaunchKernelGGL((nn_match_sparse<TL, true>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,   \
+                           (const float*)Qsp, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail); \
+    else                                                                                                           \
+        hipLaunchKernelGGL((nn_match_sparse<TL, false>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,  \
                        (const float*)Qsp, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail)
         if (!ta) ICP_LAUNCH_SP(0);
         else if (ta->metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_SP(2);
