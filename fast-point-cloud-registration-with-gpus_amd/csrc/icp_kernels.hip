@@ -810,39 +810,34 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
 constexpr int SP_NW = 16;                       // waves per block
 constexpr int SP_HCAP = 4096;                   // hit-list entries = chunks per round (SP_NW * 64 * passes <= this)
 constexpr int SP_MAX_PASSES = SP_HCAP / (SP_NW * 64);
-constexpr int SP_STAGE = 40;                    // floats per staged hit: box 8, x 8, y 8, z 8, model indices 8
 
 // one hit chunk against the lane's packed pair; (best, bj) follow the lexicographic (distance, MODEL index) rule:
-// the chunk takes a point's minimum if its own minimum is smaller, or equal with a lower model index.  The scan copy
-// may be spatially sorted, so the model index of chunk element k is a staged value (identity order: chunk * 8 + k); it
-// is looked at only on the rare path where the chunk's minimum reaches the running one.
-// `sb` is the hit's LDS stage {box 8, x 8, y 8, z 8, model index 8}.  Everything is read up front -- one LDS round trip
-// per hit instead of one per pruning level: the wave works through its hits alone, so latency is what it pays for.
-// PERM: the scan copy is a sorted view, element k of the chunk is model point qo[k]; else it is point ch * 8 + k and
-// "lowest model index" is simply "lowest k".
+// the chunk takes a point's minimum if its own minimum is smaller, or equal with a lower model index.
+// `sb` is the hit's LDS stage {box 8, x 8, y 8, z 8, model index 8}, read level by level: most hits end at the box
+// test or at the xy early-out, and with many hits per wave the 16 waves share the LDS bandwidth (reading a hit in
+// one go was measured: no gain on the hall scan, 13 % slower on the hit-heavy grid).
+// PERM: the scan copy is a sorted view, element k of the chunk is model point qo[k] (looked at only on the rare path
+// where the chunk's minimum reaches the running one); else it is point ch * 8 + k and "lowest model index" is
+// simply "lowest k".
 template <bool PERM>
 __device__ __forceinline__ void scan_hit(const float* sb, int ch, const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
                                          float (&bq)[2][3])
 {
     constexpr int C = 8;
-    const float4 b0 = *reinterpret_cast<const float4*>(sb), b1 = *reinterpret_cast<const float4*>(sb + 4);
-    const float4 qx4[2] = {*reinterpret_cast<const float4*>(sb + 8), *reinterpret_cast<const float4*>(sb + 12)};
-    const float4 qy4[2] = {*reinterpret_cast<const float4*>(sb + 16), *reinterpret_cast<const float4*>(sb + 20)};
-    const float4 qz4[2] = {*reinterpret_cast<const float4*>(sb + 24), *reinterpret_cast<const float4*>(sb + 28)};
-    int4 qo4[2] = {int4{0, 0, 0, 0}, int4{0, 0, 0, 0}};
-    if constexpr (PERM) { qo4[0] = *reinterpret_cast<const int4*>(sb + 32); qo4[1] = *reinterpret_cast<const int4*>(sb + 36); }
     {
         // level 0: the chunk's bounding box against each of the lane's points (ties pass: the hits are unordered)
         const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
-        if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, pxa, pya, pza, best)) == 0ull) return;
+        if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull) return;
     }
+    const float *qxp = sb + 8, *qyp = sb + 16, *qzp = sb + 24;
     f2 d[C];  // first dx*dx + dy*dy (the inner sum of the reference's association), then the distances
     float mxy0 = inf_<float>(), mxy1 = inf_<float>();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int kk = 4 * h;
-        const f2 qxa = f2{qx4[h].x, qx4[h].y}, qxb = f2{qx4[h].z, qx4[h].w};
-        const f2 qya = f2{qy4[h].x, qy4[h].y}, qyb = f2{qy4[h].z, qy4[h].w};
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qx4 = *reinterpret_cast<const float4*>(qxp + kk);
+        const float4 qy4 = *reinterpret_cast<const float4*>(qyp + kk);
+        const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+        const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
         f2 ax, ay;
         ax = pk_sub_bcast<0>(qxa, px); ay = pk_sub_bcast<0>(qya, py);
         d[kk + 0] = ax * ax + ay * ay;
@@ -861,9 +856,9 @@ __device__ __forceinline__ void scan_hit(const float* sb, int ch, const f2 px, c
     if (__builtin_amdgcn_ballot_w64((mxy0 <= best[0]) | (mxy1 <= best[1])) == 0ull) return;
     float c0 = inf_<float>(), c1 = inf_<float>();  // the chunk's own minima
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int kk = 4 * h;
-        const f2 qza = f2{qz4[h].x, qz4[h].y}, qzb = f2{qz4[h].z, qz4[h].w};
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qz4 = *reinterpret_cast<const float4*>(qzp + kk);
+        const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
         f2 az;
         az = pk_sub_bcast<0>(qza, pz); d[kk + 0] = d[kk + 0] + az * az;
         az = pk_sub_bcast<1>(qza, pz); d[kk + 1] = d[kk + 1] + az * az;
@@ -874,38 +869,48 @@ __device__ __forceinline__ void scan_hit(const float* sb, int ch, const f2 px, c
         c1 = fmin_(fmin_(c1, d[kk].y), d[kk + 1].y);
         c1 = fmin_(fmin_(c1, d[kk + 2].y), d[kk + 3].y);
     }
-    const bool cand0 = c0 <= best[0], cand1 = c1 <= best[1];
-    if (__builtin_amdgcn_ballot_w64(cand0 | cand1) != 0ull) {
-        // lowest model index among the chunk elements at the chunk's minimum, and where it sits
-        int o0 = 0x7fffffff, o1 = 0x7fffffff, k0 = 0, k1 = 0;
-        if constexpr (PERM) {
-            const int qo[C] = {qo4[0].x, qo4[0].y, qo4[0].z, qo4[0].w, qo4[1].x, qo4[1].y, qo4[1].z, qo4[1].w};
+    if constexpr (PERM) {
+        const bool cand0 = c0 <= best[0], cand1 = c1 <= best[1];
+        if (__builtin_amdgcn_ballot_w64(cand0 | cand1) != 0ull) {
+            // lowest model index among the chunk elements at the chunk's minimum, and where it sits
+            const int* qo = reinterpret_cast<const int*>(sb + 32);
+            int o0 = 0x7fffffff, o1 = 0x7fffffff, k0 = 0, k1 = 0;
 #pragma unroll
             for (int kk = C - 1; kk >= 0; --kk) {
-                const bool e0 = (d[kk].x == c0) & (qo[kk] < o0), e1 = (d[kk].y == c1) & (qo[kk] < o1);
-                o0 = e0 ? qo[kk] : o0; k0 = e0 ? kk : k0;
-                o1 = e1 ? qo[kk] : o1; k1 = e1 ? kk : k1;
+                const int oj = qo[kk];  // wave-uniform address: one broadcast read
+                const bool e0 = (d[kk].x == c0) & (oj < o0), e1 = (d[kk].y == c1) & (oj < o1);
+                o0 = e0 ? oj : o0; k0 = e0 ? kk : k0;
+                o1 = e1 ? oj : o1; k1 = e1 ? kk : k1;
             }
-        } else {
-            k0 = k1 = C - 1;
+            const bool take0 = cand0 & ((c0 < best[0]) | (bj[0] < 0) | (o0 < bj[0]));  // bj < 0: nothing to tie with yet
+            const bool take1 = cand1 & ((c1 < best[1]) | (bj[1] < 0) | (o1 < bj[1]));
+            best[0] = take0 ? c0 : best[0];
+            bj[0] = take0 ? o0 : bj[0];
+            best[1] = take1 ? c1 : best[1];
+            bj[1] = take1 ? o1 : bj[1];
+            if (take0) { bq[0][0] = qxp[k0]; bq[0][1] = qyp[k0]; bq[0][2] = qzp[k0]; }
+            if (take1) { bq[1][0] = qxp[k1]; bq[1][1] = qyp[k1]; bq[1][2] = qzp[k1]; }
+        }
+    } else {
+        // identity order: chunks are disjoint index ranges, "lower model index" is "lower chunk, then lower k"
+        const bool take0 = (c0 < best[0]) | ((c0 == best[0]) & (ch < (bj[0] >> 3)));  // bj = -1: nothing to tie with
+        const bool take1 = (c1 < best[1]) | ((c1 == best[1]) & (ch < (bj[1] >> 3)));
+        if (__builtin_amdgcn_ballot_w64(take0 | take1) != 0ull) {
+            int k0 = C - 1, k1 = C - 1;
 #pragma unroll
             for (int kk = C - 2; kk >= 0; --kk) {
                 k0 = (d[kk].x == c0) ? kk : k0;
                 k1 = (d[kk].y == c1) ? kk : k1;
             }
-            o0 = ch * C + k0;
-            o1 = ch * C + k1;
+            best[0] = take0 ? c0 : best[0];
+            bj[0] = take0 ? ch * C + k0 : bj[0];
+            best[1] = take1 ? c1 : best[1];
+            bj[1] = take1 ? ch * C + k1 : bj[1];
+            // the coordinates of the new minimum are at hand (LDS stage): keeping them saves the closing wave a
+            // dependent gather from global memory
+            if (take0) { bq[0][0] = qxp[k0]; bq[0][1] = qyp[k0]; bq[0][2] = qzp[k0]; }
+            if (take1) { bq[1][0] = qxp[k1]; bq[1][1] = qyp[k1]; bq[1][2] = qzp[k1]; }
         }
-        const bool take0 = cand0 & ((c0 < best[0]) | (bj[0] < 0) | (o0 < bj[0]));  // bj < 0: nothing to tie with yet
-        const bool take1 = cand1 & ((c1 < best[1]) | (bj[1] < 0) | (o1 < bj[1]));
-        best[0] = take0 ? c0 : best[0];
-        bj[0] = take0 ? o0 : bj[0];
-        best[1] = take1 ? c1 : best[1];
-        bj[1] = take1 ? o1 : bj[1];
-        // the coordinates of the new minimum are at hand (LDS stage): keeping them saves the closing wave a
-        // dependent gather from global memory
-        if (take0) { bq[0][0] = sb[8 + k0]; bq[0][1] = sb[16 + k0]; bq[0][2] = sb[24 + k0]; }
-        if (take1) { bq[1][0] = sb[8 + k1]; bq[1][1] = sb[16 + k1]; bq[1][2] = sb[24 + k1]; }
     }
 }
 
@@ -1029,17 +1034,20 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
 
 // DIAG: the phase-stamp instrumentation (ICP_NN_PHASES) is compiled into its own instantiation -- its pointers and
 // branches cost the production kernel scalar registers it does not have to spare
-template <int TAIL, bool DIAG>
+// PERM: the scan copy is a Morton-ordered view with a permutation (compiled apart as well: carrying both forms of the
+// hit processing in one loop body cost the common, identity-order case 16 % on a hit-heavy cloud)
+template <int TAIL, bool DIAG, bool PERM>
 __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __restrict__ P, int n_pad,
                                                               const float* __restrict__ Q, int m_pad, int seg_len,
                                                               int round_passes, float* __restrict__ part_d,
                                                               int32_t* __restrict__ part_idx, RT<float> rt_arg, NNFuse fuse,
                                                               NNTail tail)
 {
+    constexpr int STG = PERM ? 40 : 32;  // floats per staged hit: box 8, x 8, y 8, z 8 (, model indices 8)
     constexpr int HITS_BYTES = SP_HCAP * 4, MD_BYTES = SP_NW * 128 * 4;
     constexpr int TR_BYTES = TAIL ? ((TAIL == 2 ? 28 : 18) * 65 + 64) * 8 : 0;
     static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
-    constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * SP_STAGE * 4;
+    constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * STG * 4;
     constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
     constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x SP_NW x 128
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MQ_OFF + 3 * MD_BYTES];
@@ -1059,7 +1067,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     int pi[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) pi[t] = fuse.p_perm ? fuse.p_perm[ibase + t * 64] : ibase + t * 64;
-    float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * SP_STAGE);  // per wave: 8 hits x {box 8, x 8, y 8, z 8, model index 8}
+    float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * STG);  // per wave: 8 hits x {box 8, x 8, y 8, z 8, model index 8}
     float* msg = reinterpret_cast<float*>(lds_raw + MSG_OFF);
     float (*seedq)[128] = reinterpret_cast<float (*)[128]>(lds_raw + SEED_OFF);
     float (*mq)[SP_NW][128] = reinterpret_cast<float (*)[SP_NW][128]>(lds_raw + MQ_OFF);
@@ -1358,25 +1366,26 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                         const int chl = hits[h];
                         const float* src = part < 2 ? fuse.boxes + (size_t)chl * 8 + part * 4
                                                     : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)chl * 8 + (part & 1) * 4;
-                        *reinterpret_cast<float4*>(stage + r * SP_STAGE + part * 4) = *reinterpret_cast<const float4*>(src);
+                        *reinterpret_cast<float4*>(stage + r * STG + part * 4) = *reinterpret_cast<const float4*>(src);
                     }
                     // a sorted view: the elements' model indices (the sort permutation) are staged too
-                    const int r2 = lane >> 1, half = lane & 1;
-                    const int h2 = hb + r2 * SP_NW + w;
-                    if (fuse.q_perm && lane < 16 && h2 < h1)
-                        *reinterpret_cast<int4*>(stage + r2 * SP_STAGE + 32 + half * 4) =
-                            *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)hits[h2] * 8 + half * 4);
+                    if constexpr (PERM) {
+                        const int r2 = lane >> 1, half = lane & 1;
+                        const int h2 = hb + r2 * SP_NW + w;
+                        if (lane < 16 && h2 < h1)
+                            *reinterpret_cast<int4*>(stage + r2 * STG + 32 + half * 4) =
+                                *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)hits[h2] * 8 + half * 4);
+                    }
                 }
                 lds_same_wave_order();
                 const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
                 const int cnt = mine < 8 ? mine : 8;
-#pragma unroll 1
                 for (int rr = 0; rr < cnt; ++rr) {
-                    if (fuse.q_perm) {
-                        scan_hit<true>(stage + rr * SP_STAGE, 0, px, py, pz, best, bj, bq);
+                    if constexpr (PERM) {
+                        scan_hit<true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
                     } else {
                         const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * SP_NW + w]);
-                        scan_hit<false>(stage + rr * SP_STAGE, ch, px, py, pz, best, bj, bq);
+                        scan_hit<false>(stage + rr * STG, ch, px, py, pz, best, bj, bq);
                     }
                 }
                 lds_same_wave_order();
@@ -2559,9 +2568,12 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             int n_pad = pl.n_pad, m_pad = pl.m_pad, seg = pl.seg_len;
             float* pd = (float*)part_d;
             void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
-            const bool diag = fuse.tlog != nullptr;
-            const void* fn = ta->metric == ICP_POINT_TO_PLANE ? (diag ? (const void*)nn_match_sparse<2, true> : (const void*)nn_match_sparse<2, false>)
-                                                              : (diag ? (const void*)nn_match_sparse<1, true> : (const void*)nn_match_sparse<1, false>);
+            const bool diag = fuse.tlog != nullptr, perm = fuse.q_perm != nullptr;
+            const void* fns[2][2][2] = {{{(const void*)nn_match_sparse<1, false, false>, (const void*)nn_match_sparse<1, false, true>},
+                                         {(const void*)nn_match_sparse<1, true, false>, (const void*)nn_match_sparse<1, true, true>}},
+                                        {{(const void*)nn_match_sparse<2, false, false>, (const void*)nn_match_sparse<2, false, true>},
+                                         {(const void*)nn_match_sparse<2, true, false>, (const void*)nn_match_sparse<2, true, true>}}};
+            const void* fn = fns[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0][diag ? 1 : 0][perm ? 1 : 0];
             // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
             // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
             // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that
@@ -2569,9 +2581,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
             static const int env_coop = env_int("ICP_COOP", 0);
             if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
-            static long long capacity[2] = {-1, -1};   // blocks the machine holds at once, per kernel variant (asked once)
-            static long long capacity_diag[2] = {-1, -1};
-            long long& cap = (diag ? capacity_diag : capacity)[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0];
+            static long long capacity[2][2][2] = {{{-1, -1}, {-1, -1}}, {{-1, -1}, {-1, -1}}};   // blocks the machine holds at once, per variant
+            long long& cap = capacity[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0][diag ? 1 : 0][perm ? 1 : 0];
             if (cap < 0) {
                 int per_cu = 0, dev = 0, cus = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
@@ -2582,16 +2593,19 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             if ((long long)grid.x * grid.y > cap) return hipErrorCooperativeLaunchTooLarge;
             return hipLaunchKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
         }
-#define ICP_LAUNCH_SP(TL)                                                                                          \
-    if (fuse.tlog != nullptr)                                                                                      \
-        hipLaunchKernelGGL((nn_match_sparse<TL, true>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,   \
-                           (const float*)Qsp, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail); \
-    else                                                                                                           \
-        hipLaunchKernelGGL((nn_match_sparse<TL, false>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,  \
+#define ICP_LAUNCH_SP3(TL, DG, PM)                                                                                 \
+    hipLaunchKernelGGL((nn_match_sparse<TL, DG, PM>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,     \
                        (const float*)Qsp, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail)
+#define ICP_LAUNCH_SP(TL)                                                                                          \
+    do {                                                                                                           \
+        const bool dg_ = fuse.tlog != nullptr, pm_ = fuse.q_perm != nullptr;                                       \
+        if (dg_) { if (pm_) ICP_LAUNCH_SP3(TL, true, true); else ICP_LAUNCH_SP3(TL, true, false); }                 \
+        else { if (pm_) ICP_LAUNCH_SP3(TL, false, true); else ICP_LAUNCH_SP3(TL, false, false); }                   \
+    } while (0)
         if (!ta) ICP_LAUNCH_SP(0);
         else if (ta->metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_SP(2);
         else ICP_LAUNCH_SP(1);
+#undef ICP_LAUNCH_SP3
 #undef ICP_LAUNCH_SP
         return hipGetLastError();
     }
