@@ -306,7 +306,7 @@ static int morton_decision(icp_ctx* c, int count, int group, bool* use_sorted, i
     HIP_TRY(hipMemcpyAsync(&h, c->prep_small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (voided_out) *voided_out = h.voided;
-    static const char* force = std::getenv("ICP_SORT");   // ICP_SORT=0 never, =1 always (A/B runs)
+    const char* force = std::getenv("ICP_SORT");   // ICP_SORT=0 never, =1 always (A/B runs, tests)
     if (force && force[0] == '0') *use_sorted = false;
     else if (count <= group) *use_sorted = false;
     else if (force && force[0] == '1') *use_sorted = true;

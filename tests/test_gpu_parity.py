@@ -490,3 +490,23 @@ def test_two_ranks_one_node_local_communicator(pkg, orc, golden):
     assert_same_run(got[0]["it"], np.array(got[0]["err"]), np.array(got[0]["T"]), want, 1e-6, fp32=True)
     if got[0]["it"] == want["iterations"]:
         assert np.array_equal(np.concatenate([got[0]["idx"], got[1]["idx"]]), want["idx"])
+
+
+@pytest.mark.parametrize("force", ["1", "0"])
+def test_morton_views_do_not_change_results(pkg, orc, golden, monkeypatch, force):
+    """ICP_SORT=1 forces the sparse kernel onto Morton-ordered views of both clouds (model: sorted scan copy + permutation,
+    tie rule on model indices; moving: slot permutation), ICP_SORT=0 forbids them: indices stay bit-exact -- on the hall scan
+    (4360 voided duplicates), on the tie-rich synthetic grid, and through a whole registration."""
+    monkeypatch.setenv("ICP_SORT", force)
+    P, Q = orc.hall_clouds(golden)
+    D = pkg.datasets.synthetic_grid(64, np.float32)
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    with pkg.Context(0) as c:
+        assert np.array_equal(c.Matching(P, Q), orc.nn(P, Q))
+        assert np.array_equal(c.Matching(D, M), orc.nn(D, M))
+        assert np.array_equal(c.Matching(D, D[::-1].copy()), orc.nn(D, D[::-1].copy()))     # every distance tied with itself
+        res = c.point_to_point(P, Q, max_iter=100, tol=1e-6)
+    want = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
+    assert_same_run(res.iterations, res.err, res.T, want, 1e-6, fp32=True)
+    if res.iterations == want["iterations"]:
+        assert np.array_equal(res.idx, want["idx"])
