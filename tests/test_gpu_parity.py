@@ -510,3 +510,22 @@ def test_morton_views_do_not_change_results(pkg, orc, golden, monkeypatch, force
     assert_same_run(res.iterations, res.err, res.T, want, 1e-6, fp32=True)
     if res.iterations == want["iterations"]:
         assert np.array_equal(res.idx, want["idx"])
+
+
+@pytest.mark.parametrize("n,m", [(16, 16), (9, 30), (200, 9), (1025, 17), (130, 4097)])
+def test_resident_loop_small_and_ragged_clouds(ctx, pkg, orc, n, m):
+    """the resident registration kernel on clouds far smaller than a block row / a find pass, ragged against every
+    padding granule (blocks of pure padding, a model of two chunks): same run as the oracle"""
+    rng = np.random.default_rng(n * 1000 + m)
+    M = rng.standard_normal((m, 3)).astype(np.float32)
+    pick = rng.integers(0, m, size=n)
+    ang = np.array([0.05, -0.03, 0.04])
+    cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+    R = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @
+         np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    D = ((M[pick].astype(np.float64) - np.array([0.02, -0.01, 0.03])) @ R).astype(np.float32) + (1e-3 * rng.standard_normal((n, 3))).astype(np.float32)
+    res = ctx.point_to_point(D, M, max_iter=12, tol=1e-9)
+    want = orc.icp_p2p_f32x(D, M, 12, 1e-9)
+    assert_same_run(res.iterations, res.err, res.T, want, 1e-9, fp32=True)
+    if res.iterations == want["iterations"]:
+        assert np.array_equal(res.idx, want["idx"])
