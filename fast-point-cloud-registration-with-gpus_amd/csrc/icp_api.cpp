@@ -164,6 +164,7 @@ struct icp_ctx {
     // ICP_TRACE=1: host-side time split of the loop, printed by icp_destroy
     bool trace = false;
     double tr_first_row = 0.0, tr_last_row = 0.0;
+    std::chrono::steady_clock::time_point tr_rows_done{};
     bool trace_passes = false;         // ICP_TRACE=2: one line per pass of a resident registration
     double tr_enqueue = 0, tr_wait = 0, tr_reduce = 0, tr_solve = 0;
     uint64_t tr_n = 0;
@@ -1020,7 +1021,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
                     break;  // something is wrong (fault, hang): let the runtime report it
             }
             polled = b == L.mom_blocks;
-            if (c->trace_passes) c->tr_last_row = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (c->trace_passes) { c->tr_last_row = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); c->tr_rows_done = std::chrono::steady_clock::now(); }
             if (!polled && c->trace) {
                 std::fprintf(stderr, "[icp trace]   poll gave up at row %d; rows still missing:", b);
                 int shown = 0;
@@ -1259,6 +1260,9 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
             ++matched;
         }
         send(cmd, base + (double)sent);
+        if (c->trace_passes && sent > 0)
+            std::fprintf(stderr, "[icp trace]   host turnaround (last row seen -> next message out): %.2f us\n",
+                         1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - c->tr_rows_done).count());
         L.mom_blocks = rp.blocks_x;
         L.err_blocks = 0;
         L.rows_have_err = true;

@@ -1,0 +1,16 @@
+import os, sys, time, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+pkg = load_package()
+g = os.path.join(ROOT, "tests", "golden")
+with pkg.Context(0) as ctx:
+    B = np.fromfile(os.path.join(g, "bunny_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
+    BM = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
+    ctx.set_model(BM); ctx.set_moving(B)
+    def run():
+        ctx.reset_moving(); ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=100, tol=1e-6)
+        k, d = ctx.loop_run(1 << 20); return k
+    run()
+    t0 = time.perf_counter(); ks = [run() for _ in range(20)]; dt = time.perf_counter() - t0
+    print(f"bunny: {sum(ks)} iterations in 20 registrations: {1e6*dt/sum(ks):.2f} us/iteration")
