@@ -251,7 +251,7 @@ def main():
                                       ("1 RCCL all-reduce of 32 doubles per iteration, issued by "
                                        + ("libicp_mi355x on the loop's stream" if native_comm else "torch.distributed"))) if use_dist else "none"},
             "roofline": {
-                "kernel": ("nn_match_sparse<1>, resident: ONE cooperative launch per REGISTRATION (%.2f matching passes on average); every "
+                "kernel": ("nn_match_sparse<1>, resident: ONE launch per REGISTRATION, every block on the machine (%.2f matching passes on average); every "
                            "pass = mailbox message from the host (command, R, t) -> [transform + error of the previous pass] -> "
                            "lane-parallel chunk-box search -> hit processing (packed fp32, exact arithmetic) -> LDS key merge -> moment row "
                            "to the host.  The duration INCLUDES the host round trips between the passes (the kernel waits for every solve)."
