@@ -263,23 +263,6 @@ __device__ __forceinline__ f2 pk_dist2(f2 qx, f2 qy, f2 qz, f2 px, f2 py, f2 pz)
     return d + dz;
 }
 
-// the same with the model pair held in SGPRs (wave-uniform chunk fetched through the scalar cache)
-template <int HI>
-__device__ __forceinline__ f2 pk_sub_bcast_s(f2 q, f2 p)
-{
-    f2 r;
-    if constexpr (HI == 0)
-        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(q), "v"(p));
-    else
-        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(q), "v"(p));
-    return r;
-}
-template <int HI, bool QS>
-__device__ __forceinline__ f2 pk_sub_q(f2 q, f2 p)
-{
-    if constexpr (QS) return pk_sub_bcast_s<HI>(q, p); else return pk_sub_bcast<HI>(q, p);
-}
-
 // One wave passing data to itself through LDS: DS instructions of a wave execute in order, so all that is needed is
 // that the COMPILER keeps the order (and does not cache the values in registers).  A workgroup-scope fence would also
 // drain the wave's global stores (s_waitcnt vmcnt(0)) -- ~1 us of idle time in the matching kernel's tail.
@@ -337,8 +320,8 @@ constexpr int NN2_TQW = 256;  // model points per wave per LDS tile step
 // phase A forms pxy = dx*dx + dy*dy (the inner sum of the reference's association) for the whole chunk;
 // d = fl(pxy + dz*dz) >= pxy, so a chunk whose smallest pxy is not below any lane's running minimum cannot
 // lower it (nor win a tie: ascending order, strict <) and its z half is skipped; phase B finishes the chunk
-// exactly as the un-culled kernel would have.  QS: the chunk address is wave-uniform and q travels in SGPRs.
-template <int TP, int C, bool QS>
+// exactly as the un-culled kernel would have.
+template <int TP, int C>
 __device__ __forceinline__ void scan_chunk_xy_cull(const float* qxp, const float* qyp, const float* qzp, const f2 (&px)[TP],
                                                    const f2 (&py)[TP], const f2 (&pz)[TP], float (&best)[2 * TP])
 {
@@ -355,13 +338,13 @@ __device__ __forceinline__ void scan_chunk_xy_cull(const float* qxp, const float
 #pragma unroll
         for (int u = 0; u < TP; ++u) {
             f2 ax, ay;
-            ax = pk_sub_q<0, QS>(qxa, px[u]); ay = pk_sub_q<0, QS>(qya, py[u]);
+            ax = pk_sub_bcast<0>(qxa, px[u]); ay = pk_sub_bcast<0>(qya, py[u]);
             pxy[u][kk + 0] = ax * ax + ay * ay;
-            ax = pk_sub_q<1, QS>(qxa, px[u]); ay = pk_sub_q<1, QS>(qya, py[u]);
+            ax = pk_sub_bcast<1>(qxa, px[u]); ay = pk_sub_bcast<1>(qya, py[u]);
             pxy[u][kk + 1] = ax * ax + ay * ay;
-            ax = pk_sub_q<0, QS>(qxb, px[u]); ay = pk_sub_q<0, QS>(qyb, py[u]);
+            ax = pk_sub_bcast<0>(qxb, px[u]); ay = pk_sub_bcast<0>(qyb, py[u]);
             pxy[u][kk + 2] = ax * ax + ay * ay;
-            ax = pk_sub_q<1, QS>(qxb, px[u]); ay = pk_sub_q<1, QS>(qyb, py[u]);
+            ax = pk_sub_bcast<1>(qxb, px[u]); ay = pk_sub_bcast<1>(qyb, py[u]);
             pxy[u][kk + 3] = ax * ax + ay * ay;
             mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk].x), pxy[u][kk + 1].x);
             mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk + 2].x), pxy[u][kk + 3].x);
@@ -380,10 +363,10 @@ __device__ __forceinline__ void scan_chunk_xy_cull(const float* qxp, const float
 #pragma unroll
         for (int u = 0; u < TP; ++u) {
             f2 az;
-            az = pk_sub_q<0, QS>(qza, pz[u]); const f2 d0 = pxy[u][kk + 0] + az * az;
-            az = pk_sub_q<1, QS>(qza, pz[u]); const f2 d1 = pxy[u][kk + 1] + az * az;
-            az = pk_sub_q<0, QS>(qzb, pz[u]); const f2 d2 = pxy[u][kk + 2] + az * az;
-            az = pk_sub_q<1, QS>(qzb, pz[u]); const f2 d3 = pxy[u][kk + 3] + az * az;
+            az = pk_sub_bcast<0>(qza, pz[u]); const f2 d0 = pxy[u][kk + 0] + az * az;
+            az = pk_sub_bcast<1>(qza, pz[u]); const f2 d1 = pxy[u][kk + 1] + az * az;
+            az = pk_sub_bcast<0>(qzb, pz[u]); const f2 d2 = pxy[u][kk + 2] + az * az;
+            az = pk_sub_bcast<1>(qzb, pz[u]); const f2 d3 = pxy[u][kk + 3] + az * az;
             best[2 * u] = fmin_(fmin_(best[2 * u], d0.x), d1.x);
             best[2 * u] = fmin_(fmin_(best[2 * u], d2.x), d3.x);
             best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d0.y), d1.y);
@@ -627,7 +610,7 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
                     if (__builtin_amdgcn_ballot_w64(box_may_improve<TP>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], px, py, pz, best)) == 0ull)
                         continue;
                 }
-                scan_chunk_xy_cull<TP, C, false>(&sq[w][0][c], &sq[w][1][c], &sq[w][2][c], px, py, pz, best);
+                scan_chunk_xy_cull<TP, C>(&sq[w][0][c], &sq[w][1][c], &sq[w][2][c], px, py, pz, best);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < C; kk += 4) {
@@ -914,8 +897,7 @@ __device__ __forceinline__ void scan_hit(const float* sb, int ch, const f2 px, c
     }
 }
 
-// distances from the lane's packed pair to 8 model points (QS: held in SGPRs), folded into running minima (no index)
-template <bool QS>
+// distances from the lane's packed pair to 8 model points, folded into running minima (no index)
 __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, const float4 qy0, const float4 qy1,
                                           const float4 qz0, const float4 qz1, const f2 px, const f2 py, const f2 pz,
                                           float (&best)[2])
@@ -926,13 +908,13 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
 #pragma unroll
     for (int k = 0; k < 4; k += 2) {
         f2 ax, ay, az;
-        ax = pk_sub_q<0, QS>(qx[k], px); ay = pk_sub_q<0, QS>(qy[k], py); az = pk_sub_q<0, QS>(qz[k], pz);
+        ax = pk_sub_bcast<0>(qx[k], px); ay = pk_sub_bcast<0>(qy[k], py); az = pk_sub_bcast<0>(qz[k], pz);
         const f2 d0 = (ax * ax + ay * ay) + az * az;
-        ax = pk_sub_q<1, QS>(qx[k], px); ay = pk_sub_q<1, QS>(qy[k], py); az = pk_sub_q<1, QS>(qz[k], pz);
+        ax = pk_sub_bcast<1>(qx[k], px); ay = pk_sub_bcast<1>(qy[k], py); az = pk_sub_bcast<1>(qz[k], pz);
         const f2 d1 = (ax * ax + ay * ay) + az * az;
-        ax = pk_sub_q<0, QS>(qx[k + 1], px); ay = pk_sub_q<0, QS>(qy[k + 1], py); az = pk_sub_q<0, QS>(qz[k + 1], pz);
+        ax = pk_sub_bcast<0>(qx[k + 1], px); ay = pk_sub_bcast<0>(qy[k + 1], py); az = pk_sub_bcast<0>(qz[k + 1], pz);
         const f2 d2 = (ax * ax + ay * ay) + az * az;
-        ax = pk_sub_q<1, QS>(qx[k + 1], px); ay = pk_sub_q<1, QS>(qy[k + 1], py); az = pk_sub_q<1, QS>(qz[k + 1], pz);
+        ax = pk_sub_bcast<1>(qx[k + 1], px); ay = pk_sub_bcast<1>(qy[k + 1], py); az = pk_sub_bcast<1>(qz[k + 1], pz);
         const f2 d3 = (ax * ax + ay * ay) + az * az;
         best[0] = fmin_(fmin_(best[0], d0.x), d1.x);
         best[0] = fmin_(fmin_(best[0], d2.x), d3.x);
@@ -1296,7 +1278,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             const float4* a = reinterpret_cast<const float4*>(sl + gp * 8);
             const float4* b = reinterpret_cast<const float4*>(sl + SMAX + gp * 8);
             const float4* c = reinterpret_cast<const float4*>(sl + 2 * SMAX + gp * 8);
-            scan8_min<false>(a[0], a[1], b[0], b[1], c[0], c[1], px, py, pz, sb);
+            scan8_min(a[0], a[1], b[0], b[1], c[0], c[1], px, py, pz, sb);
         }
         if (real[0]) atomicMin(&smin[lane], __float_as_uint(sb[0]));
         if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(sb[1]));
