@@ -173,7 +173,7 @@ struct icp_ctx {
     bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
     bool arm = true;                   // ICP_ARMED=0: icp_loop_run never enqueues a pass ahead of its (R, t)
     bool resident = true;              // ICP_RESIDENT=0: icp_loop_run never keeps one kernel for a whole registration
-    bool resident_refused = false;     // the cooperative launch did not fit this plan: do not try again
+    bool resident_refused = false;     // the resident kernel does not fit the machine with this plan: do not try again
     // ring of mailboxes for armed / resident launches, in pinned mapped host memory, and the device-memory relay.
     // (Fine-grained device memory written through the PCIe BAR is ~0.5 us faster per message and needs no relay --
     // tools/mailbox_probe.hip -- but with the HIP runtime that PyTorch bundles the waiting kernel never sees a
@@ -1174,7 +1174,7 @@ void loop_withdraw_armed(icp_ctx* c)
 }  // namespace
 
 // ---- resident registration ---------------------------------------------------------------------------
-// One cooperative launch carries the whole loop: the blocks keep their points in registers and their seeds in
+// One launch (every block resident) carries the whole loop: the blocks keep their points in registers and their seeds in
 // LDS, every pass is one mailbox message (command + R, t) and one set of rows coming back.  No launch, no
 // dispatch and no kernel boundary between two passes; what is left of an iteration is the pass itself plus one
 // host <-> device round trip (~2 us, tools/mailbox_probe.hip).  The host side is the step-wise loop unchanged:
@@ -1226,7 +1226,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     const hipError_t le = icp::launch_nn(rp, P_in, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream);
     if (le != hipSuccess) {
         (void)hipGetLastError();
-        c->resident_refused = true;   // does not fit the machine (or cooperative launches are unavailable)
+        c->resident_refused = true;   // does not fit the machine
         *fell_back = true;
         return ICP_OK;
     }
