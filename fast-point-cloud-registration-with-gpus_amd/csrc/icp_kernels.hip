@@ -934,21 +934,24 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
 {
     constexpr int w = 0, phase_nw_ = SP_NW;  // (phase log) the closing wave of a sparse-kernel block
     constexpr int NACC = TAIL == 2 ? 28 : 18;
-    double acc[NACC];
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    // one wave: the lanes' contributions are transposed through LDS (rows padded to 65 doubles), slot k is then added
+    // up in lane order
+    double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
     const float* Qg = fuse.Q_gather;
+    if constexpr (TAIL == 1) {
+        double acc[NACC];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int i = fresh(pi[t]);
-        if (i < fuse.n) {
-            const int jj = j[t];
-            tail.idx_out[i] = jj;
-            const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
-            if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
-            const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
-            acc[0] += 1.0;
-            if constexpr (TAIL == 1) {
+        for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = fresh(pi[t]);
+            if (i < fuse.n) {
+                const int jj = j[t];
+                tail.idx_out[i] = jj;
+                const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
+                if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
+                const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
+                acc[0] += 1.0;
                 acc[1] += ppx; acc[2] += ppy; acc[3] += ppz;
                 acc[4] += qx; acc[5] += qy; acc[6] += qz;
                 acc[7] += qx * ppx; acc[8] += qx * ppy; acc[9] += qx * ppz;
@@ -956,30 +959,47 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
                 acc[13] += qz * ppx; acc[14] += qz * ppy; acc[15] += qz * ppz;
                 acc[16] += ppx * ppx + ppy * ppy + ppz * ppz;
                 acc[17] += qx * qx + qy * qy + qz * qz;
-            } else {
+            }
+        }
+        ICP_PHASE(7)
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
+    } else {
+        // point-to-plane: 28 sums.  The second point's terms are added to the first one's in LDS rather than in 28
+        // register pairs (the sums are the same, 0 + x0 + x1; the kernel no longer spills)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = fresh(pi[t]);
+            const bool live = i < fuse.n;
+            double cn[6] = {0, 0, 0, 0, 0, 0}, bb = 0.0;
+            if (live) {
+                const int jj = j[t];
+                tail.idx_out[i] = jj;
+                const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
+                if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
+                const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
                 const double nx = (double)tail.Nrm[jj], ny = (double)tail.Nrm[(size_t)m_pad + jj],
                              nz = (double)tail.Nrm[2 * (size_t)m_pad + jj];
-                double cn[6];
                 cn[0] = ppy * nz - ppz * ny;
                 cn[1] = ppz * nx - ppx * nz;
                 cn[2] = ppx * ny - ppy * nx;
                 cn[3] = nx; cn[4] = ny; cn[5] = nz;
-                const double bb = (ppx - qx) * nx + (ppy - qy) * ny + (ppz - qz) * nz;
-                int o = 1;
-#pragma unroll
-                for (int a = 0; a < 6; ++a)
-#pragma unroll
-                    for (int c2 = a; c2 < 6; ++c2) acc[o++] += cn[a] * cn[c2];
-#pragma unroll
-                for (int a = 0; a < 6; ++a) acc[22 + a] -= cn[a] * bb;
+                bb = (ppx - qx) * nx + (ppy - qy) * ny + (ppz - qz) * nz;
             }
-        }
-    }
-    ICP_PHASE(7)
-    // one wave: transpose through LDS (rows padded to 65 doubles), lane k adds slot k in lane order
-    double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
+            auto put = [&](int k, double v) {
+                if (t == 0) tr[k][lane] = 0.0 + v; else tr[k][lane] = tr[k][lane] + v;
+            };
+            put(0, live ? 1.0 : 0.0);
+            int o = 1;
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c2 = a; c2 < 6; ++c2) put(o++, cn[a] * cn[c2]);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) put(22 + a, -(cn[a] * bb));
+        }
+        ICP_PHASE(7)
+    }
     lds_same_wave_order();
     double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
     // Slot k is the sum of its 64 lane entries in a FIXED order: PARTS lanes per slot add a contiguous share each
@@ -989,12 +1009,16 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
     {
         const int slot = lane % NACC, part = lane / NACC;
         if (part < PARTS) {
-            double v[PER];   // all loads first, then the adds: one LDS latency instead of PER
-#pragma unroll
-            for (int l = 0; l < PER; ++l) v[l] = (part * PER + l < 64) ? tr[slot][part * PER + l] : 0.0;
+            constexpr int CH = PER > 22 ? 16 : PER;   // loads in flight: all of a share, or 16 at a time for the long ones
             double sum = 0.0;
 #pragma unroll
-            for (int l = 0; l < PER; ++l) sum += v[l];
+            for (int l0 = 0; l0 < PER; l0 += CH) {
+                double v[CH];   // loads first, then the adds: one LDS latency per CH entries instead of one per entry
+#pragma unroll
+                for (int l = 0; l < CH; ++l) v[l] = (l0 + l < PER && part * PER + l0 + l < 64) ? tr[slot][part * PER + l0 + l] : 0.0;
+#pragma unroll
+                for (int l = 0; l < CH; ++l) sum += v[l];
+            }
             tp[part * NACC + slot] = sum;
         }
     }
