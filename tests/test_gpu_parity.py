@@ -529,3 +529,59 @@ def test_resident_loop_small_and_ragged_clouds(ctx, pkg, orc, n, m):
     assert_same_run(res.iterations, res.err, res.T, want, 1e-9, fp32=True)
     if res.iterations == want["iterations"]:
         assert np.array_equal(res.idx, want["idx"])
+
+
+def _fuzz_cloud(rng, n, kind, scale):
+    if kind == "uniform":
+        X = rng.uniform(-1, 1, (n, 3))
+    elif kind == "clustered":          # a few tight clusters with exact duplicates sprinkled in
+        c = rng.uniform(-1, 1, (6, 3))
+        X = c[rng.integers(0, 6, n)] + 0.01 * rng.standard_normal((n, 3))
+        d = rng.integers(0, n, max(1, n // 10))
+        X[d] = X[rng.integers(0, n, d.size)]
+    elif kind == "lattice":            # integer lattice: exact ties everywhere
+        X = rng.integers(-3, 4, (n, 3)).astype(np.float64)
+    else:                              # "line": degenerate extent in two axes
+        X = np.zeros((n, 3))
+        X[:, 0] = rng.uniform(-1, 1, n)
+    return (scale * X).astype(np.float32)
+
+
+@pytest.mark.parametrize("sort", ["0", "1"])
+def test_matching_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort):
+    """randomised clouds (uniform / clustered with duplicates / integer lattice / collinear, three scales, ragged sizes)
+    through the sparse kernel with its Morton views forbidden and forced: indices bit-exact against the CPU oracle"""
+    monkeypatch.setenv("ICP_SORT", sort)
+    rng = np.random.default_rng(20260210 + int(sort))
+    with pkg.Context(0) as c:
+        for case in range(40):
+            n, m = int(rng.integers(1, 700)), int(rng.integers(1, 900))
+            kp, km = rng.choice(["uniform", "clustered", "lattice", "line"], 2)
+            scale = float(rng.choice([1e-3, 1.0, 1e3]))
+            P, Q = _fuzz_cloud(rng, n, kp, scale), _fuzz_cloud(rng, m, km, scale)
+            got, want = c.Matching(P, Q), orc.nn(P, Q)
+            assert np.array_equal(got, want), (case, n, m, kp, km, scale, int(np.flatnonzero(got != want)[0]))
+
+
+@pytest.mark.parametrize("sort", ["0", "1"])
+def test_registration_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort):
+    """randomised registrations (seeded passes, resident kernel, clustered / lattice models with duplicates and ties):
+    error series, transform and final correspondences against the oracle's run"""
+    monkeypatch.setenv("ICP_SORT", sort)
+    rng = np.random.default_rng(7300 + int(sort))
+    with pkg.Context(0) as c:
+        for case in range(8):
+            m = int(rng.integers(300, 2500))
+            n = int(rng.integers(200, 2500))
+            M = _fuzz_cloud(rng, m, str(rng.choice(["uniform", "clustered", "lattice"])), 1.0)
+            a = rng.uniform(-0.05, 0.05, 3)
+            Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
+            Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+            Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
+            D = ((M[rng.integers(0, m, n)].astype(np.float64) + rng.uniform(-0.02, 0.02, 3)) @ (Rz @ Ry @ Rx)).astype(np.float32)
+            D += (2e-3 * rng.standard_normal((n, 3))).astype(np.float32)
+            res = c.point_to_point(D, M, max_iter=15, tol=1e-7)
+            want = orc.icp_p2p_f32x(D, M, 15, 1e-7)
+            assert_same_run(res.iterations, res.err, res.T, want, 1e-7, fp32=True)
+            if res.iterations == want["iterations"]:
+                assert np.array_equal(res.idx, want["idx"]), case
