@@ -1288,7 +1288,13 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     if (alive) send(icp::ICP_CMD_EXIT, -(base + (double)sent));
     if (time_this && rc == ICP_OK) {
         float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(c->ev1));
+        // the kernel ends within microseconds of the exit message: spin on the event instead of a blocking wait
+        // (whose wake-up alone costs tens of microseconds of the loop being measured)
+        const auto tq = std::chrono::steady_clock::now();
+        hipError_t qe = hipErrorNotReady;
+        while ((qe = hipEventQuery(c->ev1)) == hipErrorNotReady)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tq).count() > 5.0) break;
+        if (qe != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipEventSynchronize(c->ev1)); }
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         L.seconds_nn += 1e-3 * ms;
         L.nn_launches += 1;
