@@ -132,7 +132,7 @@ struct icp_ctx {
     bool model_sorted = false, moving_sorted = false;
     // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
     DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
-    struct PrepSmall { float box[4]; double totals[2]; int voided; int pad_; };
+    struct PrepSmall { float box[4]; double totals[4]; int voided; int pad_; };
     DevBuf phase_log;        // ICP_NN_PHASES diagnostic
     std::string phase_path;
     DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
@@ -301,7 +301,7 @@ static int prep_buffers(icp_ctx* c, int count, icp::PrepBuffers& b)
 // already has locality must keep its order even if Morton cells are tighter: the hall scan's model chunks are 2.1x
 // tighter in Morton order, yet matching gets 20 % slower -- its 8-point half columns line up with the moving groups
 // (8 columns), compact Morton cells do not; the Bunny vertex list is 10x / 5.8x looser than Morton order.
-static int morton_decision(icp_ctx* c, int count, int group, bool* use_sorted, int* voided_out)
+static int morton_decision(icp_ctx* c, int count, int group, int group2, bool* use_sorted, int* voided_out)
 {
     icp_ctx::PrepSmall h{};
     HIP_TRY(hipMemcpyAsync(&h, c->prep_small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -311,10 +311,17 @@ static int morton_decision(icp_ctx* c, int count, int group, bool* use_sorted, i
     if (force && force[0] == '0') *use_sorted = false;
     else if (count <= group) *use_sorted = false;
     else if (force && force[0] == '1') *use_sorted = true;
-    else *use_sorted = 3.0 * h.totals[1] < h.totals[0];
-    if (c->trace)
-        std::fprintf(stderr, "[icp trace] %d points, groups of %d: extent %.4g in the given order, %.4g in Morton order -> %s; %d exact duplicates voided\n",
-                     count, group, h.totals[0], h.totals[1], *use_sorted ? "Morton view" : "own order", h.voided);
+    else {
+        *use_sorted = 3.0 * h.totals[1] < h.totals[0];
+        // a model searched through the box hierarchy: the order also has to serve the level above the chunks (a
+        // row-major grid has tight 8-point chunks but 512-point boxes one row thin and a fifth of the cloud long)
+        if (group2 > 0 && 3.0 * h.totals[3] < h.totals[2] && h.totals[1] <= h.totals[0]) *use_sorted = true;
+    }
+    if (c->trace) {
+        std::fprintf(stderr, "[icp trace] %d points, groups of %d: extent %.4g in the given order, %.4g in Morton order", count, group, h.totals[0], h.totals[1]);
+        if (group2 > 0) std::fprintf(stderr, "; groups of %d: %.4g, %.4g", group2, h.totals[2], h.totals[3]);
+        std::fprintf(stderr, " -> %s; %d exact duplicates voided\n", *use_sorted ? "Morton view" : "own order", h.voided);
+    }
     return ICP_OK;
 }
 
@@ -613,8 +620,9 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         HIP_TRY(c->Qs.ensure(3 * (size_t)m_pad * sizeof(float)));
         HIP_TRY(icp::launch_duplicates_and_scan_copy(pb, (const float*)c->Q.p, m, m_pad, (unsigned char*)c->prep_voided.p, &small->voided,
                                                      (float*)c->Qs.p, c->stream));
-        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->Q.p, m, m_pad, 8, (int32_t*)c->prep_perm.p, small->totals, c->stream));
-        if (int rc = morton_decision(c, m, 8, &c->model_sorted, &c->voided)) return rc;
+        const int group2 = icp::nn_plan(128, m, precision, c->num_cus).hier ? 512 : 0;   // (the model's size decides the search form)
+        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->Q.p, m, m_pad, 8, group2, (int32_t*)c->prep_perm.p, small->totals, c->stream));
+        if (int rc = morton_decision(c, m, 8, group2, &c->model_sorted, &c->voided)) return rc;
         // the sparse kernel's view: the same voided copy, in Morton order if the model's own order has no locality
         const void* view = c->Qs.p;
         if (c->model_sorted) {
@@ -625,7 +633,7 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
             view = c->Qss.p;
         }
         // bounding boxes of its 8-point chunks (the first, cheapest level of the early-out) and one point per chunk
-        HIP_TRY(c->Qbox.ensure((size_t)((m_pad + 7) / 8) * 8 * sizeof(float)));
+        HIP_TRY(c->Qbox.ensure(icp::model_boxes_bytes(m_pad)));
         HIP_TRY(icp::launch_model_boxes(view, m_pad, (float*)c->Qbox.p, c->stream));
         HIP_TRY(c->Qsamp.ensure(icp::model_samples_bytes(m_pad)));
         HIP_TRY(icp::launch_model_samples(view, m_pad, (float*)c->Qsamp.p, c->stream));
@@ -658,8 +666,8 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
         icp::PrepBuffers pb{};
         if (int rc = prep_buffers(c, n, pb)) return rc;
         icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
-        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->P.p, n, n_pad, 128, (int32_t*)c->prep_perm.p, small->totals, c->stream));
-        if (int rc = morton_decision(c, n, 128, &c->moving_sorted, nullptr)) return rc;
+        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->P.p, n, n_pad, 128, 0, (int32_t*)c->prep_perm.p, small->totals, c->stream));
+        if (int rc = morton_decision(c, n, 128, 0, &c->moving_sorted, nullptr)) return rc;
         if (c->moving_sorted) {
             HIP_TRY(c->Pperm.ensure((size_t)n_pad * sizeof(int32_t)));
             HIP_TRY(icp::launch_slot_map((const int32_t*)c->prep_perm.p, n, n_pad, (int32_t*)c->Pperm.p, c->stream));

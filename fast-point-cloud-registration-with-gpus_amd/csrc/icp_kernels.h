@@ -28,6 +28,7 @@ struct NNPlan {
     int chunk;          // index-tracking chunk of the launched kernel
     int cull;           // the packed kernel may use the seeded-bound / xy early-out variant
     int sparse;         // the geometry is the sparse kernel's (16-wave blocks of 128 moving points; needs chunk boxes)
+    int hier;           // sparse kernel: two-level search (boxes of 64 chunks first) -- large models
 };
 int nn_block_threads(const NNPlan& pl);
 
@@ -96,8 +97,9 @@ struct PrepBuffers {
 size_t prep_sort_temp_bytes(int count);
 hipError_t launch_duplicates_and_scan_copy(const PrepBuffers& b, const float* X_soa, int n, int n_pad, unsigned char* voided, int* count_dev,
                                            float* scan_out_soa, hipStream_t st);
-hipError_t launch_morton_order(const PrepBuffers& b, const float* X_soa, int n, int n_pad, int group, int32_t* perm_out, double* totals_dev,
-                               hipStream_t st);
+// totals_dev: 4 doubles -- summed extents of the groups in the given / the Morton order, for `group` and (if > 0) `group2`
+hipError_t launch_morton_order(const PrepBuffers& b, const float* X_soa, int n, int n_pad, int group, int group2, int32_t* perm_out,
+                               double* totals_dev, hipStream_t st);
 hipError_t launch_gather_sorted(const float* Qs_soa, int m, int m_pad, const int32_t* perm, float* out_soa, int32_t* perm_pad, hipStream_t st);
 hipError_t launch_slot_map(const int32_t* perm, int n, int n_pad, int32_t* out, hipStream_t st);
 size_t model_samples_bytes(int m_pad);
@@ -105,6 +107,9 @@ hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, h
 // diagnostic: per-wave phase stamps (s_memrealtime, 100 MHz) of the packed matching kernel, 10 slots per wave indexed
 // ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 10 + phase; NULL switches it off (the default)
 void set_phase_log(long long* dev, long long slots);
+// boxes: model_boxes_bytes(m_pad) -- the chunk boxes, followed by the boxes of every 64 of them and of every 64 of
+// those (the upper search levels of a large model)
+size_t model_boxes_bytes(int m_pad);
 hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st);
 
 // fused tail of the packed kernel: atomic (d, idx) keys + row tickets, the row's last block produces idx and the

@@ -1042,7 +1042,10 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
 // branches cost the production kernel scalar registers it does not have to spare
 // PERM: the scan copy is a Morton-ordered view with a permutation (compiled apart as well: carrying both forms of the
 // hit processing in one loop body cost the common, identity-order case 16 % on a hit-heavy cloud)
-template <int TAIL, bool DIAG, bool PERM>
+// HIER: two-level search (large models): boxes of 64 chunks are tested first, lane-parallel like the chunks, and only
+// the chunks of the surviving ones after them -- compiled apart for the same reason (the extra level costs a small
+// model more than it saves)
+template <int TAIL, bool DIAG, bool PERM, bool HIER = false>
 __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __restrict__ P, int n_pad,
                                                               const float* __restrict__ Q, int m_pad, int seg_len,
                                                               int round_passes, float* __restrict__ part_d,
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * STG * 4;
     constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
     constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x SP_NW x 128
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MQ_OFF + 3 * MD_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MQ_OFF + 3 * MD_BYTES + (HIER ? SP_NW * 64 * 4 : 0)];  // (+ the level-3 hit list)
     int* hits = reinterpret_cast<int*>(lds_raw);
     // merge scratch: one (distance, index, wave) key per moving point, folded with LDS atomic mins -- the 64-bit
     // integer order is the lexicographic order the tie rule needs (d >= 0; index < 2^28; the wave id rides in the
@@ -1123,10 +1126,20 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     float4 pb[PRE][2];
 #pragma unroll
     for (int r = 0; r < PRE; ++r) {
-        const int cidx = c_lo + (r * SP_NW + w) * 64 + lane;
-        const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cidx < c_hi ? cidx : 0) * 8);
-        pb[r][0] = bp[0];
-        pb[r][1] = bp[1];
+        if constexpr (HIER) {
+            // (the upper levels follow the chunk boxes in the same array; the search starts at level 3: one pass per wave)
+            const int n2_all = ((m_pad >> 3) + 63) >> 6;
+            const int t_lo = c_lo >> 12, t_hi = ((((c_hi + 63) >> 6)) + 63) >> 6;
+            const int tidx = t_lo + w * 64 + lane;
+            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)m_pad + ((size_t)n2_all + (size_t)(tidx < t_hi ? tidx : t_lo)) * 8);
+            pb[r][0] = bp[0];
+            pb[r][1] = bp[1];
+        } else {
+            const int cidx = c_lo + (r * SP_NW + w) * 64 + lane;
+            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cidx < c_hi ? cidx : 0) * 8);
+            pb[r][0] = bp[0];
+            pb[r][1] = bp[1];
+        }
     }
     for (int pass = 0;; ++pass) {
     phase_pass_ = pass;
@@ -1139,7 +1152,10 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         smin[lane] = 0x7f800000u; smin[lane + 64] = 0x7f800000u;
         mkey[lane] = ~0ull; mkey[lane + 64] = ~0ull;
     }
-    if (threadIdx.x == 0) *hcount = 0;
+    if (threadIdx.x == 0) {
+        *hcount = 0;
+        if constexpr (HIER) { hcount[1] = 0; hcount[2] = 0; }
+    }
     if (fuse.mailbox != nullptr) {
         const double want = fuse.want + (double)pass;
         if (w == 0) {
@@ -1338,6 +1354,168 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             if (pass) hits[base + rank] = cidx;
         }
     };
+    // The hits are dealt round-robin; a wave fetches the box and the coordinates of up to 8 of its hits with ONE
+    // gather -- 8 lanes x 16 bytes per hit -- into its private LDS stage, so a batch of hits costs one trip to
+    // memory instead of three or four each.
+    // (exchanging minima between the batches of a cold pass was measured too: the barriers cost more than they save)
+    auto process_hits = [&](const int h1) {
+        for (int hb = 0; hb < h1; hb += SP_NW * 8) {
+            {
+                const int r = lane >> 3, part = lane & 7;
+                const int h = hb + r * SP_NW + w;
+                if (h < h1) {
+                    const int chl = hits[h];
+                    const float* src = part < 2 ? fuse.boxes + (size_t)chl * 8 + part * 4
+                                                : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)chl * 8 + (part & 1) * 4;
+                    *reinterpret_cast<float4*>(stage + r * STG + part * 4) = *reinterpret_cast<const float4*>(src);
+                }
+                // a sorted view: the elements' model indices (the sort permutation) are staged too
+                if constexpr (PERM) {
+                    const int r2 = lane >> 1, half = lane & 1;
+                    const int h2 = hb + r2 * SP_NW + w;
+                    if (lane < 16 && h2 < h1)
+                        *reinterpret_cast<int4*>(stage + r2 * STG + 32 + half * 4) =
+                            *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)hits[h2] * 8 + half * 4);
+                }
+            }
+            lds_same_wave_order();
+            const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
+            const int cnt = mine < 8 ? mine : 8;
+            for (int rr = 0; rr < cnt; ++rr) {
+                if constexpr (PERM) {
+                    scan_hit<true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
+                } else {
+                    const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * SP_NW + w]);
+                    scan_hit<false>(stage + rr * STG, ch, px, py, pz, best, bj, bq);
+                }
+            }
+            lds_same_wave_order();
+        }
+    };
+    // exchange before the next round: every wave goes on from the block's best minimum so far, bumped by
+    // an ulp (d >= 0: the bit patterns order like the values, so this is an integer min)
+    auto exchange = [&]() {
+        if (real[0]) atomicMin(&smin[lane], __float_as_uint(best[0]));
+        if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(best[1]));
+        __syncthreads();
+        if (threadIdx.x == 0) *hcount = 0;  // the list is consumed
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned int v = smin[lane + t * 64];
+            if (real[t] && v < 0x7f800000u && v < __float_as_uint(best[t])) { best[t] = __uint_as_float(v + 1u); bj[t] = -1; }
+        }
+    };
+    if constexpr (HIER) {
+        // A hierarchy of boxes, 64 to 1: chunks (8 model points) < super boxes (512 points) < level-3 boxes (32 768
+        // points).  Every level is tested like the chunks of the flat search -- one box per lane against the group
+        // box and the largest bound -- and only the children of the survivors are looked at: a survivor costs a wave ONE
+        // pass over its 64 children.  A box contains its children and every operation of the test is monotonic, so
+        // a chunk that passes its own test has ancestors that pass too: the hit list is the one the flat search
+        // builds, the model is just not read where it cannot matter (10 M-point model: 40 MB of chunk boxes per
+        // block -> 10 KB of level-3 boxes + the children of a few survivors).
+        constexpr int SCAP = 2 * SP_NW * 64;   // super-box hit list: the children of 32 level-3 boxes
+        constexpr int TCAP = SP_NW * 64;       // level-3 hit list = level-3 boxes per outermost round (33 M model points)
+        static_assert(SCAP * 4 <= 3 * 2048 * 4 - HITS_BYTES, "the super-box hit list lies between the chunk hit list and the merge keys");
+        int* shits = reinterpret_cast<int*>(lds_raw + HITS_BYTES);
+        int* thits = reinterpret_cast<int*>(lds_raw + MQ_OFF + 3 * MD_BYTES);
+        int* scount = hcount + 1;
+        int* tcount = hcount + 2;
+        const int n2_all = ((m_pad >> 3) + 63) >> 6;
+        const float* sboxes = fuse.boxes + (size_t)m_pad;         // (the chunk boxes take m_pad floats)
+        const float* tboxes = sboxes + (size_t)n2_all * 8;
+        const int s_lo = c_lo >> 6, s_hi = (c_hi + 63) >> 6;     // a segment starts on a super-box boundary (nn_plan)
+        const int t_lo = s_lo >> 6, t_hi = (s_hi + 63) >> 6;
+        // one box per lane against the group box: true where the box may hold a winner
+        auto near_box = [&](const float4 b0, const float4 b1, float B) {
+            const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - ghi[0], glo[0] - b0.w), 0.f);
+            const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - ghi[1], glo[1] - b1.x), 0.f);
+            const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - ghi[2], glo[2] - b1.y), 0.f);
+            return ((gx * gx + gy * gy) + gz * gz) * 0.99999905f < B;
+        };
+        auto append = [&](bool pass, int value, int* list, int* count) {
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+            if (mask != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(count, (int)__builtin_popcountll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (pass) list[base + rank] = value;
+            }
+        };
+        bool list_dirty = false;   // a round has been processed: the chunk list needs the barrier after its reset
+        // (phase log: where the search spends its time -- ticks in the upper levels, the chunk find and the hit
+        // processing, barriers included, and the two hit totals; waves other than 0 leave them in slots 6..9)
+        long long dg_t[3] = {0, 0, 0}, dg_mark = 0;
+        int dg_sh = 0, dg_h = 0;
+        auto dg_lap = [&](int k) { if constexpr (DIAG) { const long long now = (long long)wall_clock64(); dg_t[k] += now - dg_mark; dg_mark = now; } };
+        if constexpr (DIAG) dg_mark = (long long)wall_clock64();
+        for (int tb = t_lo; tb < t_hi; tb += TCAP) {
+            {   // level 3: one pass per wave (the first round's boxes were fetched at kernel entry)
+                const float Bt = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
+                const int tidx = tb + w * 64 + lane;
+                float4 b0 = pb[0][0], b1 = pb[0][1];
+                if (tb != t_lo) {
+                    const float4* bp = reinterpret_cast<const float4*>(tboxes + (size_t)(tidx < t_hi ? tidx : t_lo) * 8);
+                    b0 = bp[0]; b1 = bp[1];
+                }
+                append(tidx < t_hi && near_box(b0, b1, Bt), tidx, thits, tcount);
+            }
+            __syncthreads();   // the level-3 list is complete
+            const int TH = *tcount;
+            for (int tg = 0; tg < TH; tg += 2 * SP_NW) {
+                // level 2: the children of up to 32 level-3 survivors, two per wave
+                const float Bs = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
+                const int tend = min(tg + 2 * SP_NW, TH);
+                for (int k = tg + w; k < tend; k += SP_NW) {
+                    const int sidx = (thits[k] << 6) + lane;
+                    const bool in = sidx >= s_lo && sidx < s_hi;
+                    const float4* bp = reinterpret_cast<const float4*>(sboxes + (size_t)(in ? sidx : s_lo) * 8);
+                    append(in && near_box(bp[0], bp[1], Bs), sidx, shits, scount);
+                }
+                __syncthreads();   // the super list is complete (and, after a processed round, the chunk list's reset is seen)
+                const int SH = *scount;
+                dg_lap(0);
+                dg_sh += SH;
+                const bool more_above = tend < TH || tb + TCAP < t_hi;
+                for (int sh0 = 0; sh0 < SH; sh0 += 64) {
+                    // one round: the chunks of up to 64 super boxes (<= SP_HCAP hits)
+                    const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
+                    if (list_dirty && sh0 != 0) __syncthreads();  // (sh0 == 0: the barrier above)
+                    const int send = min(sh0 + 64, SH);
+                    for (int k = sh0 + w; k < send; k += SP_NW) {
+                        const int c0 = shits[k] << 6;
+                        const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
+                        find_pass(c0, bp[0], bp[1], B);
+                    }
+                    __syncthreads();
+                    dg_lap(1);
+                    dg_h += *hcount;
+                    process_hits(*hcount);
+                    if (send < SH || more_above) { exchange(); list_dirty = true; }
+                    dg_lap(2);
+                }
+                if (more_above) {
+                    __syncthreads();   // everybody has read the super list
+                    if (threadIdx.x == 0) *scount = 0;
+                    __syncthreads();
+                }
+            }
+            if (tb + TCAP < t_hi) {
+                __syncthreads();
+                if (threadIdx.x == 0) *tcount = 0;
+                __syncthreads();
+            }
+        }
+        if constexpr (DIAG) {
+            if (fuse.tlog != nullptr && lane == 0 && w != 0 && (fuse.tlog_pass < 0 || fuse.tlog_pass == phase_pass_)) {
+                const long long slot_ = (((long long)blockIdx.y * gridDim.x + blockIdx.x) * phase_nw_ + w) * 10;
+                if (slot_ + 9 < fuse.tlog_cap) {
+                    fuse.tlog[slot_ + 6] = dg_t[0]; fuse.tlog[slot_ + 7] = dg_t[1]; fuse.tlog[slot_ + 8] = dg_t[2];
+                    fuse.tlog[slot_ + 9] = ((long long)dg_sh << 32) | (long long)dg_h;
+                }
+            }
+        }
+    } else {
     for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
         // B only shrinks while the block works: refreshed once per round
         const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
@@ -1357,59 +1535,9 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             find_pass(c0, bp[0], bp[1], B);
         }
         __syncthreads();
-        const int H = *hcount;
-        // The hits are dealt round-robin; a wave fetches the box and the coordinates of up to 8 of its hits with ONE
-        // gather -- 8 lanes x 16 bytes per hit -- into its private LDS stage, so a batch of hits costs one trip to
-        // memory instead of three or four each.
-        // (exchanging minima between the batches of a cold pass was measured too: the barriers cost more than they save)
-        {
-            const int h1 = H;
-            for (int hb = 0; hb < h1; hb += SP_NW * 8) {
-                {
-                    const int r = lane >> 3, part = lane & 7;
-                    const int h = hb + r * SP_NW + w;
-                    if (h < h1) {
-                        const int chl = hits[h];
-                        const float* src = part < 2 ? fuse.boxes + (size_t)chl * 8 + part * 4
-                                                    : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)chl * 8 + (part & 1) * 4;
-                        *reinterpret_cast<float4*>(stage + r * STG + part * 4) = *reinterpret_cast<const float4*>(src);
-                    }
-                    // a sorted view: the elements' model indices (the sort permutation) are staged too
-                    if constexpr (PERM) {
-                        const int r2 = lane >> 1, half = lane & 1;
-                        const int h2 = hb + r2 * SP_NW + w;
-                        if (lane < 16 && h2 < h1)
-                            *reinterpret_cast<int4*>(stage + r2 * STG + 32 + half * 4) =
-                                *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)hits[h2] * 8 + half * 4);
-                    }
-                }
-                lds_same_wave_order();
-                const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
-                const int cnt = mine < 8 ? mine : 8;
-                for (int rr = 0; rr < cnt; ++rr) {
-                    if constexpr (PERM) {
-                        scan_hit<true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
-                    } else {
-                        const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * SP_NW + w]);
-                        scan_hit<false>(stage + rr * STG, ch, px, py, pz, best, bj, bq);
-                    }
-                }
-                lds_same_wave_order();
-            }
-            if (rb + round_chunks < c_hi) {
-                // exchange before the next round: every wave goes on from the block's best minimum so far, bumped by
-                // an ulp (d >= 0: the bit patterns order like the values, so this is an integer min)
-                if (real[0]) atomicMin(&smin[lane], __float_as_uint(best[0]));
-                if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(best[1]));
-                __syncthreads();
-                if (threadIdx.x == 0) *hcount = 0;  // the list is consumed
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const unsigned int v = smin[lane + t * 64];
-                    if (real[t] && v < 0x7f800000u && v < __float_as_uint(best[t])) { best[t] = __uint_as_float(v + 1u); bj[t] = -1; }
-                }
-            }
-        }
+        process_hits(*hcount);
+        if (rb + round_chunks < c_hi) exchange();
+    }
     }
     ICP_PHASE(3)
 
@@ -1720,8 +1848,9 @@ hipError_t launch_duplicates_and_scan_copy(const PrepBuffers& b, const float* X,
 }
 
 // perm_out[k] = k-th point in Morton order; totals[0] / totals[1] = summed group extents of the given / the Morton order
-hipError_t launch_morton_order(const PrepBuffers& b, const float* X, int n, int n_pad, int group, int32_t* perm_out, double* totals,
-                               hipStream_t st)
+// (group2 > 0: totals[2] / totals[3] = the same for groups of group2 -- the upper search level of a large model)
+hipError_t launch_morton_order(const PrepBuffers& b, const float* X, int n, int n_pad, int group, int group2, int32_t* perm_out,
+                               double* totals, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     const dim3 blk(256), grd((n + 255) / 256);
@@ -1735,6 +1864,13 @@ hipError_t launch_morton_order(const PrepBuffers& b, const float* X, int n, int 
     hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups, totals, 0);
     hipLaunchKernelGGL(prep_group_extent_kernel, ggrd, dim3(64), 0, st, X, n, n_pad, (const int32_t*)perm_out, group, b.ext);
     hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups, totals, 1);
+    if (group2 > 0) {
+        const int groups2 = (n + group2 - 1) / group2;
+        hipLaunchKernelGGL(prep_group_extent_kernel, dim3(groups2), dim3(64), 0, st, X, n, n_pad, (const int32_t*)nullptr, group2, b.ext);
+        hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups2, totals, 2);
+        hipLaunchKernelGGL(prep_group_extent_kernel, dim3(groups2), dim3(64), 0, st, X, n, n_pad, (const int32_t*)perm_out, group2, b.ext);
+        hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups2, totals, 3);
+    }
     return hipGetLastError();
 }
 
@@ -1802,11 +1938,44 @@ hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, h
     return hipGetLastError();
 }
 
+// upper levels: the box of every 64 boxes of the level below (512, 32 768 model points), one wave per box; stored
+// behind the chunk boxes, level after level
+__global__ __launch_bounds__(256) void model_superboxes_kernel(const float* __restrict__ boxes, int chunks, int supers, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int sidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sidx >= supers) return;
+    const int c = sidx * 64 + lane;
+    float lo[3] = {inf_<float>(), inf_<float>(), inf_<float>()}, hi[3] = {-inf_<float>(), -inf_<float>(), -inf_<float>()};
+    if (c < chunks) {
+        const float4* bp = reinterpret_cast<const float4*>(boxes + (size_t)c * 8);
+        const float4 b0 = bp[0], b1 = bp[1];
+        lo[0] = b0.x; lo[1] = b0.y; lo[2] = b0.z; hi[0] = b0.w; hi[1] = b1.x; hi[2] = b1.y;
+    }
+    wave_box(lo, hi);
+    if (lane == 0) {
+        float* o = out + (size_t)sidx * 8;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
+size_t model_boxes_bytes(int m_pad)
+{
+    const size_t chunks = (size_t)(m_pad + 7) / 8, supers = (chunks + 63) / 64, thirds = (supers + 63) / 64;
+    return (chunks + supers + thirds) * 8 * sizeof(float);
+}
+
 hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st)
 {
     if (m_pad <= 0) return hipSuccess;
     const int chunks = (m_pad + 7) / 8;
     hipLaunchKernelGGL(model_boxes_kernel, dim3((chunks + 255) / 256), dim3(256), 0, st, (const float*)Qs_soa, m_pad, boxes);
+    const int supers = (chunks + 63) / 64;
+    float* l2 = boxes + (size_t)chunks * 8;
+    hipLaunchKernelGGL(model_superboxes_kernel, dim3((supers + 3) / 4), dim3(256), 0, st, (const float*)boxes, chunks, supers, l2);
+    const int thirds = (supers + 63) / 64;
+    hipLaunchKernelGGL(model_superboxes_kernel, dim3((thirds + 3) / 4), dim3(256), 0, st, (const float*)l2, supers, thirds,
+                       l2 + (size_t)supers * 8);
     return hipGetLastError();
 }
 
@@ -2417,7 +2586,11 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus)
             if (S > max_S) S = max_S;
             if (env_S > 0) S = env_S;
             if (S < 1) S = 1;
-            int seg = round_up((pl.m_pad + S - 1) / S, 8);
+            // large models are searched in two levels (boxes of 64 chunks first): from 2^17 points up, where the
+            // flat pass over the chunk boxes starts to dominate (ICP_NN_HIER = 0 / 1 overrides)
+            const int env_hier = env_int("ICP_NN_HIER", -1);   // (not cached: the tests switch it between contexts)
+            pl.hier = env_hier >= 0 ? (env_hier ? 1 : 0) : (pl.m_pad >= (1 << 17) ? 1 : 0);
+            int seg = round_up((pl.m_pad + S - 1) / S, pl.hier ? 512 : 8);   // (a segment starts on a super-box boundary)
             S = (pl.m_pad + seg - 1) / seg;
             pl.splits = S;
             pl.seg_len = seg;
@@ -2575,12 +2748,13 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             int n_pad = pl.n_pad, m_pad = pl.m_pad, seg = pl.seg_len;
             float* pd = (float*)part_d;
             void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
-            const bool diag = fuse.tlog != nullptr, perm = fuse.q_perm != nullptr;
-            const void* fns[2][2][2] = {{{(const void*)nn_match_sparse<1, false, false>, (const void*)nn_match_sparse<1, false, true>},
-                                         {(const void*)nn_match_sparse<1, true, false>, (const void*)nn_match_sparse<1, true, true>}},
-                                        {{(const void*)nn_match_sparse<2, false, false>, (const void*)nn_match_sparse<2, false, true>},
-                                         {(const void*)nn_match_sparse<2, true, false>, (const void*)nn_match_sparse<2, true, true>}}};
-            const void* fn = fns[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0][diag ? 1 : 0][perm ? 1 : 0];
+            const bool diag = fuse.tlog != nullptr, perm = fuse.q_perm != nullptr, hier = pl.hier != 0;
+#define ICP_SP_FN(TL, DG, PM) {(const void*)nn_match_sparse<TL, DG, PM, false>, (const void*)nn_match_sparse<TL, DG, PM, true>}
+            const void* fns[2][2][2][2] = {{{ICP_SP_FN(1, false, false), ICP_SP_FN(1, false, true)}, {ICP_SP_FN(1, true, false), ICP_SP_FN(1, true, true)}},
+                                           {{ICP_SP_FN(2, false, false), ICP_SP_FN(2, false, true)}, {ICP_SP_FN(2, true, false), ICP_SP_FN(2, true, true)}}};
+#undef ICP_SP_FN
+            const int variant = (((ta->metric == ICP_POINT_TO_PLANE ? 1 : 0) * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0)) * 2 + (hier ? 1 : 0);
+            const void* fn = (&fns[0][0][0][0])[variant];
             // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
             // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
             // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that
@@ -2588,9 +2762,9 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
             static const int env_coop = env_int("ICP_COOP", 0);
             if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
-            static long long capacity[2][2][2] = {{{-1, -1}, {-1, -1}}, {{-1, -1}, {-1, -1}}};   // blocks the machine holds at once, per variant
-            long long& cap = capacity[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0][diag ? 1 : 0][perm ? 1 : 0];
-            if (cap < 0) {
+            static long long capacity[16];   // blocks the machine holds at once, per variant (0: not asked yet)
+            long long& cap = capacity[variant];
+            if (cap <= 0) {
                 int per_cu = 0, dev = 0, cus = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
                     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -2600,9 +2774,11 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             if ((long long)grid.x * grid.y > cap) return hipErrorCooperativeLaunchTooLarge;
             return hipLaunchKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
         }
-#define ICP_LAUNCH_SP3(TL, DG, PM)                                                                                 \
-    hipLaunchKernelGGL((nn_match_sparse<TL, DG, PM>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,     \
+#define ICP_LAUNCH_SP4(TL, DG, PM, HR)                                                                             \
+    hipLaunchKernelGGL((nn_match_sparse<TL, DG, PM, HR>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad, \
                        (const float*)Qsp, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail)
+#define ICP_LAUNCH_SP3(TL, DG, PM)                                                                                 \
+    do { if (pl.hier) ICP_LAUNCH_SP4(TL, DG, PM, true); else ICP_LAUNCH_SP4(TL, DG, PM, false); } while (0)
 #define ICP_LAUNCH_SP(TL)                                                                                          \
     do {                                                                                                           \
         const bool dg_ = fuse.tlog != nullptr, pm_ = fuse.q_perm != nullptr;                                       \
@@ -2613,6 +2789,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         else if (ta->metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_SP(2);
         else ICP_LAUNCH_SP(1);
 #undef ICP_LAUNCH_SP3
+#undef ICP_LAUNCH_SP4
 #undef ICP_LAUNCH_SP
         return hipGetLastError();
     }

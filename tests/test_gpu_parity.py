@@ -547,11 +547,13 @@ def _fuzz_cloud(rng, n, kind, scale):
     return (scale * X).astype(np.float32)
 
 
-@pytest.mark.parametrize("sort", ["0", "1"])
-def test_matching_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort):
+@pytest.mark.parametrize("sort,hier", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
+def test_matching_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier):
     """randomised clouds (uniform / clustered with duplicates / integer lattice / collinear, three scales, ragged sizes)
-    through the sparse kernel with its Morton views forbidden and forced: indices bit-exact against the CPU oracle"""
+    through the sparse kernel with its Morton views forbidden and forced, flat and through the box hierarchy of the
+    large models (forced onto models of one or two super boxes): indices bit-exact against the CPU oracle"""
     monkeypatch.setenv("ICP_SORT", sort)
+    monkeypatch.setenv("ICP_NN_HIER", hier)
     rng = np.random.default_rng(20260210 + int(sort))
     with pkg.Context(0) as c:
         for case in range(40):
@@ -563,11 +565,12 @@ def test_matching_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort):
             assert np.array_equal(got, want), (case, n, m, kp, km, scale, int(np.flatnonzero(got != want)[0]))
 
 
-@pytest.mark.parametrize("sort", ["0", "1"])
-def test_registration_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort):
-    """randomised registrations (seeded passes, resident kernel, clustered / lattice models with duplicates and ties):
-    error series, transform and final correspondences against the oracle's run"""
+@pytest.mark.parametrize("sort,hier", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
+def test_registration_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier):
+    """randomised registrations (seeded passes, resident kernel, clustered / lattice models with duplicates and ties),
+    flat search and box hierarchy: error series, transform and final correspondences against the oracle's run"""
     monkeypatch.setenv("ICP_SORT", sort)
+    monkeypatch.setenv("ICP_NN_HIER", hier)
     rng = np.random.default_rng(7300 + int(sort))
     with pkg.Context(0) as c:
         for case in range(8):
@@ -585,3 +588,64 @@ def test_registration_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort):
             assert_same_run(res.iterations, res.err, res.T, want, 1e-7, fp32=True)
             if res.iterations == want["iterations"]:
                 assert np.array_equal(res.idx, want["idx"]), case
+
+
+# ---------------------------------------------------------------------------------------------------
+# large models: the search goes through the box hierarchy (chunks < 512-point boxes < 32 768-point boxes)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["grid", "uniform", "clustered"])
+@pytest.mark.parametrize("n", [300, 3000])
+def test_large_model_matching_against_the_oracle(ctx, pkg, orc, kind, n):
+    """a model above the size where the hierarchical search is the default (ragged against every level: 140 037 points
+    = 17 504.6 chunks, 273.5 super boxes, 4.3 level-3 boxes), a moving cloud of a few rows (the model is then cut into
+    segments on super-box boundaries) and of enough rows to go unsegmented; cold and seeded pass: bit-exact"""
+    rng = np.random.default_rng(4242 + n)
+    m = 140_037
+    if kind == "grid":
+        M = pkg.datasets.synthetic_grid(375, np.float32)[:m]          # row-major: thin 512-point boxes, own order kept or not
+        P = pkg.datasets.make_model_gpu(M[rng.integers(0, m, n)], (0.02, -0.01, 0.015), (0.01, -0.02, 0.005))
+    else:
+        M = _fuzz_cloud(rng, m, kind, 1.0)
+        P = (M[rng.integers(0, m, n)] + (5e-3 * rng.standard_normal((n, 3))).astype(np.float32)).astype(np.float32)
+    want = orc.nn(P, M)
+    ctx.set_model(M); ctx.set_moving(P)
+    ctx.nn_match_resident()
+    cold = ctx.get_indices()
+    assert np.array_equal(cold, want), int(np.flatnonzero(cold != want)[0])
+    ctx.nn_match_bench(1, seeded=True)
+    assert np.array_equal(ctx.get_indices(), want)
+
+
+def test_large_model_registration_against_the_oracle(ctx, pkg, orc):
+    """a few iterations on a 2^17-point model (hierarchical search, armed launches: 40 rows + S = 4 segments would not
+    be a resident grid): same run as the oracle, correspondences of the last pass bit-exact"""
+    W = 363                                                   # 131 769 points
+    M = pkg.datasets.synthetic_grid(W, np.float32)
+    rng = np.random.default_rng(99)
+    D = pkg.datasets.make_model_gpu(M[rng.integers(0, W * W, 5000)], (0.03, -0.02, 0.01), (0.02, -0.01, 0.015))
+    res = ctx.point_to_point(D, M, max_iter=4, tol=1e-9, fixed_iterations=True)
+    want = orc.icp_p2p_f32x(D, M, 4, 1e-9, fixed=True)
+    assert_same_run(res.iterations, res.err, res.T, want, 1e-9, fp32=True)
+    if res.iterations == want["iterations"]:
+        assert np.array_equal(res.idx, want["idx"])
+
+
+def test_million_point_self_match_is_the_identity(ctx, pkg):
+    """size-independent property at a size the CPU cannot check pair by pair: a 1024 x 1024 grid matched against
+    itself returns every point's own index (1.1e12 pairs, brute-force semantics), cold and seeded; against its moved
+    copy every index is valid and 64 sampled points agree with numpy's brute force"""
+    W = 1024
+    D = pkg.datasets.synthetic_grid(W, np.float32)
+    ctx.set_model(D); ctx.set_moving(D)
+    ctx.nn_match_resident()
+    assert np.array_equal(ctx.get_indices(), np.arange(W * W, dtype=np.int32))
+    ctx.nn_match_bench(1, seeded=True)
+    assert np.array_equal(ctx.get_indices(), np.arange(W * W, dtype=np.int32))
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    ctx.set_model(M)
+    ctx.nn_match_resident()
+    idx = ctx.get_indices()
+    assert int(idx.min()) >= 0 and int(idx.max()) < W * W
+    for i in np.random.default_rng(5).integers(0, W * W, 64):
+        d = (D[i][None, :] - M) ** 2
+        assert int(((d[:, 0] + d[:, 1]) + d[:, 2]).argmin()) == int(idx[i])

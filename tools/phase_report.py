@@ -12,6 +12,17 @@ import numpy as np
 
 a = np.fromfile(sys.argv[1], dtype=np.int64)
 a = a[: len(a) // 10 * 10].reshape(-1, 10)
+if "--hier" in sys.argv:
+    # two-level search: waves other than wave 0 of a block leave, in slots 6..9, the ticks spent in the super-box find,
+    # the chunk find and the hit processing (barriers included) and (super hits << 32 | chunk hits) of the block
+    nw = 16
+    w = np.arange(len(a)) % nw
+    r = a[(w == 1) & (a[:, 1] > 0)]
+    sf, cf, pr = r[:, 6] / 100.0, r[:, 7] / 100.0, r[:, 8] / 100.0
+    sh, h = r[:, 9] >> 32, r[:, 9] & 0xffffffff
+    for name, v in (("super find us", sf), ("chunk find us", cf), ("process us", pr), ("super hits", sh), ("chunk hits", h)):
+        print(f"{name:14s} blocks {len(v):6d}  median {np.median(v):9.2f}  mean {v.mean():9.2f}  p90 {np.percentile(v, 90):9.2f}  max {v.max():9.2f}")
+    a[w != 0, 6:] = 0
 live = (a[:, 1:] > 0).any(axis=1)
 a = a[live].astype(np.float64)
 first = 0 if (a[:, 0] > 0).all() and a[:, 0].max() <= a[:, 1][a[:, 1] > 0].min() + 1e7 and (a[:, 1][a[:, 1] > 0].min() - a[:, 0].min()) < 1e4 else 1
