@@ -1,0 +1,1489 @@
+// icp_api.cpp -- the C ABI of libicp_mi355x.so (include/icp_mi355x.h): context, HBM residency,
+// and the ICP driver loops that replace the reference's main() while-loops
+//   src/ICP_CPU.c:217-271, src/ICP_point_to_point.cu:295-423, src/ICP_point_to_plane.cu:517-631.
+//
+// Loop shape (one host round trip per iteration, no H2D traffic at all):
+//
+//   enqueue k:  [transform_error(R_{k-1}, t_{k-1})]  ->  nn_match  ->  moments  ->  finalize
+//               (R, t travel as kernel arguments)        P_k vs Q      fused       32 doubles
+//   <optional all-reduce of the 32-double vector across ranks, in place, on the same stream>
+//   complete k: D2H 256 B, E[k] and the stop rule on the host, 3x3 SVD / 6x6 Cholesky -> R_k, t_k
+//
+// The error of transform k-1 rides in slot 0 of the vector produced by enqueue k, so matching pass k
+// is issued speculatively before the stop rule for E[k] is known; when the rule fires that one
+// pass is discarded (it never touched P).  Correspondences ping-pong between two buffers so the
+// indices of the last CONTRIBUTING pass survive the speculative one.
+#include <hip/hip_runtime.h>
+
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+#endif
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <unistd.h>
+#include <limits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/icp_mi355x.h"
+#include "icp_comm.h"
+#include "icp_lcomm.h"
+#include "icp_host_loop.h"
+#include "icp_host_math.h"
+#include "icp_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(ICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+// orders the stores of a mailbox message before its sequence number (and pushes them out, should the mailbox ever
+// live in write-combining memory: the `lock or` compilers emit for a seq_cst fence does not do that)
+static inline void bar_fence()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    _mm_sfence();
+#else
+    __sync_synchronize();
+#endif
+}
+
+static constexpr int kMailSlots = 4;  // armed launches: ring of mailboxes (one is live at a time)
+static constexpr size_t kPhaseSlots = 512 * 1024;  // ICP_NN_PHASES: 10 stamps per wave
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct LoopState {
+    bool active = false;
+    bool pending = false;   // an enqueue awaits its complete
+    icp::HostLoop H;        // error series, stop rule, minimisation, transform composition (host only)
+    int applied_idx = 0;    // idx buffer used by the last applied transform
+    int mom_blocks = 0, err_blocks = 0;
+    double seconds_nn = 0.0;
+    int nn_launches = 0;
+    bool timed_nn = false;
+    bool host_reduce = false;  // how the pending enqueue's partial rows are being reduced
+    bool matched = false;      // a matching pass of THIS loop has filled idx[cur]
+    bool rows_have_err = false; // slot 0 of the pending moment rows carries the error shares (fused tail)
+    double wait_tag = 0.0;      // completion tag of the pending enqueue's rows
+    // armed launch: the matching pass AFTER the pending one is already enqueued and waits for its (R, t)
+    bool armed = false;
+    double armed_tag = 0.0;
+    int armed_slot = 0;
+    int armed_prev_cur = 0;
+};
+
+}  // namespace
+
+struct icp_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int prec = -1;  // precision of the resident clouds (model and moving must agree)
+    int n = 0, m = 0;
+    bool have_model = false, have_moving = false, have_normals = false;
+    DevBuf P0;  // pristine copy of the moving cloud as uploaded (icp_reset_moving)
+    DevBuf Qbox;  // chunk bounding boxes of Qs
+    DevBuf Qsamp; // one point per chunk of Qs
+    DevBuf Qss;   // Morton-ordered scan copy (sparse kernel), when the model's own order has no locality
+    DevBuf Qperm; // ... and its permutation: sorted position -> model index
+    DevBuf Pperm; // slot -> moving point (Morton order of the initial positions), when the cloud's own order has no locality
+    bool model_sorted = false, moving_sorted = false;
+    // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
+    DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
+    struct PrepSmall { float box[4]; double totals[2]; int voided; int pad_; };
+    DevBuf phase_log;        // ICP_NN_PHASES diagnostic
+    std::string phase_path;
+    DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
+    bool have_scan_copy = false;
+    int voided = 0;  // P2: ping-pong target of the transform fused into the matching kernel
+    DevBuf part_d, part_idx, idx[2];
+    int cur = 0;  // idx buffer written by the most recent matching pass
+    bool idx_valid = false;  // idx[cur] holds matches of the resident clouds
+    DevBuf mom_partials, err_partials, mom_own, nbr;
+    DevBuf keys, tickets;              // fused tail of the matching kernel: (d, idx) keys per moving point, row tickets
+    size_t rows_cap = 0;               // rows available in mom_partials / h_mom_partials
+    bool fused_tail = true;            // ICP_FUSED_TAIL=0 keeps matching and moments as two kernels
+    bool use_boxes = true;             // ICP_NN_BOXES=0 disables the bounding-box level of the early-out
+    double* mom_dev = nullptr;
+    double* h_mom = nullptr;  // pinned: the reduced ICP_NMOM vector as the host solve reads it
+    // single-GPU fast path: the moments / transform kernels store their per-block partial rows straight
+    // into mapped pinned host memory and the host adds them in block order -- no finalize launch, no
+    // D2H blit.  (With an external moments buffer, i.e. the multi-GPU driver, the device finalize runs.)
+    double* h_mom_partials = nullptr;  // [MOM_MAX_BLOCKS][ICP_NMOM]
+    double* h_err_partials = nullptr;  // [err_cap]
+    size_t err_cap = 0;                // rows available in err_partials / h_err_partials
+    uint64_t tag_seq = 0;              // completion tag of the most recent moments launch (exact in a double)
+    int profile_stride = 0;            // time every n-th matching launch (0 = never)
+    uint64_t nn_launch_count = 0;
+    double prof_seconds_nn = 0.0;      // cumulative over loops since icp_set_profiling
+    int prof_nn_launches = 0;
+    long long prof_nn_passes = 0;      // matching passes inside those launches (resident kernels run many)
+    uint64_t resident_launch_count = 0;
+    // ICP_TRACE=1: host-side time split of the loop, printed by icp_destroy
+    bool trace = false;
+    double tr_first_row = 0.0, tr_last_row = 0.0;
+    std::chrono::steady_clock::time_point tr_rows_done{};
+    bool trace_passes = false;         // ICP_TRACE=2: one line per pass of a resident registration
+    double tr_enqueue = 0, tr_wait = 0, tr_reduce = 0, tr_solve = 0;
+    uint64_t tr_n = 0;
+    void* comm = nullptr;              // RCCL communicator (icp_comm_init): the loop all-reduces its vector itself
+    icp::LocalComm* lcomm = nullptr;   // host-memory communicator (icp_comm_init_local): the vector is summed over the node's ranks on the host
+    bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
+    bool arm = true;                   // ICP_ARMED=0: icp_loop_run never enqueues a pass ahead of its (R, t)
+    bool resident = true;              // ICP_RESIDENT=0: icp_loop_run never keeps one kernel for a whole registration
+    bool resident_refused = false;     // the resident kernel does not fit the machine with this plan: do not try again
+    // ring of mailboxes for armed / resident launches, in pinned mapped host memory, and the device-memory relay.
+    // (Fine-grained device memory written through the PCIe BAR is ~0.5 us faster per message and needs no relay --
+    // tools/mailbox_probe.hip -- but with the HIP runtime that PyTorch bundles the waiting kernel never sees a
+    // store made after it started; host memory polled by ONE block works with every runtime.)
+    icp::NNMailbox* h_mail = nullptr;
+    bool mail_in_bar = false;
+    bool moving_is_pristine = false;   // icp_reset_moving: P is stale, the cloud to use is P0 (copied on first need)
+    // fine-grained device memory: ordinary (coarse-grained) device memory is cached per XCD L2, and a block polling
+    // it from another XCD keeps reading its stale line (seen as 24 of 128 blocks never receiving the message)
+    icp::NNMailbox* relay = nullptr;
+    uint64_t mail_seq = 0;
+    bool host_reduce() const { return !comm && mom_dev == (double*)mom_own.p && h_mom_partials != nullptr; }
+    icp::NNPlan plan{};
+    LoopState loop;
+};
+
+namespace {
+
+int use(icp_ctx* c)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return ICP_OK;
+}
+
+int ensure_work_buffers(icp_ctx* c)
+{
+    const icp::NNPlan before = c->plan;
+    c->plan = icp::nn_plan(c->n, c->m, c->prec, c->num_cus);
+    const icp::NNPlan& pl = c->plan;
+    if (before.n_pad != pl.n_pad || before.m_pad != pl.m_pad) c->resident_refused = false;  // another geometry: ask again
+    const size_t es = icp::elem_size(c->prec);
+    const size_t S = pl.splits > 0 ? (size_t)pl.splits : 1;
+    HIP_TRY(c->part_d.ensure(S * (size_t)pl.n_pad * es));
+    HIP_TRY(c->part_idx.ensure(S * (size_t)pl.n_pad * sizeof(int32_t)));
+    HIP_TRY(c->idx[0].ensure((size_t)pl.n_pad * sizeof(int32_t)));
+    HIP_TRY(c->idx[1].ensure((size_t)pl.n_pad * sizeof(int32_t)));
+    const bool fresh = c->mom_partials.cap == 0;
+    size_t rows = (size_t)icp::MOM_MAX_BLOCKS;
+    if ((size_t)pl.blocks_x > rows) rows = (size_t)pl.blocks_x;
+    if (rows > c->rows_cap) {
+        if (c->h_mom_partials) { (void)hipHostFree(c->h_mom_partials); c->h_mom_partials = nullptr; }
+        HIP_TRY(hipHostMalloc((void**)&c->h_mom_partials, rows * ICP_NMOM * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(c->h_mom_partials, 0, rows * ICP_NMOM * sizeof(double));
+        c->rows_cap = rows;
+    }
+    HIP_TRY(c->mom_partials.ensure(rows * ICP_NMOM * sizeof(double)));
+    if (icp::nn_can_fuse_tail(pl)) {
+        const size_t kb = (size_t)pl.n_pad * sizeof(unsigned long long), tb = (size_t)pl.blocks_x * sizeof(unsigned int);
+        if (kb > c->keys.cap) {
+            HIP_TRY(c->keys.ensure(kb));
+            HIP_TRY(hipMemsetAsync(c->keys.p, 0xFF, c->keys.cap, c->stream));   // "no candidate yet"
+        }
+        if (tb > c->tickets.cap) {
+            HIP_TRY(c->tickets.ensure(tb));
+            HIP_TRY(hipMemsetAsync(c->tickets.p, 0, c->tickets.cap, c->stream));
+        }
+    }
+    // one error row per matching block row (fused transform) or per transform block
+    size_t err_rows = (size_t)icp::MOM_MAX_BLOCKS;
+    if ((size_t)pl.blocks_x > err_rows) err_rows = (size_t)pl.blocks_x;
+    if (err_rows > c->err_cap) {
+        if (c->h_err_partials) { (void)hipHostFree(c->h_err_partials); c->h_err_partials = nullptr; }
+        HIP_TRY(hipHostMalloc((void**)&c->h_err_partials, err_rows * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(c->h_err_partials, 0, err_rows * sizeof(double));
+        c->err_cap = err_rows;
+    }
+    HIP_TRY(c->err_partials.ensure(err_rows * sizeof(double)));
+    if (icp::nn_can_fuse_transform(pl)) HIP_TRY(c->P2.ensure(3 * (size_t)pl.n_pad * es));
+    HIP_TRY(c->mom_own.ensure(ICP_NMOM * sizeof(double)));
+    if (fresh) {
+        HIP_TRY(hipMemsetAsync(c->mom_partials.p, 0, c->mom_partials.cap, c->stream));
+        HIP_TRY(hipMemsetAsync(c->err_partials.p, 0, c->err_partials.cap, c->stream));
+        HIP_TRY(hipMemsetAsync(c->mom_own.p, 0, c->mom_own.cap, c->stream));
+    }
+    if (!c->mom_dev) c->mom_dev = (double*)c->mom_own.p;
+    return ICP_OK;
+}
+
+// upload a host AoS cloud and convert it to the padded SoA layout
+int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision, DevBuf& dst)
+{
+    const size_t es = icp::elem_size(precision);
+    HIP_TRY(dst.ensure(3 * (size_t)pad * es));
+    if (count <= 0) return ICP_OK;
+    HIP_TRY(c->stage.ensure(3 * (size_t)count * es));
+    HIP_TRY(hipMemcpyAsync(c->stage.p, aos, 3 * (size_t)count * es, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(icp::launch_aos_to_soa(precision, c->stage.p, count, pad, dst.p, c->stream));
+    // the staging buffer is reused by the next upload: order them on the stream, and make sure the
+    // pageable host source has been consumed before returning
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+// ---- spatial order and duplicate flags, on the device ---------------------------------------------------------------
+// The sparse matching kernel prunes by bounding boxes of 8 consecutive model points and of 128 consecutive moving
+// points: it needs clouds whose index order has spatial locality.  A LiDAR scan has it; a mesh's vertex list
+// (Bunny) does not.  Where Morton order makes the groups clearly tighter than the given order, the kernel works
+// on a Morton-ordered view (a permutation: the clouds at the ABI and every index it returns stay in user order).
+// Sorting and the extent test run on the device (rocPRIM radix sorts, fixed-order reductions): a few dozen
+// microseconds per cloud instead of milliseconds of std::sort on the host.
+static int prep_buffers(icp_ctx* c, int count, icp::PrepBuffers& b)
+{
+    const size_t tb = icp::prep_sort_temp_bytes(count);
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(c->prep_keys[k].ensure((size_t)count * sizeof(unsigned int)));
+        HIP_TRY(c->prep_vals[k].ensure((size_t)count * sizeof(int32_t)));
+    }
+    HIP_TRY(c->prep_tmp.ensure(tb));
+    HIP_TRY(c->prep_small.ensure(sizeof(icp_ctx::PrepSmall)));
+    HIP_TRY(c->prep_ext.ensure((size_t)((count + 7) / 8) * sizeof(double)));
+    HIP_TRY(c->prep_voided.ensure((size_t)icp::round_up(count, 16) + 16));
+    HIP_TRY(c->prep_perm.ensure((size_t)count * sizeof(int32_t)));
+    b.keys[0] = (unsigned int*)c->prep_keys[0].p; b.keys[1] = (unsigned int*)c->prep_keys[1].p;
+    b.vals[0] = (int32_t*)c->prep_vals[0].p; b.vals[1] = (int32_t*)c->prep_vals[1].p;
+    b.temp = c->prep_tmp.p;
+    b.temp_bytes = tb;
+    b.box = (float*)c->prep_small.p;
+    b.ext = (double*)c->prep_ext.p;
+    HIP_TRY(hipMemsetAsync(c->prep_small.p, 0, sizeof(icp_ctx::PrepSmall), c->stream));
+    return ICP_OK;
+}
+
+// reads the extent totals back and decides: true when Morton order makes the groups at least 3x tighter.  A scan that
+// already has locality must keep its order even if Morton cells are tighter: the hall scan's model chunks are 2.1x
+// tighter in Morton order, yet matching gets 20 % slower -- its 8-point half columns line up with the moving groups
+// (8 columns), compact Morton cells do not; the Bunny vertex list is 10x / 5.8x looser than Morton order.
+static int morton_decision(icp_ctx* c, int count, int group, bool* use_sorted, int* voided_out)
+{
+    icp_ctx::PrepSmall h{};
+    HIP_TRY(hipMemcpyAsync(&h, c->prep_small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (voided_out) *voided_out = h.voided;
+    const char* force = std::getenv("ICP_SORT");   // ICP_SORT=0 never, =1 always (A/B runs, tests)
+    if (force && force[0] == '0') *use_sorted = false;
+    else if (count <= group) *use_sorted = false;
+    else if (force && force[0] == '1') *use_sorted = true;
+    else *use_sorted = 3.0 * h.totals[1] < h.totals[0];
+    if (c->trace)
+        std::fprintf(stderr, "[icp trace] %d points, groups of %d: extent %.4g in the given order, %.4g in Morton order -> %s; %d exact duplicates voided\n",
+                     count, group, h.totals[0], h.totals[1], *use_sorted ? "Morton view" : "own order", h.voided);
+    return ICP_OK;
+}
+
+int check_precision(int precision)
+{
+    if (precision != ICP_F32 && precision != ICP_F64) return fail(ICP_ERR_INVALID, "unknown precision");
+    return ICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icp_abi_version(void) { return ICP_ABI_VERSION; }
+
+const char* icp_strerror(int code)
+{
+    switch (code) {
+        case ICP_OK: return "ok";
+        case ICP_ERR_INVALID: return "invalid argument";
+        case ICP_ERR_NO_DEVICE: return "no usable gfx950 HIP device (there is no CPU fallback)";
+        case ICP_ERR_HIP: return "HIP runtime error";
+        case ICP_ERR_EMPTY: return "empty model cloud";
+        case ICP_ERR_SINGULAR: return "point-to-plane system is not positive definite";
+        case ICP_ERR_IO: return "dataset file missing or malformed";
+        case ICP_ERR_STATE: return "call sequence error";
+        case ICP_ERR_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+const char* icp_last_error(void) { return g_last_error.c_str(); }
+
+int icp_device_count(void)
+{
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ICP_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    return n;
+}
+
+static void mailbox_selftest(icp_ctx* c, int slot, const char* when)
+{
+    icp::NNMailbox* mb = c->h_mail + slot;
+    volatile double* ack = c->h_mom;
+    *ack = 0.0;
+    *(volatile double*)&mb->seq = 1.0;
+    bar_fence();
+    (void)icp::launch_mailbox_selftest(mb, c->h_mom, c->stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    while (*ack != 1.0 && since() < 5.0) {}
+    const double t_start = since();
+    *(volatile double*)&mb->seq = 2.0;
+    bar_fence();
+    while (*ack != 2.0 && *ack != -1.0 && since() < 10.0) {}
+    std::fprintf(stderr, "[icp selftest %s slot %d] kernel running after %.6f s; live store %s after %.6f s (ack %.0f)\n", when, slot, t_start,
+                 *ack == 2.0 ? "SEEN" : "NOT seen", since() - t_start, *ack);
+    (void)hipStreamSynchronize(c->stream);
+    *(volatile double*)&mb->seq = 0.0;
+    bar_fence();
+}
+
+int icp_create(int device, icp_ctx** out)
+{
+    if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    const int nd = icp_device_count();
+    if (nd <= 0) return fail(ICP_ERR_NO_DEVICE, "no HIP device visible: " + g_last_error);
+    if (device < 0 || device >= nd) return fail(ICP_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ICP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    icp_ctx* c = new (std::nothrow) icp_ctx();
+    if (!c) return fail(ICP_ERR_NOMEM, "context allocation failed");
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mom, ICP_NMOM * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) {
+        // mailbox: fine-grained device memory written through the PCIe BAR when the machine allows it (every block
+        // polls its own memory), else pinned host memory polled by block 0 and relayed (ICP_MAILBOX=host forces that)
+        const char* mv = std::getenv("ICP_MAILBOX");
+        int large_bar = 0;
+        if (!(mv && mv[0] == 'h') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
+            hipExtMallocWithFlags((void**)&c->h_mail, kMailSlots * sizeof(icp::NNMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
+            c->mail_in_bar = true;
+        } else {
+            (void)hipGetLastError();
+            e = hipHostMalloc((void**)&c->h_mail, kMailSlots * sizeof(icp::NNMailbox), hipHostMallocMapped | hipHostMallocCoherent);
+        }
+        if (e == hipSuccess) { std::memset(c->h_mail, 0, kMailSlots * sizeof(icp::NNMailbox)); bar_fence(); }
+    }
+    if (e == hipSuccess) {
+        if (hipExtMallocWithFlags((void**)&c->relay, sizeof(icp::NNMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
+            e = hipMemset(c->relay, 0, sizeof(icp::NNMailbox));
+        } else {
+            (void)hipGetLastError();
+            c->relay = nullptr;  // no armed / resident launches on this device: every pass is launched after its solve
+        }
+    }
+
+    if (e != hipSuccess) {
+        const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
+        icp_destroy(c);
+        return fail(ICP_ERR_HIP, msg);
+    }
+    c->stream = c->own_stream;
+    if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
+    if (const char* v = std::getenv("ICP_ARMED")) c->arm = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_TRACE")) { c->trace = v[0] == '1' || v[0] == '2'; c->trace_passes = v[0] == '2'; }
+    if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_NN_PHASES")) {
+        // diagnostic: the matching kernel stamps its phases per wave; the last launch's stamps are written to the
+        // named file (raw int64) when the context is destroyed -- tools/phase_report.py reads it
+        if (v[0] && c->phase_log.ensure(kPhaseSlots * sizeof(long long)) == hipSuccess &&
+            hipMemset(c->phase_log.p, 0, kPhaseSlots * sizeof(long long)) == hipSuccess) {
+            c->phase_path = v;
+            icp::set_phase_log((long long*)c->phase_log.p, (long long)kPhaseSlots);
+        }
+    }
+    if (const char* v = std::getenv("ICP_SELFTEST"))
+        if (v[0] == '1') mailbox_selftest(c, 3, "create");
+    *out = c;
+    return ICP_OK;
+}
+
+void icp_destroy(icp_ctx* c)
+{
+    if (!c) return;
+    if (c->trace && c->tr_n)
+        std::fprintf(stderr, "[icp trace] %llu iterations: enqueue %.2f us, wait %.2f us, reduce %.2f us, solve %.2f us (host, per iteration)\n",
+                     (unsigned long long)c->tr_n, 1e6 * c->tr_enqueue / c->tr_n, 1e6 * c->tr_wait / c->tr_n,
+                     1e6 * c->tr_reduce / c->tr_n, 1e6 * c->tr_solve / c->tr_n);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
+    if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
+    if (c->phase_log.p && !c->phase_path.empty()) {
+        icp::set_phase_log(nullptr, 0);
+        std::vector<long long> h(kPhaseSlots);
+        if (hipMemcpy(h.data(), c->phase_log.p, kPhaseSlots * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = std::fopen(c->phase_path.c_str(), "wb")) { std::fwrite(h.data(), sizeof(long long), h.size(), f); std::fclose(f); }
+        }
+        c->phase_log.release();
+    }
+    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+                      &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
+    for (DevBuf* b : bufs) b->release();
+    if (c->h_mom) (void)hipHostFree(c->h_mom);
+    if (c->h_mail) { if (c->mail_in_bar) (void)hipFree(c->h_mail); else (void)hipHostFree(c->h_mail); }
+    if (c->relay) (void)hipFree(c->relay);
+    if (c->h_mom_partials) (void)hipHostFree(c->h_mom_partials);
+    if (c->h_err_partials) (void)hipHostFree(c->h_err_partials);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int icp_comm_unique_id(void* out_bytes)
+{
+    if (!out_bytes) return fail(ICP_ERR_INVALID, "out == NULL");
+    std::string err;
+    const int rc = icp::comm_unique_id(out_bytes, err);
+    return rc == ICP_OK ? ICP_OK : fail(rc, err);
+}
+
+int icp_comm_init(icp_ctx* c, const void* id_bytes, int rank, int world)
+{
+    if (int rc = use(c)) return rc;
+    if (!id_bytes || world < 1 || rank < 0 || rank >= world) return fail(ICP_ERR_INVALID, "bad communicator arguments");
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
+    HIP_TRY(c->mom_own.ensure(ICP_NMOM * sizeof(double)));
+    if (!c->mom_dev) c->mom_dev = (double*)c->mom_own.p;
+    std::string err;
+    const int rc = icp::comm_init(id_bytes, rank, world, &c->comm, err);
+    return rc == ICP_OK ? ICP_OK : fail(rc, err);
+}
+
+int icp_comm_destroy(icp_ctx* c)
+{
+    if (int rc = use(c)) return rc;
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
+    if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
+    return ICP_OK;
+}
+
+int icp_comm_random_id(void* out_bytes)
+{
+    if (!out_bytes) return fail(ICP_ERR_INVALID, "out == NULL");
+    std::memset(out_bytes, 0, ICP_COMM_ID_BYTES);
+    FILE* f = std::fopen("/dev/urandom", "rb");
+    size_t got = f ? std::fread(out_bytes, 1, 16, f) : 0;
+    if (f) std::fclose(f);
+    if (got != 16) {  // fall back to clock + pid: unique enough for a segment name on one node
+        const uint64_t a = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count(), b = (uint64_t)getpid();
+        std::memcpy(out_bytes, &a, 8);
+        std::memcpy((char*)out_bytes + 8, &b, 8);
+    }
+    return ICP_OK;
+}
+
+int icp_comm_init_local(icp_ctx* c, const void* id_bytes, int rank, int world)
+{
+    if (int rc = use(c)) return rc;
+    if (!id_bytes || world < 1 || rank < 0 || rank >= world) return fail(ICP_ERR_INVALID, "bad communicator arguments");
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    if (c->comm) return fail(ICP_ERR_STATE, "a device communicator is attached: destroy it first");
+    if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
+    std::string err;
+    const int rc = icp::lcomm_create(id_bytes, rank, world, &c->lcomm, err);
+    return rc == ICP_OK ? ICP_OK : fail(rc, err);
+}
+
+struct icp_lcomm { icp::LocalComm* p; };
+
+int icp_lcomm_create(const void* id_bytes, int rank, int world, icp_lcomm** out)
+{
+    if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    std::string err;
+    icp::LocalComm* p = nullptr;
+    if (int rc = icp::lcomm_create(id_bytes, rank, world, &p, err)) return fail(rc, err);
+    *out = new icp_lcomm{p};
+    return ICP_OK;
+}
+
+int icp_lcomm_allreduce(icp_lcomm* h, double* v, int count)
+{
+    if (!h) return fail(ICP_ERR_INVALID, "null communicator");
+    std::string err;
+    const int rc = icp::lcomm_allreduce_sum_f64(h->p, v, count, err);
+    return rc == ICP_OK ? ICP_OK : fail(rc, err);
+}
+
+void icp_lcomm_destroy(icp_lcomm* h)
+{
+    if (!h) return;
+    icp::lcomm_destroy(h->p);
+    delete h;
+}
+
+int icp_set_stream(icp_ctx* c, void* hip_stream)
+{
+    if (int rc = use(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return ICP_OK;
+}
+
+int icp_set_profiling(icp_ctx* c, int enable)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    c->profiling = enable != 0;
+    c->profile_stride = enable > 0 ? enable : 0;
+    c->prof_seconds_nn = 0.0;
+    c->prof_nn_launches = 0;
+    c->prof_nn_passes = 0;
+    return ICP_OK;
+}
+
+int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = check_precision(precision)) return rc;
+    if (m < 0 || (m > 0 && !xyz)) return fail(ICP_ERR_INVALID, "bad model cloud");
+    if (c->have_moving && c->prec != precision) { c->have_moving = false; c->n = 0; }
+    c->prec = precision;
+    c->m = m;
+    c->have_normals = false;
+    c->loop.active = false;
+    c->idx_valid = false;
+    if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q)) return rc;
+    c->have_scan_copy = false;
+    if (precision == ICP_F32 && m > 0) {
+        // scan copy for the early-out matching kernels: exact duplicates of a lower-index point (and the padding)
+        // voided to +inf -- they can never be the lowest-index minimum (see NNCullInputs).  Flags, Morton order and
+        // the extent test are computed on the device from the uploaded cloud.
+        const int m_pad = icp::pad_model(m);
+        icp::PrepBuffers pb{};
+        if (int rc = prep_buffers(c, m, pb)) return rc;
+        icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
+        HIP_TRY(c->Qs.ensure(3 * (size_t)m_pad * sizeof(float)));
+        HIP_TRY(icp::launch_duplicates_and_scan_copy(pb, (const float*)c->Q.p, m, m_pad, (unsigned char*)c->prep_voided.p, &small->voided,
+                                                     (float*)c->Qs.p, c->stream));
+        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->Q.p, m, m_pad, 8, (int32_t*)c->prep_perm.p, small->totals, c->stream));
+        if (int rc = morton_decision(c, m, 8, &c->model_sorted, &c->voided)) return rc;
+        // the sparse kernel's view: the same voided copy, in Morton order if the model's own order has no locality
+        const void* view = c->Qs.p;
+        if (c->model_sorted) {
+            HIP_TRY(c->Qss.ensure(3 * (size_t)m_pad * sizeof(float)));
+            HIP_TRY(c->Qperm.ensure((size_t)m_pad * sizeof(int32_t)));
+            HIP_TRY(icp::launch_gather_sorted((const float*)c->Qs.p, m, m_pad, (const int32_t*)c->prep_perm.p, (float*)c->Qss.p,
+                                              (int32_t*)c->Qperm.p, c->stream));
+            view = c->Qss.p;
+        }
+        // bounding boxes of its 8-point chunks (the first, cheapest level of the early-out) and one point per chunk
+        HIP_TRY(c->Qbox.ensure((size_t)((m_pad + 7) / 8) * 8 * sizeof(float)));
+        HIP_TRY(icp::launch_model_boxes(view, m_pad, (float*)c->Qbox.p, c->stream));
+        HIP_TRY(c->Qsamp.ensure(icp::model_samples_bytes(m_pad)));
+        HIP_TRY(icp::launch_model_samples(view, m_pad, (float*)c->Qsamp.p, c->stream));
+        c->have_scan_copy = true;
+    }
+    c->have_model = true;
+    return ICP_OK;
+}
+
+int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = check_precision(precision)) return rc;
+    if (n < 0 || (n > 0 && !xyz)) return fail(ICP_ERR_INVALID, "bad moving cloud");
+    if (c->have_model && c->prec != precision)
+        return fail(ICP_ERR_INVALID, "moving cloud precision differs from the resident model");
+    c->prec = precision;
+    c->n = n;
+    c->loop.active = false;
+    c->idx_valid = false;
+    if (int rc = upload_cloud(c, xyz, n, icp::pad_moving(n), precision, c->P)) return rc;
+    if (n > 0) {
+        const size_t bytes = 3 * (size_t)icp::pad_moving(n) * icp::elem_size(precision);
+        HIP_TRY(c->P0.ensure(bytes));
+        HIP_TRY(hipMemcpyAsync(c->P0.p, c->P.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->moving_sorted = false;
+    if (precision == ICP_F32 && n > 128) {
+        const int n_pad = icp::pad_moving(n);
+        icp::PrepBuffers pb{};
+        if (int rc = prep_buffers(c, n, pb)) return rc;
+        icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
+        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->P.p, n, n_pad, 128, (int32_t*)c->prep_perm.p, small->totals, c->stream));
+        if (int rc = morton_decision(c, n, 128, &c->moving_sorted, nullptr)) return rc;
+        if (c->moving_sorted) {
+            HIP_TRY(c->Pperm.ensure((size_t)n_pad * sizeof(int32_t)));
+            HIP_TRY(icp::launch_slot_map((const int32_t*)c->prep_perm.p, n, n_pad, (int32_t*)c->Pperm.p, c->stream));
+        }
+    }
+    c->have_moving = true;
+    c->moving_is_pristine = false;
+    return ICP_OK;
+}
+
+int icp_reset_moving(icp_ctx* c)
+{
+    if (int rc = use(c)) return rc;
+    if (!c->have_moving) return fail(ICP_ERR_STATE, "no moving cloud resident");
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    c->moving_is_pristine = true;
+    c->loop.active = false;
+    c->idx_valid = false;
+    return ICP_OK;
+}
+
+int icp_set_model_normals(icp_ctx* c, const void* nxyz, int m)
+{
+    if (int rc = use(c)) return rc;
+    if (!c->have_model) return fail(ICP_ERR_STATE, "set the model before its normals");
+    if (m != c->m || (m > 0 && !nxyz)) return fail(ICP_ERR_INVALID, "normal count must equal the model size");
+    if (int rc = upload_cloud(c, nxyz, m, icp::pad_model(m), c->prec, c->Nrm)) return rc;
+    c->have_normals = true;
+    return ICP_OK;
+}
+
+static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
+{
+    icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
+    if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
+    if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
+    return o;
+}
+
+// icp_reset_moving is lazy: whoever needs the moving cloud in c->P asks for it here (the resident kernel does not --
+// it reads the pristine copy directly and writes c->P itself, which saves a device-to-device copy and a dependent
+// dispatch per registration)
+static int materialize_moving(icp_ctx* c)
+{
+    if (c->moving_is_pristine && c->n > 0) {
+        const size_t bytes = 3 * (size_t)icp::pad_moving(c->n) * icp::elem_size(c->prec);
+        HIP_TRY(hipMemcpyAsync(c->P.p, c->P0.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->moving_is_pristine = false;
+    return ICP_OK;
+}
+
+int icp_get_moving(icp_ctx* c, void* out)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = materialize_moving(c)) return rc;
+    if (!c->have_moving) return fail(ICP_ERR_STATE, "no moving cloud resident");
+    if (c->n == 0) return ICP_OK;
+    if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
+    const size_t bytes = 3 * (size_t)c->n * icp::elem_size(c->prec);
+    HIP_TRY(c->stage.ensure(bytes));
+    HIP_TRY(icp::launch_soa_to_aos(c->prec, c->P.p, c->n, icp::pad_moving(c->n), c->stage.p, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->stage.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+static int download_idx(icp_ctx* c, int which, int32_t* out)
+{
+    if (c->n == 0) return ICP_OK;
+    if (!out) return fail(ICP_ERR_INVALID, "idx_out == NULL");
+    if (!c->idx[which].p) return fail(ICP_ERR_STATE, "no matching pass has run");
+    HIP_TRY(hipMemcpyAsync(out, c->idx[which].p, (size_t)c->n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+int icp_get_indices(icp_ctx* c, int32_t* out)
+{
+    if (int rc = use(c)) return rc;
+    return download_idx(c, c->cur, out);
+}
+
+static int require_clouds(icp_ctx* c)
+{
+    if (!c->have_model || !c->have_moving) return fail(ICP_ERR_STATE, "model and moving clouds must be resident");
+    if (c->n > 0 && c->m == 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    return ICP_OK;
+}
+
+int icp_nn_match_resident(icp_ctx* c, float* kernel_ms)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = require_clouds(c)) return rc;
+    if (int rc = ensure_work_buffers(c)) return rc;
+    if (int rc = materialize_moving(c)) return rc;
+    if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    const icp::NNCullInputs cull = make_cull(c, nullptr);
+    HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
+    if (kernel_ms) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(icp::launch_merge(c->plan, c->part_d.p, (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->idx_valid = true;
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, c->ev0, c->ev1));
+    return ICP_OK;
+}
+
+int icp_nn_match_bench(icp_ctx* c, int reps, float* total_ms) { return icp_nn_match_bench_ex(c, reps, 1, total_ms); }
+
+int icp_nn_match_bench_ex(icp_ctx* c, int reps, int seeded, float* total_ms)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = require_clouds(c)) return rc;
+    if (reps <= 0 || !total_ms) return fail(ICP_ERR_INVALID, "reps/total_ms");
+    if (int rc = ensure_work_buffers(c)) return rc;
+    if (int rc = materialize_moving(c)) return rc;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // seeded with the most recent correspondences when there are any: this is how the loop launches it
+    const icp::NNCullInputs cull = make_cull(c, (seeded && c->idx_valid) ? (const int32_t*)c->idx[c->cur].p : nullptr);
+    for (int r = 0; r < reps; ++r)
+        HIP_TRY(icp::launch_nn(c->plan, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, nullptr, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventElapsedTime(total_ms, c->ev0, c->ev1));
+    return ICP_OK;
+}
+
+int icp_nn_launch_info(icp_ctx* c, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    if (splits) *splits = c->plan.splits;
+    if (blocks) *blocks = c->plan.blocks_x * c->plan.splits;
+    if (threads) *threads = icp::nn_block_threads(c->plan);
+    if (n_pad) *n_pad = c->plan.n_pad;
+    if (m_pad) *m_pad = c->plan.m_pad;
+    return ICP_OK;
+}
+
+static int nn_match_host(icp_ctx* c, const void* P, int n, const void* Q, int m, int precision, int32_t* idx)
+{
+    if (int rc = use(c)) return rc;
+    if (n < 0 || m < 0) return fail(ICP_ERR_INVALID, "negative size");
+    if (n == 0) return ICP_OK;
+    if (m == 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    if (!P || !Q || !idx) return fail(ICP_ERR_INVALID, "null pointer");
+    if (int rc = icp_set_model(c, Q, m, precision)) return rc;
+    if (int rc = icp_set_moving(c, P, n, precision)) return rc;
+    if (int rc = icp_nn_match_resident(c, nullptr)) return rc;
+    return download_idx(c, c->cur, idx);
+}
+
+int icp_nn_match_f32(icp_ctx* c, const float* P, int n, const float* Q, int m, int32_t* idx)
+{
+    return nn_match_host(c, P, n, Q, m, ICP_F32, idx);
+}
+
+int icp_nn_match_f64(icp_ctx* c, const double* P, int n, const double* Q, int m, int32_t* idx)
+{
+    return nn_match_host(c, P, n, Q, m, ICP_F64, idx);
+}
+
+// ---- normals -----------------------------------------------------------------------------------
+int icp_estimate_normals(icp_ctx* c, void* nxyz_out, int32_t* nbr_out)
+{
+    if (int rc = use(c)) return rc;
+    if (!c->have_model) return fail(ICP_ERR_STATE, "no model resident");
+    const int m = c->m;
+    if (m == 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    if (m < 5) return fail(ICP_ERR_INVALID, "normals need at least 5 model points (k = 4 neighbours + self)");
+    icp::NNPlan pl = icp::nn_plan(m, m, c->prec, c->num_cus);
+    HIP_TRY(c->nbr.ensure((size_t)m * 4 * sizeof(int32_t)));
+    const size_t es = icp::elem_size(c->prec);
+    HIP_TRY(c->Nrm.ensure(3 * (size_t)pl.m_pad * es));
+    static const bool knn_v1 = std::getenv("ICP_KNN_V1") && std::getenv("ICP_KNN_V1")[0] == '1';
+    if (c->prec == ICP_F32 && !knn_v1) {
+        int n_pad, bx, S, seg;
+        icp::knn4_v2_geometry(m, c->num_cus, &n_pad, &bx, &S, &seg);
+        // the per-segment top-5 lists reuse the matching partial buffers
+        HIP_TRY(c->part_d.ensure((size_t)S * n_pad * 5 * sizeof(float)));
+        HIP_TRY(c->part_idx.ensure((size_t)S * n_pad * 5 * sizeof(int32_t)));
+        HIP_TRY(icp::launch_knn4_v2(c->Q.p, m, c->num_cus, (float*)c->part_d.p, (int32_t*)c->part_idx.p, (int32_t*)c->nbr.p,
+                                    c->stream));
+    } else {
+        HIP_TRY(icp::launch_knn4(pl, c->Q.p, (int32_t*)c->nbr.p, c->stream));
+    }
+    // covariance + eigen-solve on the device, straight into the resident (padded SoA) normal cloud
+    HIP_TRY(icp::launch_normals(c->prec, c->Q.p, m, pl.m_pad, (const int32_t*)c->nbr.p, c->Nrm.p, c->stream));
+    if (nxyz_out) {
+        HIP_TRY(c->stage.ensure(3 * (size_t)m * es));
+        HIP_TRY(icp::launch_soa_to_aos(c->prec, c->Nrm.p, m, pl.m_pad, c->stage.p, c->stream));
+        HIP_TRY(hipMemcpyAsync(nxyz_out, c->stage.p, 3 * (size_t)m * es, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (nbr_out)
+        HIP_TRY(hipMemcpyAsync(nbr_out, c->nbr.p, (size_t)m * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_normals = true;
+    return ICP_OK;
+}
+
+// ---- the loop ----------------------------------------------------------------------------------
+int icp_loop_begin(icp_ctx* c, const icp_params* prm)
+{
+    if (int rc = use(c)) return rc;
+    if (!prm) return fail(ICP_ERR_INVALID, "params == NULL");
+    if (int rc = require_clouds(c)) return rc;
+    if (prm->max_iter < 1) return fail(ICP_ERR_INVALID, "max_iter must be >= 1");
+    if (prm->metric != ICP_POINT_TO_POINT && prm->metric != ICP_POINT_TO_PLANE) return fail(ICP_ERR_INVALID, "unknown metric");
+    if (prm->precision != c->prec) return fail(ICP_ERR_INVALID, "params precision differs from the resident clouds");
+    if (prm->metric == ICP_POINT_TO_PLANE && !c->have_normals) return fail(ICP_ERR_STATE, "point-to-plane needs model normals");
+    if (c->n == 0) return fail(ICP_ERR_INVALID, "empty moving cloud");
+    if (int rc = ensure_work_buffers(c)) return rc;
+    LoopState& L = c->loop;
+    L = LoopState();
+    if (int rc = L.H.begin(*prm)) return fail(rc, "bad loop parameters");
+    L.active = true;
+    return ICP_OK;
+}
+
+int icp_loop_enqueue(icp_ctx* c)
+{
+    if (int rc = use(c)) return rc;
+    LoopState& L = c->loop;
+    if (!L.active || L.H.done || L.pending) return fail(ICP_ERR_STATE, "enqueue: loop not ready");
+    if (int rc = materialize_moving(c)) return rc;
+    const auto tr0 = std::chrono::steady_clock::now();
+    const icp::NNPlan& pl = c->plan;
+    L.err_blocks = 0;
+    L.mom_blocks = 0;
+    L.rows_have_err = false;
+    const bool host_reduce = c->host_reduce();
+    double* mom_rows = host_reduce ? c->h_mom_partials : (double*)c->mom_partials.p;
+    double* err_rows = (double*)c->err_partials.p;  // device: the moments kernel folds them into its rows
+    const bool apply = L.H.have_rt;
+    const bool final_only = L.H.next_is_final();  // the loop ends after this error whatever it is
+    // the transform of the previous pass rides in the front of the matching kernel when that kernel
+    // supports it; otherwise (fp64, or nothing left to match) it is its own launch
+    const bool fused = apply && !final_only && icp::nn_can_fuse_transform(pl);
+    if (apply) {
+        if (!fused)  // with nothing left to match, the last pass's rows go straight to the host
+            HIP_TRY(icp::launch_transform_error(c->prec, c->P.p, c->n, pl.n_pad, L.H.R, L.H.t, c->Q.p, pl.m_pad,
+                                                (const int32_t*)c->idx[c->cur].p,
+                                                (final_only && host_reduce) ? c->h_err_partials : err_rows,
+                                                &L.err_blocks, c->stream));
+        L.applied_idx = c->cur;
+        L.H.note_applied();
+    }
+    L.timed_nn = false;
+    if (!final_only) {
+        // the previous pass's matches seed the early-out bound (any valid index would do)
+        const icp::NNCullInputs cull = make_cull(c, L.matched ? (const int32_t*)c->idx[c->cur].p : nullptr);
+        c->cur ^= 1;
+        L.matched = true;
+        c->idx_valid = true;
+        const bool time_this = c->profile_stride > 0 && (c->nn_launch_count++ % (uint64_t)c->profile_stride) == 0;
+        if (time_this) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); }
+        // fused tail: the matching kernel itself merges the segments (atomic keys), stores idx and produces the
+        // moment rows -- no partial arrays, no second launch.  ICP_FUSED_TAIL=0 keeps the two-kernel form.
+        const bool tail = c->fused_tail && icp::nn_can_fuse_tail(pl);
+        icp::NNTailArgs ta{};
+        if (tail) {
+            ta.metric = L.H.prm.metric;
+            ta.keys = (unsigned long long*)c->keys.p;
+            ta.tickets = (unsigned int*)c->tickets.p;
+            ta.err_tile = (double*)c->err_partials.p;
+            ta.idx_out = (int32_t*)c->idx[c->cur].p;
+            ta.Nrm_soa = c->Nrm.p;
+            ta.rows = mom_rows;
+            ta.tag = (double)(++c->tag_seq);
+        }
+        if (fused) {
+            icp::NNFusedTransform ft{L.H.R, L.H.t, (const int32_t*)c->idx[L.applied_idx].p, c->P2.p, err_rows};
+            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, tail ? &ta : nullptr, c->stream));
+            std::swap(c->P, c->P2);  // the moved cloud is the current one from here on
+            L.err_blocks = pl.blocks_x;
+        } else {
+            HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, tail ? &ta : nullptr, c->stream));
+        }
+        if (time_this) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); L.timed_nn = true; }
+        if (tail) {
+            L.mom_blocks = pl.blocks_x;   // one row per row of matching blocks, error share in slot 0
+            L.err_blocks = 0;
+            L.rows_have_err = true;
+        } else {
+            HIP_TRY(icp::launch_moments(pl, L.H.prm.metric, c->P.p, c->Q.p, c->Nrm.p, c->part_d.p,
+                                        (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, mom_rows,
+                                        &L.mom_blocks, (double)(++c->tag_seq), err_rows, L.err_blocks, c->stream));
+            if (host_reduce) L.err_blocks = 0;  // already inside the moment rows
+        }
+    }
+    if (!host_reduce) {
+        HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
+                                     (const double*)c->err_partials.p, L.err_blocks, L.rows_have_err ? 1 : 0, c->stream));
+        if (c->comm) {  // the iteration's one collective: 32 doubles, in place, on the loop's stream
+            std::string err;
+            if (int rc = icp::comm_allreduce_sum_f64(c->comm, c->mom_dev, ICP_NMOM, c->stream, err)) return fail(rc, err);
+        }
+    }
+    L.host_reduce = host_reduce;
+    L.wait_tag = (double)c->tag_seq;
+    L.pending = true;
+    if (c->trace) c->tr_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+    return ICP_OK;
+}
+
+void* icp_loop_moments_dev(icp_ctx* c) { return c ? (void*)c->mom_dev : nullptr; }
+
+int icp_loop_set_moments_dev(icp_ctx* c, void* dev_ptr)
+{
+    if (int rc = use(c)) return rc;
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    if (!dev_ptr) {
+        HIP_TRY(c->mom_own.ensure(ICP_NMOM * sizeof(double)));
+        c->mom_dev = (double*)c->mom_own.p;
+    } else {
+        c->mom_dev = (double*)dev_ptr;
+    }
+    return ICP_OK;
+}
+
+int icp_loop_complete(icp_ctx* c, int* done)
+{
+    if (int rc = use(c)) return rc;
+    LoopState& L = c->loop;
+    if (!L.active || !L.pending) return fail(ICP_ERR_STATE, "complete without enqueue");
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr1 = tr0;
+    if (L.host_reduce) {
+        // the kernels wrote their partial rows into mapped pinned memory.  Instead of a stream
+        // synchronisation the host polls the per-row completion tags (each row is released to system
+        // scope before its tag); the matching kernel's error rows were complete before the moments
+        // kernel started.  Fixed block order => the same bits every run.
+        // Rows are summed in block order AS their tags arrive, so the reduction overlaps the kernel's last blocks.
+        double* mom = c->h_mom;
+        auto start_sum = [&]() {
+            for (int k = 0; k < ICP_NMOM; ++k) mom[k] = 0.0;
+            for (int b = 0; b < L.err_blocks; ++b) mom[ICP_MOM_ERR] += c->h_err_partials[b];
+        };
+        auto add_row = [&](int b) {
+            const double* row = c->h_mom_partials + (size_t)b * ICP_NMOM;
+            for (int k = 0; k < ICP_NMOM - 1; ++k) mom[k] += row[k];  // the last slot is the completion tag
+        };
+        bool polled = false;
+        if (L.mom_blocks > 0 && !L.timed_nn && c->poll && L.err_blocks == 0) {
+            const double want = L.wait_tag;
+            const auto t0 = std::chrono::steady_clock::now();
+            int b = 0;
+            unsigned spins = 0;
+            start_sum();
+            while (b < L.mom_blocks) {
+                const volatile double* tagp = c->h_mom_partials + (size_t)b * ICP_NMOM + (ICP_NMOM - 1);
+                if (*tagp == want) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    if (c->trace_passes && b == 0) c->tr_first_row = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    add_row(b++);
+                    continue;
+                }
+                if ((++spins & 0x3ff) == 0 &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
+                    break;  // something is wrong (fault, hang): let the runtime report it
+            }
+            polled = b == L.mom_blocks;
+            if (c->trace_passes) { c->tr_last_row = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); c->tr_rows_done = std::chrono::steady_clock::now(); }
+            if (!polled && c->trace) {
+                std::fprintf(stderr, "[icp trace]   poll gave up at row %d; rows still missing:", b);
+                int shown = 0;
+                for (int r = 0; r < L.mom_blocks && shown < 40; ++r)
+                    if (c->h_mom_partials[(size_t)r * ICP_NMOM + (ICP_NMOM - 1)] != want) { std::fprintf(stderr, " %d", r); ++shown; }
+                std::fprintf(stderr, "\n");
+            }
+        }
+        tr1 = std::chrono::steady_clock::now();
+        if (!polled) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            tr1 = std::chrono::steady_clock::now();
+            for (int b = 0; b < L.mom_blocks; ++b)
+                if (c->h_mom_partials[(size_t)b * ICP_NMOM + (ICP_NMOM - 1)] != L.wait_tag) {
+                    L.pending = false;
+                    char msg[240];
+                    int have = 0;
+                    for (int r = 0; r < L.mom_blocks; ++r) have += c->h_mom_partials[(size_t)r * ICP_NMOM + (ICP_NMOM - 1)] == L.wait_tag ? 1 : 0;
+                    std::snprintf(msg, sizeof msg, "a matching pass ended without producing its rows: row %d of %d carries tag %.0f, expected %.0f; %d rows arrived (armed / resident launch timed out?)",
+                                  b, L.mom_blocks, c->h_mom_partials[(size_t)b * ICP_NMOM + (ICP_NMOM - 1)], L.wait_tag, have);
+                    return fail(ICP_ERR_HIP, msg);
+                }
+            start_sum();
+            for (int b = 0; b < L.mom_blocks; ++b) add_row(b);
+        }
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->h_mom, c->mom_dev, ICP_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        tr1 = std::chrono::steady_clock::now();
+    }
+    const auto tr2 = std::chrono::steady_clock::now();
+    L.pending = false;
+    if (L.timed_nn) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        L.seconds_nn += 1e-3 * ms;
+        L.nn_launches += 1;
+        c->prof_seconds_nn += 1e-3 * ms;
+        c->prof_nn_launches += 1;
+        c->prof_nn_passes += 1;
+    }
+    if (c->lcomm && L.host_reduce) {  // the node's ranks exchange their sums (rank order: identical on every rank)
+        std::string err;
+        if (int rc = icp::lcomm_allreduce_sum_f64(c->lcomm, c->h_mom, ICP_NMOM, err)) return fail(rc, err);
+    }
+    const int adv = L.H.advance(c->h_mom);
+    if (adv != ICP_OK) {
+        if (done) *done = 1;
+        return fail(adv, "minimisation failed (degenerate correspondences)");
+    }
+    if (c->trace) {
+        const auto tr3 = std::chrono::steady_clock::now();
+        c->tr_wait += std::chrono::duration<double>(tr1 - tr0).count();
+        c->tr_reduce += std::chrono::duration<double>(tr2 - tr1).count();
+        c->tr_solve += std::chrono::duration<double>(tr3 - tr2).count();
+        c->tr_n += 1;
+    }
+    if (done) *done = L.H.done ? 1 : 0;
+    return ICP_OK;
+}
+
+// ---- armed launches ------------------------------------------------------------------------------
+// icp_loop_run keeps one matching pass enqueued AHEAD of the (R, t) it will apply: the kernel is launched and
+// dispatched while the previous pass still runs and the host still solves, waits on a mailbox in pinned memory
+// and starts the moment the solution is published -- the launch + dispatch latency (~8 us of a ~23 us iteration
+// on the hall cloud) leaves the critical path.  If the loop stops instead, the pass is withdrawn and exits
+// without having touched anything.
+namespace {
+
+bool can_arm(icp_ctx* c)
+{
+    const LoopState& L = c->loop;
+    const icp::NNPlan& pl = c->plan;
+    return c->arm && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
+           icp::nn_can_fuse_transform(pl) && c->have_scan_copy && c->use_boxes && L.active && L.pending && !L.armed &&
+           L.matched && !L.H.done && !L.H.have_rt &&
+           !L.timed_nn &&  // a timed pass is completed with a stream synchronisation: nothing may wait behind it
+           L.H.applied + 1 < L.H.prm.max_iter &&  // the pass after the pending one still matches (it is not the final, error-only one)
+           !(c->profile_stride > 0 && (c->nn_launch_count % (uint64_t)c->profile_stride) == 0);  // timed launches stay plain
+}
+
+int loop_arm(icp_ctx* c)
+{
+    LoopState& L = c->loop;
+    const icp::NNPlan& pl = c->plan;
+    const icp::NNCullInputs cull = make_cull(c, (const int32_t*)c->idx[c->cur].p);
+    const int prev_cur = c->cur;
+    const int slot = (int)(c->mail_seq++ % kMailSlots);
+    icp::NNMailbox* mb = c->h_mail + slot;
+    const double tag = (double)(++c->tag_seq);
+    *(volatile double*)&mb->seq = 0.0;
+    bar_fence();
+    icp::NNTailArgs ta{};
+    ta.metric = L.H.prm.metric;
+    ta.keys = (unsigned long long*)c->keys.p;
+    ta.tickets = (unsigned int*)c->tickets.p;
+    ta.err_tile = (double*)c->err_partials.p;
+    ta.idx_out = (int32_t*)c->idx[prev_cur ^ 1].p;
+    ta.Nrm_soa = c->Nrm.p;
+    ta.rows = c->h_mom_partials;
+    ta.tag = tag;
+    icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[prev_cur].p, c->P2.p, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, tag};
+    if (c->profile_stride > 0) c->nn_launch_count++;
+    HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream));
+    std::swap(c->P, c->P2);
+    c->cur = prev_cur ^ 1;
+    L.armed = true;
+    L.armed_tag = tag;
+    L.armed_slot = slot;
+    L.armed_prev_cur = prev_cur;
+    return ICP_OK;
+}
+
+// the solution is in: publish it to the waiting kernel, which becomes the pending pass
+void loop_release_armed(icp_ctx* c)
+{
+    LoopState& L = c->loop;
+    icp::NNMailbox* mb = c->h_mail + L.armed_slot;
+    for (int k = 0; k < 9; ++k) mb->rt[k] = (float)L.H.R[k];
+    for (int k = 0; k < 3; ++k) mb->rt[9 + k] = (float)L.H.t[k];
+    mb->cmd = icp::ICP_CMD_TRANSFORM_MATCH;
+    bar_fence();
+    *(volatile double*)&mb->seq = L.armed_tag;
+    bar_fence();
+    L.applied_idx = L.armed_prev_cur;
+    L.H.note_applied();
+    L.mom_blocks = c->plan.blocks_x;
+    L.err_blocks = 0;
+    L.rows_have_err = true;
+    L.host_reduce = true;
+    L.timed_nn = false;
+    L.wait_tag = L.armed_tag;
+    L.pending = true;
+    L.armed = false;
+}
+
+// the loop ended (or failed): the waiting kernel exits without touching anything; undo the bookkeeping
+void loop_withdraw_armed(icp_ctx* c)
+{
+    LoopState& L = c->loop;
+    if (!L.armed) return;
+    icp::NNMailbox* mb = c->h_mail + L.armed_slot;
+    *(volatile double*)&mb->seq = -L.armed_tag;
+    bar_fence();
+    std::swap(c->P, c->P2);
+    c->cur = L.armed_prev_cur;
+    L.armed = false;
+}
+
+}  // namespace
+
+// ---- resident registration ---------------------------------------------------------------------------
+// One launch (every block resident) carries the whole loop: the blocks keep their points in registers and their seeds in
+// LDS, every pass is one mailbox message (command + R, t) and one set of rows coming back.  No launch, no
+// dispatch and no kernel boundary between two passes; what is left of an iteration is the pass itself plus one
+// host <-> device round trip (~2 us, tools/mailbox_probe.hip).  The host side is the step-wise loop unchanged:
+// the same HostLoop decides, the same rows are reduced in the same order -- the results are bit-identical.
+namespace {
+
+bool can_reside(icp_ctx* c)
+{
+    const LoopState& L = c->loop;
+    const icp::NNPlan& pl = c->plan;
+    return c->resident && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
+           icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done;
+}
+
+// returns ICP_OK with *fell_back = true when the resident kernel could not be launched (nothing has been done)
+int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fell_back)
+{
+    LoopState& L = c->loop;
+    icp::NNPlan rp = c->plan;   // the resident kernel closes every row inside its block: one segment
+    rp.splits = 1;
+    rp.seg_len = icp::round_up(rp.m_pad, 8);
+    if (const char* v = std::getenv("ICP_SELFTEST"))
+        if (v[0] == '2') { mailbox_selftest(c, 0, "loop"); mailbox_selftest(c, 1, "loop"); }
+    icp::NNMailbox* mb = c->h_mail + (int)(c->mail_seq++ % kMailSlots);
+    const int pass_cap = L.H.prm.max_iter + 2;
+    const double base = (double)(c->tag_seq + 1);
+    c->tag_seq += (uint64_t)pass_cap + 1;
+    *(volatile double*)&mb->seq = 0.0;
+    bar_fence();
+    const int c0 = c->cur;
+    const icp::NNCullInputs cull = make_cull(c, L.matched ? (const int32_t*)c->idx[c0].p : nullptr);
+    icp::NNTailArgs ta{};
+    ta.metric = L.H.prm.metric;
+    ta.keys = (unsigned long long*)c->keys.p;
+    ta.tickets = (unsigned int*)c->tickets.p;
+    ta.err_tile = (double*)c->err_partials.p;
+    ta.idx_out = (int32_t*)c->idx[c0 ^ 1].p;   // pass 0, 2, ... (the step-wise loop flips before it writes, too)
+    ta.idx_out_odd = (int32_t*)c->idx[c0].p;
+    ta.Nrm_soa = c->Nrm.p;
+    ta.rows = c->h_mom_partials;
+    ta.tag = 0.0;
+    icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[c0].p, c->P.p /* in place */, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, base, true};
+    // icp_set_profiling(n): every n-th resident kernel is bracketed by events (read after it has ended)
+    const bool time_this = c->profile_stride > 0 && (c->resident_launch_count++ % (uint64_t)c->profile_stride) == 0;
+    if (time_this) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // after icp_reset_moving the kernel reads the pristine copy and (re)writes c->P itself -- no copy is enqueued
+    const void* P_in = c->moving_is_pristine ? c->P0.p : c->P.p;
+    ft.store_first = c->moving_is_pristine;
+    const hipError_t le = icp::launch_nn(rp, P_in, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream);
+    if (le != hipSuccess) {
+        (void)hipGetLastError();
+        c->resident_refused = true;   // does not fit the machine
+        *fell_back = true;
+        return ICP_OK;
+    }
+    c->moving_is_pristine = false;
+    *fell_back = false;
+    if (time_this) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (c->trace_passes) std::fprintf(stderr, "[icp trace] resident launch: mailbox %p relay %p base %.0f\n", (void*)mb, (void*)c->relay, base);
+    auto send = [&](int cmd, double seq) {
+        mb->cmd = cmd;
+        bar_fence();
+        *(volatile double*)&mb->seq = seq;
+        bar_fence();
+    };
+    int k = *k_io, d = *d_io, sent = 0, matched = 0, rc = ICP_OK;
+    bool alive = true;
+    while (!d && k < max_steps && sent < pass_cap) {
+        const auto tr0 = std::chrono::steady_clock::now();
+        const bool apply = L.H.have_rt;
+        const bool final_only = L.H.next_is_final();
+        const int cmd = !apply ? icp::ICP_CMD_MATCH : (final_only ? icp::ICP_CMD_TRANSFORM_ONLY : icp::ICP_CMD_TRANSFORM_MATCH);
+        if (apply) {
+            for (int q = 0; q < 9; ++q) mb->rt[q] = (float)L.H.R[q];
+            for (int q = 0; q < 3; ++q) mb->rt[9 + q] = (float)L.H.t[q];
+            L.applied_idx = c->cur;
+            L.H.note_applied();
+        }
+        if (cmd != icp::ICP_CMD_TRANSFORM_ONLY) {
+            c->cur ^= 1;
+            L.matched = true;
+            c->idx_valid = true;
+            ++matched;
+        }
+        send(cmd, base + (double)sent);
+        if (c->trace_passes && sent > 0)
+            std::fprintf(stderr, "[icp trace]   host turnaround (last row seen -> next message out): %.2f us\n",
+                         1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - c->tr_rows_done).count());
+        L.mom_blocks = rp.blocks_x;
+        L.err_blocks = 0;
+        L.rows_have_err = true;
+        L.host_reduce = true;
+        L.timed_nn = false;
+        L.wait_tag = base + (double)sent;
+        L.pending = true;
+        ++sent;
+        if (c->trace) c->tr_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+        const auto tc0 = std::chrono::steady_clock::now();
+        rc = icp_loop_complete(c, &d);
+        if (c->trace_passes)
+            std::fprintf(stderr, "[icp trace] resident pass %d cmd %d: %.2f us from message to reduced rows + solve (row 0 after %.2f us, all rows after %.2f us)\n", sent - 1, cmd,
+                         1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count(), 1e6 * c->tr_first_row, 1e6 * c->tr_last_row);
+        if (rc != ICP_OK) {
+            if (c->trace) std::fprintf(stderr, "[icp trace] resident pass %d failed: mailbox %p reads back seq %.0f cmd %d (sent seq %.0f)\n",
+                                       sent - 1, (void*)mb, *(volatile double*)&mb->seq, *(volatile int*)&mb->cmd, base + (double)(sent - 1));
+            break;
+        }
+        ++k;
+        if (cmd == icp::ICP_CMD_TRANSFORM_ONLY) { alive = false; break; }  // the kernel ends itself after that pass
+    }
+    if (alive) send(icp::ICP_CMD_EXIT, -(base + (double)sent));
+    if (time_this && rc == ICP_OK) {
+        float ms = 0.f;
+        // the kernel ends within microseconds of the exit message: spin on the event instead of a blocking wait
+        // (whose wake-up alone costs tens of microseconds of the loop being measured)
+        const auto tq = std::chrono::steady_clock::now();
+        hipError_t qe = hipErrorNotReady;
+        while ((qe = hipEventQuery(c->ev1)) == hipErrorNotReady)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tq).count() > 5.0) break;
+        if (qe != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipEventSynchronize(c->ev1)); }
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        L.seconds_nn += 1e-3 * ms;
+        L.nn_launches += 1;
+        c->prof_seconds_nn += 1e-3 * ms;
+        c->prof_nn_launches += 1;
+        c->prof_nn_passes += matched;
+    }
+    *k_io = k;
+    *d_io = d;
+    return rc;
+}
+
+}  // namespace
+
+int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
+{
+    if (max_steps < 0) return fail(ICP_ERR_INVALID, "max_steps < 0");
+    int d = c && c->loop.active && c->loop.H.done ? 1 : 0, k = 0;
+    while (!d && k < max_steps) {
+        if (can_reside(c)) {
+            bool fell_back = false;
+            if (int rc = loop_run_resident(c, max_steps, &k, &d, &fell_back)) return rc;
+            if (!fell_back) continue;
+        }
+        if (!c->loop.pending)
+            if (int rc = icp_loop_enqueue(c)) return rc;
+        if (k + 1 < max_steps && can_arm(c))
+            if (int rc = loop_arm(c)) return rc;
+        if (int rc = icp_loop_complete(c, &d)) { loop_withdraw_armed(c); return rc; }
+        if (c->loop.armed) {
+            if (d) loop_withdraw_armed(c);
+            else loop_release_armed(c);
+        }
+        ++k;
+    }
+    if (steps_done) *steps_done = k;
+    if (done) *done = d;
+    return ICP_OK;
+}
+
+int icp_loop_state(icp_ctx* c, int* iterations, int* passes, double* err, int err_cap, double* T16)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    const LoopState& L = c->loop;
+    if (!L.active) return fail(ICP_ERR_STATE, "no loop");
+    if (iterations) *iterations = L.H.iterations;
+    if (passes) *passes = L.H.applied;
+    if (err) {
+        const int cnt = (int)L.H.err.size() < err_cap ? (int)L.H.err.size() : err_cap;
+        for (int i = 0; i < cnt; ++i) err[i] = L.H.err[i];
+    }
+    if (T16) std::memcpy(T16, L.H.T, sizeof L.H.T);
+    return ICP_OK;
+}
+
+int icp_loop_timing(icp_ctx* c, double* seconds_nn, int* nn_launches)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    if (seconds_nn) *seconds_nn = c->prof_seconds_nn;
+    if (nn_launches) *nn_launches = c->prof_nn_launches;
+    return ICP_OK;
+}
+
+int icp_loop_timing_passes(icp_ctx* c, long long* passes)
+{
+    if (!c || !passes) return fail(ICP_ERR_INVALID, "null argument");
+    *passes = c->prof_nn_passes;
+    return ICP_OK;
+}
+
+int icp_loop_indices(icp_ctx* c, int32_t* out)
+{
+    if (int rc = use(c)) return rc;
+    if (!c->loop.active) return fail(ICP_ERR_STATE, "no loop");
+    return download_idx(c, c->loop.H.applied > 0 ? c->loop.applied_idx : c->cur, out);
+}
+
+static int run_loop(icp_ctx* c, const icp_params* prm, icp_result* out)
+{
+    if (int rc = icp_loop_begin(c, prm)) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    int done = 0;
+    while (!done)
+        if (int rc = icp_loop_run(c, 1 << 20, nullptr, &done)) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
+    const LoopState& L = c->loop;
+    if (out) {
+        std::memcpy(out->T, L.H.T, sizeof L.H.T);
+        out->iterations = L.H.iterations;
+        out->passes = L.H.applied;
+        out->seconds_total = std::chrono::duration<double>(t1 - t0).count();
+        out->seconds_nn = L.seconds_nn;
+        if (out->err)
+            for (size_t i = 0; i < L.H.err.size(); ++i) out->err[i] = L.H.err[i];
+        if (out->idx)
+            if (int rc = icp_loop_indices(c, out->idx)) return rc;
+        if (out->moved)
+            if (int rc = icp_get_moving(c, out->moved)) return rc;
+    }
+    return ICP_OK;
+}
+
+int icp_point_to_point(icp_ctx* c, const void* data, int n, const void* model, int m, const icp_params* prm,
+                       icp_result* out)
+{
+    if (int rc = use(c)) return rc;
+    if (!prm) return fail(ICP_ERR_INVALID, "params == NULL");
+    if (n <= 0) return fail(ICP_ERR_INVALID, "empty moving cloud");
+    if (m <= 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    icp_params p = *prm;
+    p.metric = ICP_POINT_TO_POINT;
+    if (int rc = icp_set_model(c, model, m, p.precision)) return rc;
+    if (int rc = icp_set_moving(c, data, n, p.precision)) return rc;
+    return run_loop(c, &p, out);
+}
+
+int icp_point_to_plane(icp_ctx* c, const void* data, int n, const void* model, int m, const void* normals,
+                       const icp_params* prm, icp_result* out)
+{
+    if (int rc = use(c)) return rc;
+    if (!prm) return fail(ICP_ERR_INVALID, "params == NULL");
+    if (n <= 0) return fail(ICP_ERR_INVALID, "empty moving cloud");
+    if (m <= 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
+    icp_params p = *prm;
+    p.metric = ICP_POINT_TO_PLANE;
+    if (int rc = icp_set_model(c, model, m, p.precision)) return rc;
+    if (normals) {
+        if (int rc = icp_set_model_normals(c, normals, m)) return rc;
+    } else {
+        if (int rc = icp_estimate_normals(c, nullptr, nullptr)) return rc;
+    }
+    if (int rc = icp_set_moving(c, data, n, p.precision)) return rc;
+    return run_loop(c, &p, out);
+}
+
+int icp_os1_packets_to_cartesian(icp_ctx* c, const uint8_t* packets, int n_packets, const float alt16[16],
+                                 const float az16[16], float* xyz_out, uint32_t* ranges_out)
+{
+    if (int rc = use(c)) return rc;
+    if (n_packets < 0 || (n_packets > 0 && (!packets || !xyz_out)) || !alt16 || !az16) return fail(ICP_ERR_INVALID, "bad arguments");
+    if (n_packets == 0) return ICP_OK;
+    const size_t n = (size_t)n_packets * 256, bytes = (size_t)n_packets * 12608;
+    DevBuf d_pk, d_ang, d_r, d_xyz;
+    auto body = [&]() -> int {
+        HIP_TRY(d_pk.ensure(bytes));
+        HIP_TRY(d_ang.ensure(32 * sizeof(float)));
+        HIP_TRY(d_r.ensure(n * sizeof(uint32_t)));
+        HIP_TRY(d_xyz.ensure(3 * n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(d_pk.p, packets, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_ang.p, alt16, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync((float*)d_ang.p + 16, az16, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(icp::launch_os1_packets((const uint8_t*)d_pk.p, n_packets, (const float*)d_ang.p, (const float*)d_ang.p + 16,
+                                        (uint32_t*)d_r.p, (float*)d_xyz.p, c->stream));
+        HIP_TRY(hipMemcpyAsync(xyz_out, d_xyz.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (ranges_out) HIP_TRY(hipMemcpyAsync(ranges_out, d_r.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return ICP_OK;
+    };
+    const int rc = body();
+    d_pk.release(); d_ang.release(); d_r.release(); d_xyz.release();
+    return rc;
+}
+
+int icp_os1_to_cartesian(icp_ctx* c, const uint32_t* ranges, int n, uint32_t encoder0, const float alt16[16],
+                         const float az16[16], float* xyz_out)
+{
+    if (int rc = use(c)) return rc;
+    if (n < 0 || (n > 0 && (!ranges || !xyz_out)) || !alt16 || !az16) return fail(ICP_ERR_INVALID, "bad arguments");
+    if (n == 0) return ICP_OK;
+    DevBuf d_r, d_ang, d_xyz;
+    int rc = ICP_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(d_r.ensure((size_t)n * sizeof(uint32_t)));
+        HIP_TRY(d_ang.ensure(32 * sizeof(float)));
+        HIP_TRY(d_xyz.ensure(3 * (size_t)n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(d_r.p, ranges, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_ang.p, alt16, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync((float*)d_ang.p + 16, az16, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(icp::launch_os1_conversion((const uint32_t*)d_r.p, n, encoder0, (const float*)d_ang.p,
+                                           (const float*)d_ang.p + 16, (float*)d_xyz.p, c->stream));
+        HIP_TRY(hipMemcpyAsync(xyz_out, d_xyz.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return ICP_OK;
+    };
+    rc = body();
+    d_r.release();
+    d_ang.release();
+    d_xyz.release();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// icp_kernels.h -- host-callable launchers of the gfx950 kernels (icp_kernels.hip).
+// Internal to libicp_mi355x.so; the public surface is include/icp_mi355x.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/icp_mi355x.h"
+
+namespace icp {
+
+// Internal HBM layout of a cloud: SoA, x[pad] | y[pad] | z[pad], `pad` >= count.
+//   moving cloud: pad = multiple of NN_POINT_ALIGN (whole NN blocks, no bounds checks in the hot loop)
+//   model  cloud: pad = multiple of NN_CHUNK; entries [m, m_pad) replicate point m-1, which can
+//                 never win a first-minimum search against its lower-index original.
+constexpr int NN_BLOCK = 256;        // threads per matching block (4 wave64)
+constexpr int NN_POINT_ALIGN = 1024; // moving-point padding granule
+constexpr int NN_CHUNK = 16;         // model points per index-tracking chunk
+
+struct NNPlan {
+    int precision;  // ICP_F32 / ICP_F64
+    int n, m;       // real counts
+    int n_pad, m_pad;
+    int pts_per_thread; // T
+    int blocks_x;       // n_pad / (NN_BLOCK * T)
+    int splits;         // S: model segments scanned by different blocks (grid.y)
+    int seg_len;        // model points per segment (multiple of NN_CHUNK)
+    int version;        // 1: generic kernel (fp64, A/B), 2: packed fp32 kernel
+    int chunk;          // index-tracking chunk of the launched kernel
+    int cull;           // the packed kernel may use the seeded-bound / xy early-out variant
+    int sparse;         // the geometry is the sparse kernel's (16-wave blocks of 128 moving points; needs chunk boxes)
+};
+int nn_block_threads(const NNPlan& pl);
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+inline int pad_moving(int n) { return n <= 0 ? 0 : round_up(n, NN_POINT_ALIGN); }
+inline int pad_model(int m) { return m <= 0 ? 0 : round_up(m, NN_CHUNK); }
+
+// Choose the launch geometry.  `num_cus` comes from hipDeviceProp_t::multiProcessorCount.
+NNPlan nn_plan(int n, int m, int precision, int num_cus);
+
+size_t elem_size(int precision);
+
+// the transform of the previous pass, fused into the front of the matching kernel (fp32 kernel only):
+// P_out <- R * P_in + t, err_rows[block_x] <- sum |p_new - q[idx_prev]|^2
+// mailbox of an armed / resident launch, in pinned mapped host memory: the host stores rt and cmd, then (fenced)
+// seq = +tag to let the waiting kernel go, or seq = -tag to withdraw it.  Block 0 polls it and relays the message to
+// the other blocks through a copy in device memory (`relay`).
+struct NNMailbox {
+    float rt[12];  // R row-major, then t -- already rounded to the storage precision
+    double seq;
+    int cmd;       // ICP_CMD_*
+    int pad_;
+};
+enum { ICP_CMD_EXIT = 0, ICP_CMD_MATCH = 1, ICP_CMD_TRANSFORM_MATCH = 2, ICP_CMD_TRANSFORM_ONLY = 3 };
+hipError_t launch_mailbox_selftest(const NNMailbox* mb, double* ack, hipStream_t st);
+struct NNFusedTransform {
+    const double* R9;  // NULL with a mailbox
+    const double* t3;
+    const int32_t* idx_prev;
+    void* P_out;       // SoA, same padding as the input; must not alias it
+    double* err_rows;  // >= blocks_x doubles
+    const NNMailbox* mailbox = nullptr;  // armed launch (sparse kernel only): R9/t3 are not read
+    NNMailbox* relay = nullptr;          // device-memory copy for the blocks other than block 0 (one per context)
+    double want = 0.0;                   // sequence number of the (first) message
+    bool resident = false;               // the kernel stays for the whole registration: pass p is message want + p
+    bool store_first = false;            // resident: the input is not P_out (pristine copy): store the cloud in pass 0 as well
+};
+bool nn_can_fuse_transform(const NNPlan& pl);
+
+// inputs of the early-out ("cull") variant of the packed kernel.  Q_scan is a copy of the model whose
+// exact duplicates (same x,y,z as a LOWER index) are voided to +inf: such a point can never be the
+// lowest-index minimum, and voiding it keeps one coincident cluster (e.g. the hall scan's 4361
+// no-return points) from defeating the early-out for every chunk.  seed_idx: any valid model index
+// per moving point (the previous pass's match) or NULL.
+struct NNCullInputs {
+    const void* Q_scan;
+    const int32_t* seed_idx;
+    const void* boxes;  // per 8-point chunk of Q_scan: {lo.xyz, hi.xyz, 0, 0} floats (launch_model_boxes), or NULL
+    const void* samples = nullptr;  // one point per chunk of Q_scan (launch_model_samples): the sparse kernel's cold start
+    // sparse kernel only: when the model's own order has no locality its scan copy is kept in Morton order instead
+    // (boxes and samples then describe THAT copy) with q_perm[sorted j] = model index; likewise the moving points are
+    // dealt to the blocks in Morton order of their initial positions, p_perm[slot] = point.  NULL = identity.
+    const void* Q_scan_sorted = nullptr;
+    const int32_t* q_perm = nullptr;
+    const int32_t* p_perm = nullptr;
+};
+// device-side preparation of the sparse kernel's views (icp_set_model / icp_set_moving): scratch owned by the caller
+struct PrepBuffers {
+    unsigned int* keys[2];   // >= count each
+    int32_t* vals[2];        // >= count each
+    void* temp;              // rocPRIM radix-sort scratch, prep_sort_temp_bytes(count)
+    size_t temp_bytes;
+    float* box;              // 4 floats
+    double* ext;             // >= ceil(count / smallest group) doubles
+};
+size_t prep_sort_temp_bytes(int count);
+hipError_t launch_duplicates_and_scan_copy(const PrepBuffers& b, const float* X_soa, int n, int n_pad, unsigned char* voided, int* count_dev,
+                                           float* scan_out_soa, hipStream_t st);
+hipError_t launch_morton_order(const PrepBuffers& b, const float* X_soa, int n, int n_pad, int group, int32_t* perm_out, double* totals_dev,
+                               hipStream_t st);
+hipError_t launch_gather_sorted(const float* Qs_soa, int m, int m_pad, const int32_t* perm, float* out_soa, int32_t* perm_pad, hipStream_t st);
+hipError_t launch_slot_map(const int32_t* perm, int n, int n_pad, int32_t* out, hipStream_t st);
+size_t model_samples_bytes(int m_pad);
+hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, hipStream_t st);
+// diagnostic: per-wave phase stamps (s_memrealtime, 100 MHz) of the packed matching kernel, 10 slots per wave indexed
+// ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 10 + phase; NULL switches it off (the default)
+void set_phase_log(long long* dev, long long slots);
+hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st);
+
+// fused tail of the packed kernel: atomic (d, idx) keys + row tickets, the row's last block produces idx and the
+// moment row (see NNTail in icp_kernels.hip).  keys must be all-ones and tickets zero before the first launch;
+// the kernel leaves them that way.
+struct NNTailArgs {
+    int metric;                 // ICP_POINT_TO_POINT / ICP_POINT_TO_PLANE
+    unsigned long long* keys;   // [n_pad]
+    unsigned int* tickets;      // [blocks_x]
+    double* err_tile;           // [blocks_x] device
+    int32_t* idx_out;           // [n_pad]
+    int32_t* idx_out_odd = nullptr;  // resident launch: odd passes write here (NULL: idx_out)
+    const void* Nrm_soa;        // normals (plane)
+    double* rows;               // [blocks_x][ICP_NMOM], pinned host or device
+    double tag;
+};
+bool nn_can_fuse_tail(const NNPlan& pl);
+
+// matching: per (segment, point) partial minimum + index.  `ft` (optional) = fused transform,
+// `opt` (optional) = early-out inputs, `ta` (optional) = fused tail (then no partials are written).
+hipError_t launch_nn(const NNPlan& pl, const void* P_soa, const void* Q_soa, void* part_d, int32_t* part_idx,
+                     const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st);
+// stand-alone merge of the segment partials into idx (icp_nn_match_* only; the ICP loop merges
+// inside the moments kernel)
+hipError_t launch_merge(const NNPlan& pl, const void* part_d, const int32_t* part_idx, int32_t* idx, hipStream_t st);
+
+constexpr int MOM_MAX_BLOCKS = 1024;
+// fused: merge segment partials -> idx, gather q[idx], accumulate the metric's moments in fp64.
+// partials: [blocks][ICP_NMOM] doubles; returns the number of blocks used in *blocks.
+hipError_t launch_moments(const NNPlan& pl, int metric, const void* P_soa, const void* Q_soa, const void* N_soa,
+                          const void* part_d, const int32_t* part_idx, int32_t* idx, double* partials, int* blocks,
+                          double tag /* stored in slot ICP_NMOM-1 of every row once the row is complete */,
+                          const double* err_rows /* device */, int err_count /* folded into slot ICP_MOM_ERR */,
+                          hipStream_t st);
+// p <- R p + t in place (storage precision, separately rounded mul/add), and
+// sum |p_new - q[idx]|^2 in fp64 -> err_partials[block]
+hipError_t launch_transform_error(int precision, void* P_soa, int n, int n_pad, const double* R9, const double* t3,
+                                  const void* Q_soa, int m_pad, const int32_t* idx, double* err_partials,
+                                  int* blocks, hipStream_t st);
+// deterministic fixed-order reduction of the per-block partials into the ICP_NMOM-vector
+hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_blocks, const double* err_partials,
+                           int err_blocks, int rows_have_err /* slot 0 of the rows carries error shares */, hipStream_t st);
+
+hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st);
+hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, void* aos, hipStream_t st);
+
+// model-on-model 4 nearest neighbours (self / rank 0 dropped)
+hipError_t launch_knn4(const NNPlan& pl, const void* Q_soa, int32_t* nbr /*[m][4]*/, hipStream_t st);
+// fp32: packed, wave-/segment-split top-5 kernel + merge.  part_* hold splits * n_pad * 5 entries.
+void knn4_v2_geometry(int m, int num_cus, int* n_pad, int* blocks_x, int* splits, int* seg_len);
+hipError_t launch_knn4_v2(const void* Q_soa, int m, int num_cus, float* part_d, int32_t* part_j, int32_t* nbr,
+                          hipStream_t st);
+// covariance of the 4 neighbours + fp64 Jacobi eigen-solve per lane -> padded SoA normals on the device
+hipError_t launch_normals(int precision, const void* Q_soa, int m, int m_pad, const int32_t* nbr, void* Nrm_soa,
+                          hipStream_t st);
+hipError_t launch_os1_packets(const uint8_t* packets, int n_packets, const float* alt16, const float* az16,
+                              uint32_t* ranges, float* xyz_aos, hipStream_t st);
+hipError_t launch_os1_conversion(const uint32_t* ranges, int n, uint32_t encoder0, const float* alt16,
+                                 const float* az16, float* xyz_aos, hipStream_t st);
+
+}  // namespace icp

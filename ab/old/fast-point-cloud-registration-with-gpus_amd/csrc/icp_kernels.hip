@@ -1,0 +1,2819 @@
+// icp_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ICP hot path.
+//
+// Kernel inventory (reference statement each one replaces; file:line relative to the reference):
+//   nn_match_kernel        Matching<<<>>>  src/CUDA/GPU_point_to_point_real.cu:38-79 (fp32),
+//                          MKL matching loop src/ICP_CPU.c:220-234 (fp64)
+//   moments_kernel         Q_index + 2x cublasSgemv + deviation + cublasSgemm
+//                          src/ICP_point_to_point.cu:308-357; Cxb + 2x Sgemv
+//                          src/CUDA/GPU_point_to_plane_real.cu:246-288,532-549
+//   transform_error_kernel RyT + Scopy + Scopy/Saxpy/Snrm2  src/ICP_point_to_point.cu:81-88,403-416
+//   finalize_kernel        (the reductions hidden inside cuBLAS)
+//   knn4_kernel/normals    knn + Normals + host ssyev loop  src/CUDA/GPU_point_to_plane_real.cu:54-188,413-423
+//   os1_conversion_kernel  Conversion     src/CUDA/GPU_point_to_point_real.cu:20-36
+//
+// Numerics contract of the matching kernels: the squared distance is evaluated exactly as the CPU
+// path does -- dx = q-p; dx*dx; (dx2+dy2)+dz2, every operation rounded separately -- so the file is
+// compiled with FP contraction OFF and tests/test_build.py greps the ISA of nn_match_kernel for
+// fma/mad/fmac.  Ties resolve to the lowest model index.
+#include "icp_kernels.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#pragma clang fp contract(off)
+
+namespace icp {
+
+size_t elem_size(int precision) { return precision == ICP_F64 ? sizeof(double) : sizeof(float); }
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+template <typename F> struct Vec16;  // 16-byte vector of F
+template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+
+__device__ __forceinline__ float vget(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ double vget(const double2& v, int i) { return i == 0 ? v.x : v.y; }
+
+__device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double fmin_(double a, double b) { return __builtin_fmin(a, b); }
+
+template <typename F> __device__ __forceinline__ F inf_();
+template <> __device__ __forceinline__ float inf_<float>() { return __builtin_huge_valf(); }
+template <> __device__ __forceinline__ double inf_<double>() { return __builtin_huge_val(); }
+
+// (dx*dx + dy*dy) + dz*dz, each op rounded on its own (contraction is off for this TU)
+template <typename F>
+__device__ __forceinline__ F dist2(F px, F py, F pz, F qx, F qy, F qz)
+{
+    F dx = qx - px;
+    F dy = qy - py;
+    F dz = qz - pz;
+    dx = dx * dx;
+    dy = dy * dy;
+    dz = dz * dz;
+    F d = dx + dy;
+    return d + dz;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-wide sum of NACC per-thread doubles -> out[0..NACC) (written by threads 0..NACC-1).
+// Fixed combination order => bitwise reproducible for a fixed launch geometry.
+template <int NACC, int BLOCK>
+__device__ __forceinline__ void block_sum_store(const double (&acc)[NACC], double* out)
+{
+    constexpr int NW = BLOCK / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if constexpr (NW == 1 && NACC > 2) {
+        // single wave, many slots: transpose through LDS (rows padded to 65 doubles: lane k reads bank 2k)
+        // and let lane k add its slot's 64 entries in lane order -- far fewer cross-lane ops than NACC butterflies
+        __shared__ double tr[NACC][65];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
+        __syncthreads();
+        if (lane < NACC) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int l = 0; l < 64; ++l) s += tr[lane][l];
+            out[lane] = s;
+        }
+        return;
+    }
+    __shared__ double red[NW][NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) red[w][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double s = red[0][threadIdx.x];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) s += red[ww][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion
+// ------------------------------------------------------------------------------------------------
+template <typename F>
+__global__ void aos_to_soa_kernel(const F* __restrict__ aos, int n, int n_pad, F* __restrict__ soa)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    const int s = i < n ? i : n - 1;  // padding replicates the last real point
+    soa[i] = aos[3 * (size_t)s + 0];
+    soa[(size_t)n_pad + i] = aos[3 * (size_t)s + 1];
+    soa[2 * (size_t)n_pad + i] = aos[3 * (size_t)s + 2];
+}
+
+template <typename F>
+__global__ void soa_to_aos_kernel(const F* __restrict__ soa, int n, int n_pad, F* __restrict__ aos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    aos[3 * (size_t)i + 0] = soa[i];
+    aos[3 * (size_t)i + 1] = soa[(size_t)n_pad + i];
+    aos[3 * (size_t)i + 2] = soa[2 * (size_t)n_pad + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// matching
+//
+// grid = (n_pad / (256*T), S).  A block owns 256*T moving points (T per lane, in registers) and one
+// segment [q0, q1) of the model.  The segment streams through LDS in SoA tiles; every lane reads the
+// SAME LDS address (broadcast, conflict-free), 16 bytes per ds_read.
+//
+// The inner loop keeps only the running MINIMUM per moving point (8 rounding-exact VALU ops per
+// pair + a min), not the arg-min: per NN_CHUNK model points one compare records the id of the
+// chunk that last lowered the minimum.  Because the compare is strict, that is the FIRST chunk
+// holding the final minimum; the index is recovered afterwards by re-evaluating just that chunk
+// (16 pairs per moving point) and taking the lowest j with d_j == min.  Same answer as the
+// reference's ascending strict-< scan, ~25% fewer VALU ops per pair.
+// ------------------------------------------------------------------------------------------------
+template <typename F, int T, int TQ>
+__global__ __launch_bounds__(NN_BLOCK) void nn_match_kernel(const F* __restrict__ P, int n_pad,
+                                                            const F* __restrict__ Q, int m_pad, int seg_len,
+                                                            F* __restrict__ part_d, int32_t* __restrict__ part_idx)
+{
+    using V = typename Vec16<F>::type;
+    constexpr int VN = Vec16<F>::N;
+    constexpr int C = NN_CHUNK;
+    __shared__ __attribute__((aligned(16))) F sq[3 * TQ];
+
+    const int q0 = blockIdx.y * seg_len;
+    const int q1 = min(q0 + seg_len, m_pad);
+    const int ibase = blockIdx.x * (NN_BLOCK * T) + threadIdx.x;
+
+    F px[T], py[T], pz[T], best[T];
+    int cst[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int i = ibase + t * NN_BLOCK;
+        px[t] = P[i];
+        py[t] = P[(size_t)n_pad + i];
+        pz[t] = P[2 * (size_t)n_pad + i];
+        best[t] = inf_<F>();
+        cst[t] = q0 / C;
+    }
+
+    for (int tile = q0; tile < q1; tile += TQ) {
+        const int len = min(TQ, q1 - tile);  // multiple of C
+        __syncthreads();
+        for (int e = threadIdx.x * VN; e < len; e += NN_BLOCK * VN) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                *reinterpret_cast<V*>(&sq[a * TQ + e]) =
+                    *reinterpret_cast<const V*>(&Q[(size_t)a * m_pad + tile + e]);
+        }
+        __syncthreads();
+
+        for (int c = 0; c < len; c += C) {
+            F bo[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) bo[t] = best[t];
+#pragma unroll
+            for (int k = 0; k < C; k += VN) {
+                const V qx = *reinterpret_cast<const V*>(&sq[c + k]);
+                const V qy = *reinterpret_cast<const V*>(&sq[TQ + c + k]);
+                const V qz = *reinterpret_cast<const V*>(&sq[2 * TQ + c + k]);
+#pragma unroll
+                for (int v = 0; v < VN; ++v) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const F d = dist2<F>(px[t], py[t], pz[t], vget(qx, v), vget(qy, v), vget(qz, v));
+                        best[t] = fmin_(best[t], d);
+                    }
+                }
+            }
+            const int cid = (tile + c) / C;
+#pragma unroll
+            for (int t = 0; t < T; ++t) cst[t] = (best[t] < bo[t]) ? cid : cst[t];
+        }
+    }
+
+    // index recovery inside the winning chunk (global memory, L2-resident)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int base = cst[t] * C;
+        int idx = base;
+        const F b = best[t];
+        for (int k = C - 1; k >= 0; --k) {
+            const int j = base + k;
+            const F d = dist2<F>(px[t], py[t], pz[t], Q[j], Q[(size_t)m_pad + j], Q[2 * (size_t)m_pad + j]);
+            idx = (d == b) ? j : idx;
+        }
+        const size_t o = (size_t)blockIdx.y * n_pad + ibase + t * NN_BLOCK;
+        part_d[o] = b;
+        part_idx[o] = idx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// matching, fp32, v2 -- the shipped fp32 kernel.
+//
+// What the gfx950 VALU probe (profiles/r1/valu_rate_gfx950.txt) says and how the kernel answers:
+//   * one wave issues a VALU instruction only every ~6 cycles whatever its ILP; a SIMD saturates
+//     at ~8 resident waves  -> <= 64 VGPRs (launch_bounds(256, 8)), 16 KB LDS per block;
+//   * v_pk_add/mul_f32 retire 2 results per issue slot (70 T results/s vs 51 T for plain ops)
+//     -> every sub/mul/add of the distance is a packed op over TWO MOVING POINTS of the lane; the
+//     model coordinate is broadcast into both halves with op_sel straight from the LDS quad,
+//     no v_mov.  Each half is an ordinary IEEE add/mul, so rounding is identical to the scalar form;
+//   * v_cndmask (VCC read) costs ~9 issue slots -> the chunk-id update sits behind a wave-uniform
+//     branch that is skipped while no lane's minimum moved.
+// Small clouds cannot fill 8 waves x 1024 SIMDs along the moving axis, so the model range is split
+// twice: grid.y segments (merged later from the partials) and, inside a block, one contiguous
+// quarter of the segment per wave (merged through LDS in ascending order, strict <, so the lowest
+// index still wins).  All four waves of a block own the SAME 64*T moving points.
+// ------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// (q.lo - p.lo, q.lo - p.hi) / (q.hi - p.lo, q.hi - p.hi): src0 half broadcast by op_sel, src1 negated
+template <int HI>
+__device__ __forceinline__ f2 pk_sub_bcast(f2 q, f2 p)
+{
+    f2 r;
+    if constexpr (HI == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(q), "v"(p));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(q), "v"(p));
+    return r;
+}
+
+template <int HI>
+__device__ __forceinline__ f2 pk_dist2(f2 qx, f2 qy, f2 qz, f2 px, f2 py, f2 pz)
+{
+    f2 dx = pk_sub_bcast<HI>(qx, px);
+    f2 dy = pk_sub_bcast<HI>(qy, py);
+    f2 dz = pk_sub_bcast<HI>(qz, pz);
+    dx = dx * dx;
+    dy = dy * dy;
+    dz = dz * dz;
+    f2 d = dx + dy;
+    return d + dz;
+}
+
+// One wave passing data to itself through LDS: DS instructions of a wave execute in order, so all that is needed is
+// that the COMPILER keeps the order (and does not cache the values in registers).  A workgroup-scope fence would also
+// drain the wave's global stores (s_waitcnt vmcnt(0)) -- ~1 us of idle time in the matching kernel's tail.
+__device__ __forceinline__ void lds_same_wave_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// An index the compiler must treat as new: keeps it from hoisting the per-lane 64-bit addresses derived from a
+// loop-invariant index out of the resident kernel's pass loop (a dozen register pairs held for nothing -- it spilled).
+__device__ __forceinline__ int fresh(int i) { asm volatile("" : "+v"(i)); return i; }
+
+// wave-wide min / max of a float by DPP (no LDS): row_shr 1,2,4,8 leave each row's result in its lane 15
+// (min/max are idempotent, overlapping windows are harmless), row_bcast15/31 carry it to lane 63.
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax(float v)
+{
+    // written as DPP-fused instructions (the compiler would spend seven per step); s_nop 1 covers the
+    // VALU-write -> DPP-read hazard, lanes without a source keep their value
+#define ICP_DPP_STEP(CTRL)                                                                       \
+    if constexpr (MAX) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL : "+v"(v));   \
+    else asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL : "+v"(v));
+    ICP_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+    ICP_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+    ICP_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+    ICP_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+    ICP_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    ICP_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef ICP_DPP_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// bounding box of the wave's values: three minima and three maxima reduced together, so that the six dependent DPP
+// chains overlap (every DPP reads a register written six instructions earlier: no wait states except the first)
+__device__ __forceinline__ void wave_box(float (&lo)[3], float (&hi)[3])
+{
+#define ICP_BOX_STEP(CTRL)                                                                                      \
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL "\n\tv_min_f32_dpp %1, %1, %1 " CTRL "\n\tv_min_f32_dpp %2, %2, %2 " CTRL \
+                 "\n\tv_max_f32_dpp %3, %3, %3 " CTRL "\n\tv_max_f32_dpp %4, %4, %4 " CTRL "\n\tv_max_f32_dpp %5, %5, %5 " CTRL        \
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]));
+    ICP_BOX_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+    ICP_BOX_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+    ICP_BOX_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+    ICP_BOX_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+    ICP_BOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    ICP_BOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef ICP_BOX_STEP
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo[a]), 63));
+        hi[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi[a]), 63));
+    }
+}
+
+constexpr int NN2_TQW = 256;  // model points per wave per LDS tile step
+
+// One chunk of C model points against the lane's packed moving points, with the xy early-out:
+// phase A forms pxy = dx*dx + dy*dy (the inner sum of the reference's association) for the whole chunk;
+// d = fl(pxy + dz*dz) >= pxy, so a chunk whose smallest pxy is not below any lane's running minimum cannot
+// lower it (nor win a tie: ascending order, strict <) and its z half is skipped; phase B finishes the chunk
+// exactly as the un-culled kernel would have.
+template <int TP, int C>
+__device__ __forceinline__ void scan_chunk_xy_cull(const float* qxp, const float* qyp, const float* qzp, const f2 (&px)[TP],
+                                                   const f2 (&py)[TP], const f2 (&pz)[TP], float (&best)[2 * TP])
+{
+    f2 pxy[TP][C];
+    float mxy[2 * TP];
+#pragma unroll
+    for (int t = 0; t < 2 * TP; ++t) mxy[t] = inf_<float>();
+#pragma unroll
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qx4 = *reinterpret_cast<const float4*>(qxp + kk);
+        const float4 qy4 = *reinterpret_cast<const float4*>(qyp + kk);
+        const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+        const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            f2 ax, ay;
+            ax = pk_sub_bcast<0>(qxa, px[u]); ay = pk_sub_bcast<0>(qya, py[u]);
+            pxy[u][kk + 0] = ax * ax + ay * ay;
+            ax = pk_sub_bcast<1>(qxa, px[u]); ay = pk_sub_bcast<1>(qya, py[u]);
+            pxy[u][kk + 1] = ax * ax + ay * ay;
+            ax = pk_sub_bcast<0>(qxb, px[u]); ay = pk_sub_bcast<0>(qyb, py[u]);
+            pxy[u][kk + 2] = ax * ax + ay * ay;
+            ax = pk_sub_bcast<1>(qxb, px[u]); ay = pk_sub_bcast<1>(qyb, py[u]);
+            pxy[u][kk + 3] = ax * ax + ay * ay;
+            mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk].x), pxy[u][kk + 1].x);
+            mxy[2 * u] = fmin_(fmin_(mxy[2 * u], pxy[u][kk + 2].x), pxy[u][kk + 3].x);
+            mxy[2 * u + 1] = fmin_(fmin_(mxy[2 * u + 1], pxy[u][kk].y), pxy[u][kk + 1].y);
+            mxy[2 * u + 1] = fmin_(fmin_(mxy[2 * u + 1], pxy[u][kk + 2].y), pxy[u][kk + 3].y);
+        }
+    }
+    bool need = false;
+#pragma unroll
+    for (int t = 0; t < 2 * TP; ++t) need |= mxy[t] < best[t];
+    if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;  // wave-uniform early-out
+#pragma unroll
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qz4 = *reinterpret_cast<const float4*>(qzp + kk);
+        const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            f2 az;
+            az = pk_sub_bcast<0>(qza, pz[u]); const f2 d0 = pxy[u][kk + 0] + az * az;
+            az = pk_sub_bcast<1>(qza, pz[u]); const f2 d1 = pxy[u][kk + 1] + az * az;
+            az = pk_sub_bcast<0>(qzb, pz[u]); const f2 d2 = pxy[u][kk + 2] + az * az;
+            az = pk_sub_bcast<1>(qzb, pz[u]); const f2 d3 = pxy[u][kk + 3] + az * az;
+            best[2 * u] = fmin_(fmin_(best[2 * u], d0.x), d1.x);
+            best[2 * u] = fmin_(fmin_(best[2 * u], d2.x), d3.x);
+            best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d0.y), d1.y);
+            best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d2.y), d3.y);
+        }
+    }
+}
+
+// lower bound of every reference distance between the lane's points and a box: per axis
+// g = max(lo - p, p - hi, 0) <= |q - p| for every q inside, rounding is monotonic, and L uses the reference's own
+// association (gx*gx + gy*gy) + gz*gz, so L <= d operation by operation; the 2^-20 shave is belt and braces.
+template <int TP, bool LE = false /*ties count: the chunks are not visited in ascending order*/>
+__device__ __forceinline__ bool box_may_improve(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                                const f2 (&px)[TP], const f2 (&py)[TP], const f2 (&pz)[TP],
+                                                const float (&best)[2 * TP])
+{
+    bool needb = false;
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        const f2 ax = f2{lox, lox} - px[u], bxx = px[u] - f2{hix, hix};
+        const f2 ay = f2{loy, loy} - py[u], byy = py[u] - f2{hiy, hiy};
+        const f2 az = f2{loz, loz} - pz[u], bzz = pz[u] - f2{hiz, hiz};
+        f2 gx = f2{__builtin_fmaxf(__builtin_fmaxf(ax.x, bxx.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ax.y, bxx.y), 0.f)};
+        f2 gy = f2{__builtin_fmaxf(__builtin_fmaxf(ay.x, byy.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ay.y, byy.y), 0.f)};
+        f2 gz = f2{__builtin_fmaxf(__builtin_fmaxf(az.x, bzz.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(az.y, bzz.y), 0.f)};
+        f2 L = (gx * gx + gy * gy) + gz * gz;
+        L = L * f2{0.99999905f, 0.99999905f};  // 1 - 2^-20
+        if constexpr (LE) needb |= (L.x <= best[2 * u]) | (L.y <= best[2 * u + 1]);
+        else needb |= (L.x < best[2 * u]) | (L.y < best[2 * u + 1]);
+    }
+    return needb;
+}
+
+// Optional fused TAIL of the matching kernel (TAIL = 1 point-to-point, 2 point-to-plane): instead of leaving
+// per-segment (d, idx) partials for a second kernel, every block folds its result into one 64-bit key per moving
+// point with a device-scope atomic min -- key = (float bits of d) << 32 | idx, so the integer order IS the
+// lexicographic (d, idx) order the tie rule needs -- then draws a ticket for its row of moving points.  The block
+// that draws the last ticket of a row (all S segment blocks have contributed) reads the final keys, stores idx,
+// gathers q (and the normal) and produces the row's moment sums: the work of moments_kernel without a second
+// launch, a dependent dispatch or the partial arrays.  Protocol (agent scope, placement independent): the payload
+// is written ONLY by agent-scope atomics; every wave drains them (s_waitcnt vmcnt(0)) and the block barriers
+// before one lane adds the ticket; the last arriver reads the keys back with agent-scope atomic loads.
+struct NNTail {
+    unsigned long long* keys;  // [n_pad], all ones between launches (the last block of a row resets them)
+    unsigned int* tickets;     // [gridDim.x], zero between launches (reset by the last block)
+    double* err_tile;          // [gridDim.x] device: error of the fused transform, from the grid.y == 0 block
+    int32_t* idx_out;          // [n_pad]
+    int32_t* idx_out_odd;      // resident launch: the odd passes' correspondences (ping-pong with idx_out)
+    const float* Nrm;          // model normals (SoA, m_pad) for TAIL == 2
+    double* rows;              // [gridDim.x][ICP_NMOM]: pinned host (single GPU) or device (finalize follows)
+    double tag;                // completion tag stored in slot ICP_NMOM-1 of the row
+};
+
+// rigid motion applied to the moving cloud; travels by value in the kernel-argument segment
+template <typename F> struct RT { F r[9]; F t[3]; };
+
+// ((r0*x + r1*y) + r2*z) + t with separately rounded products and sums -- the association of RyT
+// (src/ICP_point_to_point.cu:85).  One definition for every kernel that moves points, so the fused
+// and the stand-alone transform produce the same bits.
+template <typename F>
+__device__ __forceinline__ void apply_rt(const RT<F>& rt, F x, F y, F z, F& ox, F& oy, F& oz)
+{
+    F o[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        F c = rt.r[a * 3 + 0] * x;
+        c = c + rt.r[a * 3 + 1] * y;
+        c = c + rt.r[a * 3 + 2] * z;
+        o[a] = c + rt.t[a];
+    }
+    ox = o[0]; oy = o[1]; oz = o[2];
+}
+
+// optional fused front end of the matching kernel: the transform of the PREVIOUS pass
+struct NNFuse {
+    int apply;               // 0: match P as it is
+    int n;                   // real moving points (the error and the seeds skip the padding)
+    int m;                   // real model points (seed validation)
+    const int32_t* idx_prev; // correspondences the applied (R, t) came from
+    float* P_out;            // transformed cloud (written by the grid.y == 0 blocks only)
+    double* err_rows;        // [gridDim.x] sum |p_new - q[idx_prev]|^2 per block
+    const int32_t* seed_idx; // CULL kernels: any valid model index per moving point (or NULL); it only
+                             // tightens the starting bound, the result does not depend on it
+    const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
+    const float* boxes;      // CULL kernels: per 8-point chunk of the scan copy {lo.xyz, hi.xyz, -, -} (or NULL)
+    int sample_groups;       // sparse kernel: at most this many groups of 8 samples are used by the cold start (<= 256)
+    const int32_t* q_perm;   // sparse kernel: the scan copy is spatially sorted; q_perm[sorted j] = model index (NULL: identity)
+    const int32_t* p_perm;   // sparse kernel: slot -> moving point handled there (spatially sorted groups; NULL: identity)
+    int store_first;         // resident launch reading a pristine copy: pass 0 stores the cloud to P_out even without a transform
+    int resident;            // resident launch: after a pass the block waits for the next message instead of ending
+    NNMailbox* relay;        // ... relayed by block 0 to the other blocks through this device-memory copy
+    const NNMailbox* mailbox; // armed launch (sparse kernel): (R, t) arrive here from the host AFTER the kernel was enqueued
+    double want;             // ... under this sequence number (+want: go, -want: withdrawn)
+    const float* samples;    // sparse kernel: one point per chunk of the scan copy (SoA, round_up(m_pad/8, 8) entries) or NULL
+    long long* tlog;         // diagnostic (ICP_NN_PHASES): per-wave s_memrealtime stamps, 10 slots per wave, or NULL
+    long long tlog_cap;      // slots available
+    int tlog_pass;           // resident launch: stamp this pass only (-1: every pass, the last one survives)
+};
+
+// phase stamp of the diagnostic log: one scalar branch when the log is off
+#define ICP_PHASE(PH)                                                                                              \
+    if constexpr (phase_diag_) if (fuse.tlog != nullptr && lane == 0 && (fuse.tlog_pass < 0 || fuse.tlog_pass == phase_pass_)) {                                                                       \
+        const long long slot_ = (((long long)blockIdx.y * gridDim.x + blockIdx.x) * phase_nw_ + w) * 10 + (PH);                     \
+        if (slot_ < fuse.tlog_cap) fuse.tlog[slot_] = (long long)wall_clock64();                                   \
+    }
+
+template <int T /*2 or 4*/, int C /*chunk: 8 or 16*/, int CULL /*0: plain; 1: seeded bound + box/xy early-out over LDS tiles*/, int TAIL = 0>
+__global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(const float* __restrict__ P, int n_pad,
+                                                               const float* __restrict__ Q, int m_pad, int seg_len,
+                                                               float* __restrict__ part_d,
+                                                               int32_t* __restrict__ part_idx, RT<float> rt,
+                                                               NNFuse fuse, NNTail tail)
+{
+    constexpr int TP = T / 2;  // packed pairs of moving points per lane
+    // one raw LDS block, carved by hand: the tail's transpose buffer overlays the tile + merge scratch
+    constexpr int SQ_BYTES = 4 * 3 * NN2_TQW * 4, MD_BYTES = 4 * 64 * T * 4;
+    constexpr int TR_BYTES = TAIL ? (TAIL == 2 ? 28 : 18) * 65 * 8 : 0;
+    constexpr int LDS_BYTES = (SQ_BYTES + 2 * MD_BYTES + 16) > TR_BYTES ? (SQ_BYTES + 2 * MD_BYTES + 16) : TR_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    float (*sq)[3][NN2_TQW] = reinterpret_cast<float (*)[3][NN2_TQW]>(lds_raw);
+    float (*md)[64 * T] = reinterpret_cast<float (*)[64 * T]>(lds_raw + SQ_BYTES);
+    int (*mi)[64 * T] = reinterpret_cast<int (*)[64 * T]>(lds_raw + SQ_BYTES + MD_BYTES);
+    int* s_flag = reinterpret_cast<int*>(lds_raw + SQ_BYTES + 2 * MD_BYTES);
+
+    const int lane = threadIdx.x & 63;
+    // the wave id as a SCALAR: everything derived from it (ranges, loop bounds, the box addresses) then lives in
+    // SGPRs, the loops are scalar loops and the per-chunk boxes arrive through the scalar cache
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int phase_pass_ = 0, phase_nw_ = 4;  // (phase log)
+    constexpr bool phase_diag_ = true;
+    const int wseg = seg_len >> 2;              // model points per wave (multiple of C)
+    const int q0 = blockIdx.y * seg_len;
+    const int my0 = q0 + w * wseg;
+    const int my1 = min(my0 + wseg, m_pad);     // may be <= my0: this wave's range is empty
+    const int ibase = blockIdx.x * (64 * T) + lane;
+
+    f2 px[TP], py[TP], pz[TP];
+    float best[T];
+    int cst[T];
+    ICP_PHASE(0)
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        const int i0 = ibase + (2 * u) * 64, i1 = i0 + 64;
+        px[u] = f2{P[i0], P[i1]};
+        py[u] = f2{P[(size_t)n_pad + i0], P[(size_t)n_pad + i1]};
+        pz[u] = f2{P[2 * (size_t)n_pad + i0], P[2 * (size_t)n_pad + i1]};
+    }
+    if (fuse.apply) {
+        // every block re-derives the moved points in registers (same instructions => same bits);
+        // the grid.y == 0 row stores them and accounts the error of the pass that produced (R, t)
+        double err = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int u = t >> 1;
+            float x = (t & 1) ? px[u].y : px[u].x, y = (t & 1) ? py[u].y : py[u].x, z = (t & 1) ? pz[u].y : pz[u].x;
+            apply_rt<float>(rt, x, y, z, x, y, z);
+            if (t & 1) { px[u].y = x; py[u].y = y; pz[u].y = z; } else { px[u].x = x; py[u].x = y; pz[u].x = z; }
+            if (blockIdx.y == 0 && w == 0) {
+                const int i = ibase + t * 64;
+                fuse.P_out[i] = x;
+                fuse.P_out[(size_t)n_pad + i] = y;
+                fuse.P_out[2 * (size_t)n_pad + i] = z;
+                if (i < fuse.n) {
+                    const int j = fuse.idx_prev[i];
+                    const float* Qg = fuse.Q_gather;
+                    const double ex = (double)Qg[j] - (double)x;
+                    const double ey = (double)Qg[(size_t)m_pad + j] - (double)y;
+                    const double ez = (double)Qg[2 * (size_t)m_pad + j] - (double)z;
+                    err += ex * ex + ey * ey + ez * ez;
+                }
+            }
+        }
+        if (blockIdx.y == 0 && w == 0) {
+            err = wave_sum(err);
+            if (lane == 0) {
+                if constexpr (TAIL != 0)  // read by whichever block closes this row: agent-scope store, drained before our ticket
+                    __hip_atomic_store(&tail.err_tile[blockIdx.x], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    fuse.err_rows[blockIdx.x] = err;
+            }
+        }
+    }
+    ICP_PHASE(1)
+#pragma unroll
+    for (int t = 0; t < T; ++t) { best[t] = inf_<float>(); cst[t] = -1; }
+    if constexpr (CULL) {
+        // Seeded bound: start from the distance to ANY model point (last pass's match) bumped by one ulp.
+        // The true minimum is <= that distance < bound, so the ordinary ascending strict-< scan still ends
+        // on the first index of the minimum -- the seed changes how much work is skipped, never the answer.
+        if (fuse.seed_idx) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int u = t >> 1;
+                const float x = (t & 1) ? px[u].y : px[u].x, y = (t & 1) ? py[u].y : py[u].x, z = (t & 1) ? pz[u].y : pz[u].x;
+                // padding lanes (i >= n) have no previous match, and a seed is trusted only if it is a
+                // real model index: anything else simply starts unbounded
+                const int i = ibase + t * 64;
+                int j = (i < fuse.n) ? fuse.seed_idx[i] : -1;
+                const bool ok = (unsigned)j < (unsigned)fuse.m;
+                j = ok ? j : 0;
+                const float* Qg = fuse.Q_gather;
+                const float d = dist2<float>(x, y, z, Qg[j], Qg[(size_t)m_pad + j], Qg[2 * (size_t)m_pad + j]);
+                // next float above d (d >= 0, finite): bit pattern + 1; inf stays inf
+                best[t] = (ok && d < inf_<float>()) ? __uint_as_float(__float_as_uint(d) + 1u) : inf_<float>();
+                // padding lanes can never improve on a bound of zero: they cost no chunk visits (their result,
+                // "nothing found", is never read)
+                best[t] = (i < fuse.n) ? best[t] : 0.f;
+            }
+        }
+    }
+
+    ICP_PHASE(2)
+    {
+    const int ntile = (wseg + NN2_TQW - 1) / NN2_TQW;
+    for (int k = 0; k < ntile; ++k) {
+        __syncthreads();
+        // cooperative fill of the four per-wave sub-tiles: 4 x 3 x 256 floats = 768 float4, 3 per thread
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int v = threadIdx.x + r * NN_BLOCK;      // 0..767
+            const int ww = v / 192, rem = v % 192;         // 192 float4 per wave sub-tile
+            const int a = rem / 64, e = (rem % 64) * 4;    // coordinate array, element offset
+            const int off = k * NN2_TQW + e;               // offset inside the wave's range
+            const int src = q0 + ww * wseg + off;
+            if (off < wseg && src < m_pad)
+                *reinterpret_cast<float4*>(&sq[ww][a][e]) = *reinterpret_cast<const float4*>(&Q[(size_t)a * m_pad + src]);
+        }
+        __syncthreads();
+
+        const int tile0 = my0 + k * NN2_TQW;
+        const int len = min(NN2_TQW, my1 - tile0);  // multiple of C, <= 0 when exhausted
+        for (int c = 0; c < len; c += C) {
+            float bo[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) bo[t] = best[t];
+            if constexpr (CULL) {
+                // level 0: the chunk's bounding box (precomputed once per model over the scan copy): ~20 VALU ops
+                // per chunk and lane pair instead of ~50, wave-uniform skip; then the xy early-out
+                if (fuse.boxes) {
+                    const float* bx = fuse.boxes + (size_t)((tile0 + c) / C) * 8;  // scalar address -> s_load
+                    if (__builtin_amdgcn_ballot_w64(box_may_improve<TP>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], px, py, pz, best)) == 0ull)
+                        continue;
+                }
+                scan_chunk_xy_cull<TP, C>(&sq[w][0][c], &sq[w][1][c], &sq[w][2][c], px, py, pz, best);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < C; kk += 4) {
+                    const float4 qx4 = *reinterpret_cast<const float4*>(&sq[w][0][c + kk]);
+                    const float4 qy4 = *reinterpret_cast<const float4*>(&sq[w][1][c + kk]);
+                    const float4 qz4 = *reinterpret_cast<const float4*>(&sq[w][2][c + kk]);
+                    const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+                    const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+                    const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) {
+                        const f2 d0 = pk_dist2<0>(qxa, qya, qza, px[u], py[u], pz[u]);
+                        const f2 d1 = pk_dist2<1>(qxa, qya, qza, px[u], py[u], pz[u]);
+                        const f2 d2 = pk_dist2<0>(qxb, qyb, qzb, px[u], py[u], pz[u]);
+                        const f2 d3 = pk_dist2<1>(qxb, qyb, qzb, px[u], py[u], pz[u]);
+                        best[2 * u] = fmin_(fmin_(best[2 * u], d0.x), d1.x);
+                        best[2 * u] = fmin_(fmin_(best[2 * u], d2.x), d3.x);
+                        best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d0.y), d1.y);
+                        best[2 * u + 1] = fmin_(fmin_(best[2 * u + 1], d2.y), d3.y);
+                    }
+                }
+            }
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < T; ++t) any |= best[t] < bo[t];
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // wave-uniform: skipped while no minimum moved
+                const int cid = (tile0 + c) / C;
+#pragma unroll
+                for (int t = 0; t < T; ++t) cst[t] = (best[t] < bo[t]) ? cid : cst[t];
+            }
+        }
+    }
+    }  // tile scan
+    ICP_PHASE(3)
+
+    // index recovery inside the winning chunk (lowest j with d_j == min), then the in-block merge
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float pxt = (t & 1) ? px[t >> 1].y : px[t >> 1].x;
+        const float pyt = (t & 1) ? py[t >> 1].y : py[t >> 1].x;
+        const float pzt = (t & 1) ? pz[t >> 1].y : pz[t >> 1].x;
+        const bool found = cst[t] >= 0;  // this wave's range lowered the (possibly seeded) bound at least once
+        const int base = found ? cst[t] * C : 0;
+        int idx = 0x7fffffff;
+        const float b = found ? best[t] : inf_<float>();
+        if (found) {
+            idx = base;
+#pragma unroll 4
+            for (int kk = C - 1; kk >= 0; --kk) {
+                const int j = base + kk;
+                const float d = dist2<float>(pxt, pyt, pzt, Q[j], Q[(size_t)m_pad + j], Q[2 * (size_t)m_pad + j]);
+                idx = (d == b) ? j : idx;
+            }
+        }
+        md[w][lane + t * 64] = b;
+        mi[w][lane + t * 64] = idx;
+    }
+    ICP_PHASE(4)
+    __syncthreads();
+    ICP_PHASE(5)
+    if (threadIdx.x < 64 * T) {
+        float b = md[0][threadIdx.x];
+        int bi = mi[0][threadIdx.x];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const float d = md[ww][threadIdx.x];
+            const int j = mi[ww][threadIdx.x];
+            if (d < b) { b = d; bi = j; }
+        }
+        if constexpr (TAIL == 0) {
+            const size_t o = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * (64 * T) + threadIdx.x;
+            part_d[o] = b;
+            part_idx[o] = bi;
+        } else {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(b) << 32) | (unsigned int)bi;
+            __hip_atomic_fetch_min(&tail.keys[(size_t)blockIdx.x * (64 * T) + threadIdx.x], key, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (TAIL != 0) {
+        static_assert(TAIL == 0 || T == 2, "the fused tail is written for two moving points per lane");
+        // every wave drains its atomics, the block meets, one lane draws the row's ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ICP_PHASE(6)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int ticket = __hip_atomic_fetch_add(&tail.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_flag = (ticket == gridDim.y - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        ICP_PHASE(7)
+        if (*s_flag == 0 || w != 0) return;  // only wave 0 of the row's last block goes on (the LDS is all its own now)
+
+        constexpr int NACC = TAIL == 2 ? 28 : 18;
+        double acc[NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+        const float* Qg = fuse.Q_gather;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = ibase + t * 64;
+            const unsigned long long key = __hip_atomic_load(&tail.keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail.keys[i] = ~0ull;  // ready for the next launch (nobody touches this row again in this one)
+            int j = (int)(unsigned int)(key & 0xffffffffull);
+            j = ((unsigned)j < (unsigned)fuse.m) ? j : fuse.m - 1;  // unreachable clamp, keeps idx in range by construction
+            if (i < fuse.n) {
+                tail.idx_out[i] = j;
+                const double ppx = (double)(t ? px[0].y : px[0].x), ppy = (double)(t ? py[0].y : py[0].x),
+                             ppz = (double)(t ? pz[0].y : pz[0].x);
+                const double qx = (double)Qg[j], qy = (double)Qg[(size_t)m_pad + j], qz = (double)Qg[2 * (size_t)m_pad + j];
+                acc[0] += 1.0;
+                if constexpr (TAIL == 1) {
+                    acc[1] += ppx; acc[2] += ppy; acc[3] += ppz;
+                    acc[4] += qx; acc[5] += qy; acc[6] += qz;
+                    acc[7] += qx * ppx; acc[8] += qx * ppy; acc[9] += qx * ppz;
+                    acc[10] += qy * ppx; acc[11] += qy * ppy; acc[12] += qy * ppz;
+                    acc[13] += qz * ppx; acc[14] += qz * ppy; acc[15] += qz * ppz;
+                    acc[16] += ppx * ppx + ppy * ppy + ppz * ppz;
+                    acc[17] += qx * qx + qy * qy + qz * qz;
+                } else {
+                    const double nx = (double)tail.Nrm[j], ny = (double)tail.Nrm[(size_t)m_pad + j],
+                                 nz = (double)tail.Nrm[2 * (size_t)m_pad + j];
+                    double cn[6];
+                    cn[0] = ppy * nz - ppz * ny;
+                    cn[1] = ppz * nx - ppx * nz;
+                    cn[2] = ppx * ny - ppy * nx;
+                    cn[3] = nx; cn[4] = ny; cn[5] = nz;
+                    const double bb = (ppx - qx) * nx + (ppy - qy) * ny + (ppz - qz) * nz;
+                    int o = 1;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int c2 = a; c2 < 6; ++c2) acc[o++] += cn[a] * cn[c2];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) acc[22 + a] -= cn[a] * bb;
+                }
+            }
+        }
+        // one wave: transpose through LDS (rows padded to 65 doubles), lane k adds slot k in lane order
+        double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // same wave: DS ops are in order; this pins the compiler
+        double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
+        if (lane < NACC) {
+            double sum = 0.0;
+#pragma unroll 8
+            for (int l = 0; l < 64; ++l) sum += tr[lane][l];
+            row[1 + lane] = sum;
+        }
+        if (lane == 0) {
+            row[ICP_MOM_ERR] = fuse.apply ? __hip_atomic_load(&tail.err_tile[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            tail.tickets[blockIdx.x] = 0u;
+        }
+        __threadfence_system();  // the row is visible to a polling host before its tag
+        if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], tail.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ICP_PHASE(8)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// matching, fp32, sparse -- the shipped kernel whenever the model has chunk boxes.
+//
+// The phase log of the tiled early-out kernel (ICP_NN_PHASES) showed what was left once ~99 % of the chunks
+// were being skipped: the chunks that do survive all sit in the range of ONE wave of the 64 that share a group
+// of moving points, and that wave worked through them alone (median scan 1 us, slowest 17 us of a 27 us kernel).
+// This kernel separates FINDING the surviving chunks from PROCESSING them:
+//   * a block is SP_NW waves that all hold the same 128 moving points (two per lane, packed);
+//   * find: the bounding box G of the 128 points and their largest running bound B are wave-uniform, so the
+//     test "chunk box closer to G than B" runs lane-parallel -- lane l tests chunk l, 64 chunks per ~25 VALU ops;
+//     survivors are appended to a hit list in LDS;
+//   * process: the hits are dealt round-robin to the waves.  Each goes through the per-point box test and the
+//     xy early-out as before; its coordinates arrive through the scalar cache (wave-uniform address).
+// The list is unordered (atomic append), so the tie rule is explicit here instead of implied by scan order:
+// a chunk takes a point's minimum if its own minimum is smaller, or equal with a lower chunk number; the
+// pruning tests therefore let ties through (<=).  Between rounds of the find step the waves exchange their
+// minima through LDS and restart from the best one bumped by an ulp (the seeded-bound argument again), which is
+// what makes an unseeded (cold) pass converge quickly too.  Results are bit-identical to the plain scan.
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_NW = 16;                       // waves per block
+constexpr int SP_HCAP = 4096;                   // hit-list entries = chunks per round (SP_NW * 64 * passes <= this)
+constexpr int SP_MAX_PASSES = SP_HCAP / (SP_NW * 64);
+
+// one hit chunk against the lane's packed pair; (best, bj) follow the lexicographic (distance, MODEL index) rule:
+// the chunk takes a point's minimum if its own minimum is smaller, or equal with a lower model index.
+// `sb` is the hit's LDS stage {box 8, x 8, y 8, z 8, model index 8}, read level by level: most hits end at the box
+// test or at the xy early-out, and with many hits per wave the 16 waves share the LDS bandwidth (reading a hit in
+// one go was measured: no gain on the hall scan, 13 % slower on the hit-heavy grid).
+// PERM: the scan copy is a sorted view, element k of the chunk is model point qo[k] (looked at only on the rare path
+// where the chunk's minimum reaches the running one); else it is point ch * 8 + k and "lowest model index" is
+// simply "lowest k".
+template <bool PERM>
+__device__ __forceinline__ void scan_hit(const float* sb, int ch, const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
+                                         float (&bq)[2][3])
+{
+    constexpr int C = 8;
+    {
+        // level 0: the chunk's bounding box against each of the lane's points (ties pass: the hits are unordered)
+        const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
+        if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull) return;
+    }
+    const float *qxp = sb + 8, *qyp = sb + 16, *qzp = sb + 24;
+    f2 d[C];  // first dx*dx + dy*dy (the inner sum of the reference's association), then the distances
+    float mxy0 = inf_<float>(), mxy1 = inf_<float>();
+#pragma unroll
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qx4 = *reinterpret_cast<const float4*>(qxp + kk);
+        const float4 qy4 = *reinterpret_cast<const float4*>(qyp + kk);
+        const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+        const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+        f2 ax, ay;
+        ax = pk_sub_bcast<0>(qxa, px); ay = pk_sub_bcast<0>(qya, py);
+        d[kk + 0] = ax * ax + ay * ay;
+        ax = pk_sub_bcast<1>(qxa, px); ay = pk_sub_bcast<1>(qya, py);
+        d[kk + 1] = ax * ax + ay * ay;
+        ax = pk_sub_bcast<0>(qxb, px); ay = pk_sub_bcast<0>(qyb, py);
+        d[kk + 2] = ax * ax + ay * ay;
+        ax = pk_sub_bcast<1>(qxb, px); ay = pk_sub_bcast<1>(qyb, py);
+        d[kk + 3] = ax * ax + ay * ay;
+        mxy0 = fmin_(fmin_(mxy0, d[kk].x), d[kk + 1].x);
+        mxy0 = fmin_(fmin_(mxy0, d[kk + 2].x), d[kk + 3].x);
+        mxy1 = fmin_(fmin_(mxy1, d[kk].y), d[kk + 1].y);
+        mxy1 = fmin_(fmin_(mxy1, d[kk + 2].y), d[kk + 3].y);
+    }
+    // d = fl(pxy + dz*dz) >= pxy: a chunk whose smallest pxy is above every lane's minimum cannot matter (ties pass)
+    if (__builtin_amdgcn_ballot_w64((mxy0 <= best[0]) | (mxy1 <= best[1])) == 0ull) return;
+    float c0 = inf_<float>(), c1 = inf_<float>();  // the chunk's own minima
+#pragma unroll
+    for (int kk = 0; kk < C; kk += 4) {
+        const float4 qz4 = *reinterpret_cast<const float4*>(qzp + kk);
+        const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+        f2 az;
+        az = pk_sub_bcast<0>(qza, pz); d[kk + 0] = d[kk + 0] + az * az;
+        az = pk_sub_bcast<1>(qza, pz); d[kk + 1] = d[kk + 1] + az * az;
+        az = pk_sub_bcast<0>(qzb, pz); d[kk + 2] = d[kk + 2] + az * az;
+        az = pk_sub_bcast<1>(qzb, pz); d[kk + 3] = d[kk + 3] + az * az;
+        c0 = fmin_(fmin_(c0, d[kk].x), d[kk + 1].x);
+        c0 = fmin_(fmin_(c0, d[kk + 2].x), d[kk + 3].x);
+        c1 = fmin_(fmin_(c1, d[kk].y), d[kk + 1].y);
+        c1 = fmin_(fmin_(c1, d[kk + 2].y), d[kk + 3].y);
+    }
+    if constexpr (PERM) {
+        const bool cand0 = c0 <= best[0], cand1 = c1 <= best[1];
+        if (__builtin_amdgcn_ballot_w64(cand0 | cand1) != 0ull) {
+            // lowest model index among the chunk elements at the chunk's minimum, and where it sits
+            const int* qo = reinterpret_cast<const int*>(sb + 32);
+            int o0 = 0x7fffffff, o1 = 0x7fffffff, k0 = 0, k1 = 0;
+#pragma unroll
+            for (int kk = C - 1; kk >= 0; --kk) {
+                const int oj = qo[kk];  // wave-uniform address: one broadcast read
+                const bool e0 = (d[kk].x == c0) & (oj < o0), e1 = (d[kk].y == c1) & (oj < o1);
+                o0 = e0 ? oj : o0; k0 = e0 ? kk : k0;
+                o1 = e1 ? oj : o1; k1 = e1 ? kk : k1;
+            }
+            const bool take0 = cand0 & ((c0 < best[0]) | (bj[0] < 0) | (o0 < bj[0]));  // bj < 0: nothing to tie with yet
+            const bool take1 = cand1 & ((c1 < best[1]) | (bj[1] < 0) | (o1 < bj[1]));
+            best[0] = take0 ? c0 : best[0];
+            bj[0] = take0 ? o0 : bj[0];
+            best[1] = take1 ? c1 : best[1];
+            bj[1] = take1 ? o1 : bj[1];
+            if (take0) { bq[0][0] = qxp[k0]; bq[0][1] = qyp[k0]; bq[0][2] = qzp[k0]; }
+            if (take1) { bq[1][0] = qxp[k1]; bq[1][1] = qyp[k1]; bq[1][2] = qzp[k1]; }
+        }
+    } else {
+        // identity order: chunks are disjoint index ranges, "lower model index" is "lower chunk, then lower k"
+        const bool take0 = (c0 < best[0]) | ((c0 == best[0]) & (ch < (bj[0] >> 3)));  // bj = -1: nothing to tie with
+        const bool take1 = (c1 < best[1]) | ((c1 == best[1]) & (ch < (bj[1] >> 3)));
+        if (__builtin_amdgcn_ballot_w64(take0 | take1) != 0ull) {
+            int k0 = C - 1, k1 = C - 1;
+#pragma unroll
+            for (int kk = C - 2; kk >= 0; --kk) {
+                k0 = (d[kk].x == c0) ? kk : k0;
+                k1 = (d[kk].y == c1) ? kk : k1;
+            }
+            best[0] = take0 ? c0 : best[0];
+            bj[0] = take0 ? ch * C + k0 : bj[0];
+            best[1] = take1 ? c1 : best[1];
+            bj[1] = take1 ? ch * C + k1 : bj[1];
+            // the coordinates of the new minimum are at hand (LDS stage): keeping them saves the closing wave a
+            // dependent gather from global memory
+            if (take0) { bq[0][0] = qxp[k0]; bq[0][1] = qyp[k0]; bq[0][2] = qzp[k0]; }
+            if (take1) { bq[1][0] = qxp[k1]; bq[1][1] = qyp[k1]; bq[1][2] = qzp[k1]; }
+        }
+    }
+}
+
+// distances from the lane's packed pair to 8 model points, folded into running minima (no index)
+__device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, const float4 qy0, const float4 qy1,
+                                          const float4 qz0, const float4 qz1, const f2 px, const f2 py, const f2 pz,
+                                          float (&best)[2])
+{
+    const f2 qx[4] = {f2{qx0.x, qx0.y}, f2{qx0.z, qx0.w}, f2{qx1.x, qx1.y}, f2{qx1.z, qx1.w}};
+    const f2 qy[4] = {f2{qy0.x, qy0.y}, f2{qy0.z, qy0.w}, f2{qy1.x, qy1.y}, f2{qy1.z, qy1.w}};
+    const f2 qz[4] = {f2{qz0.x, qz0.y}, f2{qz0.z, qz0.w}, f2{qz1.x, qz1.y}, f2{qz1.z, qz1.w}};
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        f2 ax, ay, az;
+        ax = pk_sub_bcast<0>(qx[k], px); ay = pk_sub_bcast<0>(qy[k], py); az = pk_sub_bcast<0>(qz[k], pz);
+        const f2 d0 = (ax * ax + ay * ay) + az * az;
+        ax = pk_sub_bcast<1>(qx[k], px); ay = pk_sub_bcast<1>(qy[k], py); az = pk_sub_bcast<1>(qz[k], pz);
+        const f2 d1 = (ax * ax + ay * ay) + az * az;
+        ax = pk_sub_bcast<0>(qx[k + 1], px); ay = pk_sub_bcast<0>(qy[k + 1], py); az = pk_sub_bcast<0>(qz[k + 1], pz);
+        const f2 d2 = (ax * ax + ay * ay) + az * az;
+        ax = pk_sub_bcast<1>(qx[k + 1], px); ay = pk_sub_bcast<1>(qy[k + 1], py); az = pk_sub_bcast<1>(qz[k + 1], pz);
+        const f2 d3 = (ax * ax + ay * ay) + az * az;
+        best[0] = fmin_(fmin_(best[0], d0.x), d1.x);
+        best[0] = fmin_(fmin_(best[0], d2.x), d3.x);
+        best[1] = fmin_(fmin_(best[1], d0.y), d1.y);
+        best[1] = fmin_(fmin_(best[1], d2.y), d3.y);
+    }
+}
+
+// moment row of one row of 128 moving points, by ONE wave holding them two per lane (px.x = point lane,
+// px.y = point lane + 64) with their final correspondences j[]: stores idx, gathers q (and the normal),
+// accumulates in fp64, reduces through LDS in lane order and writes the row + completion tag.
+// (qio: the coordinates of the correspondences -- gathered here when `gather`, else supplied by the caller)
+template <int TAIL, bool phase_diag_>
+__device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f2 pz, const int (&j)[2], int lane, const int (&pi)[2],
+                                               int m_pad, const NNFuse& fuse, const NNTail& tail, double err_row,
+                                               unsigned char* lds_raw, float (&qio)[2][3], bool gather, int phase_pass_ = 0)
+{
+    constexpr int w = 0, phase_nw_ = SP_NW;  // (phase log) the closing wave of a sparse-kernel block
+    constexpr int NACC = TAIL == 2 ? 28 : 18;
+    // one wave: the lanes' contributions are transposed through LDS (rows padded to 65 doubles), slot k is then added
+    // up in lane order
+    double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
+    const float* Qg = fuse.Q_gather;
+    if constexpr (TAIL == 1) {
+        double acc[NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = fresh(pi[t]);
+            if (i < fuse.n) {
+                const int jj = j[t];
+                tail.idx_out[i] = jj;
+                const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
+                if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
+                const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
+                acc[0] += 1.0;
+                acc[1] += ppx; acc[2] += ppy; acc[3] += ppz;
+                acc[4] += qx; acc[5] += qy; acc[6] += qz;
+                acc[7] += qx * ppx; acc[8] += qx * ppy; acc[9] += qx * ppz;
+                acc[10] += qy * ppx; acc[11] += qy * ppy; acc[12] += qy * ppz;
+                acc[13] += qz * ppx; acc[14] += qz * ppy; acc[15] += qz * ppz;
+                acc[16] += ppx * ppx + ppy * ppy + ppz * ppz;
+                acc[17] += qx * qx + qy * qy + qz * qz;
+            }
+        }
+        ICP_PHASE(7)
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) tr[k][lane] = acc[k];
+    } else {
+        // point-to-plane: 28 sums.  The second point's terms are added to the first one's in LDS rather than in 28
+        // register pairs (the sums are the same, 0 + x0 + x1; the kernel no longer spills)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = fresh(pi[t]);
+            const bool live = i < fuse.n;
+            double cn[6] = {0, 0, 0, 0, 0, 0}, bb = 0.0;
+            if (live) {
+                const int jj = j[t];
+                tail.idx_out[i] = jj;
+                const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
+                if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
+                const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
+                const double nx = (double)tail.Nrm[jj], ny = (double)tail.Nrm[(size_t)m_pad + jj],
+                             nz = (double)tail.Nrm[2 * (size_t)m_pad + jj];
+                cn[0] = ppy * nz - ppz * ny;
+                cn[1] = ppz * nx - ppx * nz;
+                cn[2] = ppx * ny - ppy * nx;
+                cn[3] = nx; cn[4] = ny; cn[5] = nz;
+                bb = (ppx - qx) * nx + (ppy - qy) * ny + (ppz - qz) * nz;
+            }
+            auto put = [&](int k, double v) {
+                if (t == 0) tr[k][lane] = 0.0 + v; else tr[k][lane] = tr[k][lane] + v;
+            };
+            put(0, live ? 1.0 : 0.0);
+            int o = 1;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c2 = a; c2 < 6; ++c2) put(o++, cn[a] * cn[c2]);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) put(22 + a, -(cn[a] * bb));
+        }
+        ICP_PHASE(7)
+    }
+    lds_same_wave_order();
+    double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
+    // Slot k is the sum of its 64 lane entries in a FIXED order: PARTS lanes per slot add a contiguous share each
+    // (loaded first, added after: the LDS latencies overlap), the shares are then added in part order.
+    constexpr int PARTS = 64 / NACC, PER = (64 + PARTS - 1) / PARTS;
+    double* tp = &tr[NACC][0];  // PARTS x NACC partial sums, behind the transpose rows
+    {
+        const int slot = lane % NACC, part = lane / NACC;
+        if (part < PARTS) {
+            constexpr int CH = PER > 22 ? 16 : PER;   // loads in flight: all of a share, or 16 at a time for the long ones
+            double sum = 0.0;
+#pragma unroll
+            for (int l0 = 0; l0 < PER; l0 += CH) {
+                double v[CH];   // loads first, then the adds: one LDS latency per CH entries instead of one per entry
+#pragma unroll
+                for (int l = 0; l < CH; ++l) v[l] = (l0 + l < PER && part * PER + l0 + l < 64) ? tr[slot][part * PER + l0 + l] : 0.0;
+#pragma unroll
+                for (int l = 0; l < CH; ++l) sum += v[l];
+            }
+            tp[part * NACC + slot] = sum;
+        }
+    }
+    lds_same_wave_order();
+    // The row goes out as system-scope (write-through) stores, drained before the tag is issued: the host may
+    // read the row as soon as it sees the tag.  (No L2 write-back here -- it would flush the whole cache for the
+    // sake of 19 doubles; the other outputs of the pass are for later kernels and become visible at kernel end.)
+    if (lane < NACC) {
+        double sum = tp[lane];
+#pragma unroll
+        for (int q = 1; q < PARTS; ++q) sum += tp[q * NACC + lane];
+        __hip_atomic_store(&row[1 + lane], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lane == 0) __hip_atomic_store(&row[ICP_MOM_ERR], err_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    ICP_PHASE(8)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], tail.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// DIAG: the phase-stamp instrumentation (ICP_NN_PHASES) is compiled into its own instantiation -- its pointers and
+// branches cost the production kernel scalar registers it does not have to spare
+// PERM: the scan copy is a Morton-ordered view with a permutation (compiled apart as well: carrying both forms of the
+// hit processing in one loop body cost the common, identity-order case 16 % on a hit-heavy cloud)
+template <int TAIL, bool DIAG, bool PERM>
+__global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __restrict__ P, int n_pad,
+                                                              const float* __restrict__ Q, int m_pad, int seg_len,
+                                                              int round_passes, float* __restrict__ part_d,
+                                                              int32_t* __restrict__ part_idx, RT<float> rt_arg, NNFuse fuse,
+                                                              NNTail tail)
+{
+    constexpr int STG = PERM ? 40 : 32;  // floats per staged hit: box 8, x 8, y 8, z 8 (, model indices 8)
+    constexpr int HITS_BYTES = SP_HCAP * 4, MD_BYTES = SP_NW * 128 * 4;
+    constexpr int TR_BYTES = TAIL ? ((TAIL == 2 ? 28 : 18) * 65 + 64) * 8 : 0;
+    static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
+    constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * STG * 4;
+    constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
+    constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x SP_NW x 128
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MQ_OFF + 3 * MD_BYTES];
+    int* hits = reinterpret_cast<int*>(lds_raw);
+    // merge scratch: one (distance, index, wave) key per moving point, folded with LDS atomic mins -- the 64-bit
+    // integer order is the lexicographic order the tie rule needs (d >= 0; index < 2^28; the wave id rides in the
+    // low 4 bits and tells the closing wave whose coordinates to pick up)
+    // (placed behind the 24 KB the cold start stages its samples in)
+    unsigned long long* mkey = reinterpret_cast<unsigned long long*>(lds_raw + 3 * 2048 * 4);
+    static_assert(3 * 2048 * 4 + 128 * 8 <= HITS_BYTES + 2 * MD_BYTES, "merge keys fit behind the sample stage");
+    unsigned int* smin = reinterpret_cast<unsigned int*>(lds_raw + HITS_BYTES + 2 * MD_BYTES);
+    int* hcount = reinterpret_cast<int*>(lds_raw + HITS_BYTES + 2 * MD_BYTES + 128 * 4);
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ibase = blockIdx.x * 128 + lane;   // the block's slots; the moving point in slot s is p_perm[s] (spatially sorted groups)
+    int pi[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) pi[t] = fuse.p_perm ? fuse.p_perm[ibase + t * 64] : ibase + t * 64;
+    float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * STG);  // per wave: 8 hits x {box 8, x 8, y 8, z 8, model index 8}
+    float* msg = reinterpret_cast<float*>(lds_raw + MSG_OFF);
+    float (*seedq)[128] = reinterpret_cast<float (*)[128]>(lds_raw + SEED_OFF);
+    float (*mq)[SP_NW][128] = reinterpret_cast<float (*)[SP_NW][128]>(lds_raw + MQ_OFF);
+    int phase_pass_ = 0;  // (phase log)
+    constexpr int phase_nw_ = SP_NW;
+    constexpr bool phase_diag_ = DIAG;
+    ICP_PHASE(0)
+    const int q0 = blockIdx.y * seg_len;
+    const int c_lo = q0 / 8, c_hi = min(q0 + seg_len, m_pad) / 8;
+    constexpr int PRE = 2;
+    // issued first, with everything else that does not depend on the points:
+    // the seed gather does not depend on the points (the compiler cannot move these loads above the
+    // stores to P_out itself), and when the seeds are the correspondences the fused transform came from -- the
+    // ordinary loop -- the same gathered q serves the error of that pass
+    bool real[2], sok[2];
+    float sq[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = fresh(pi[t]);
+        real[t] = i < fuse.n;
+        sok[t] = false;
+        sq[t][0] = sq[t][1] = sq[t][2] = 0.f;
+        {
+            // no previous match (cold start): the model point at the same RELATIVE index -- consecutive scans of one
+            // sensor, or a cloud and its moved copy, keep their order, and any valid index is a valid bound
+            int j = !real[t] ? -1 : fuse.seed_idx ? fuse.seed_idx[i] : (int)(((long long)i * fuse.m) / fuse.n);
+            sok[t] = (unsigned)j < (unsigned)fuse.m;  // a seed is trusted only if it is a real model index
+            j = sok[t] ? j : 0;
+            const float* Qg = fuse.Q_gather;
+            sq[t][0] = Qg[j]; sq[t][1] = Qg[(size_t)m_pad + j]; sq[t][2] = Qg[2 * (size_t)m_pad + j];
+        }
+    }
+    f2 px, py, pz;
+    px = f2{P[pi[0]], P[pi[1]]};
+    py = f2{P[(size_t)n_pad + pi[0]], P[(size_t)n_pad + pi[1]]};
+    pz = f2{P[2 * (size_t)n_pad + pi[0]], P[2 * (size_t)n_pad + pi[1]]};
+    // ---- the pass loop: one turn for an ordinary launch, one per ICP pass for a resident one -------------------
+    // Armed launch: the kernel was enqueued while the previous pass was still running, so the launch and dispatch
+    // latencies are behind it; what it lacks is the (R, t) the host is solving for.  Resident launch: the same,
+    // carried through -- the blocks stay on the machine for the whole registration (cooperative launch: they are
+    // all resident), keep their points in registers and their seeds in LDS, and every pass is one message from the
+    // host: no launch, no dispatch, no kernel boundary between two passes.
+    // Wave 0 of every block waits for the message (see below), the other waves sleep at the barrier.  The poll budget
+    // (a few seconds) is the exit every wave reaches if the host never answers.
+    // the chunk boxes of the wave's first two find passes: fetched once (a resident kernel keeps them in registers: the model
+    // does not change)
+    float4 pb[PRE][2];
+#pragma unroll
+    for (int r = 0; r < PRE; ++r) {
+        const int cidx = c_lo + (r * SP_NW + w) * 64 + lane;
+        const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cidx < c_hi ? cidx : 0) * 8);
+        pb[r][0] = bp[0];
+        pb[r][1] = bp[1];
+    }
+    for (int pass = 0;; ++pass) {
+    phase_pass_ = pass;
+    double err_row = 0.0;
+    RT<float> rt = rt_arg;
+    int cmd = fuse.apply ? ICP_CMD_TRANSFORM_MATCH : ICP_CMD_MATCH;
+    double row_tag = tail.tag;
+    const bool have_seeds = pass > 0 || fuse.seed_idx != nullptr;
+    if (w == 0) {  // (wave 0 alone: in a resident launch it may still be reading last pass's keys when the others get here)
+        smin[lane] = 0x7f800000u; smin[lane + 64] = 0x7f800000u;
+        mkey[lane] = ~0ull; mkey[lane + 64] = ~0ull;
+    }
+    if (threadIdx.x == 0) *hcount = 0;
+    if (fuse.mailbox != nullptr) {
+        const double want = fuse.want + (double)pass;
+        if (w == 0) {
+            // Block 0 alone talks to the host: it polls the mailbox in pinned host memory (one reader: ~1.3 us each
+            // way; 128 readers would queue up to ~20 us, tools/mailbox_probe.hip) and relays the message through
+            // device memory, where the other blocks wait for it with agent-scope loads.
+            // (no relay: the mailbox itself is device memory the host writes through the BAR, every block polls it)
+            const bool first = (blockIdx.x == 0 && blockIdx.y == 0) || fuse.relay == nullptr;
+            const NNMailbox* src = first ? fuse.mailbox : fuse.relay;
+            double sq_ = 0.0;
+            for (int spins = 0; spins < (1 << 22); ++spins) {
+                sq_ = first ? __hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                            : __hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sq_ == want || sq_ == -want) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            // the message was written before its sequence number
+            if (first) __atomic_thread_fence(__ATOMIC_ACQUIRE); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const bool go = sq_ == want;
+            float v = 0.f;
+            int cm = ICP_CMD_EXIT;
+            if (first) {
+                if (lane < 12) v = __hip_atomic_load(&src->rt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (go) cm = __hip_atomic_load(&src->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // relay (also a withdrawal or a time-out: the other blocks must end too)
+                if (fuse.relay != nullptr) {
+                    NNMailbox* dst = fuse.relay;
+                    if (lane < 12) __hip_atomic_store(&dst->rt[lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_store(&dst->cmd, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) __hip_atomic_store(&dst->seq, go ? want : -want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                }
+            } else {
+                if (lane < 12) v = __hip_atomic_load(&src->rt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (go) cm = __hip_atomic_load(&src->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane < 12) msg[lane] = v;
+            if (lane == 0) reinterpret_cast<int*>(msg)[12] = cm;
+        }
+        __syncthreads();
+        cmd = reinterpret_cast<const int*>(msg)[12];
+        if (cmd == ICP_CMD_EXIT) return;  // withdrawn (the loop stopped) or timed out: nothing more is touched
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rt.r[k] = msg[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rt.t[k] = msg[9 + k];
+        row_tag = want;
+        if (pass > 0) {
+            // the seeds of a resident pass are the matches of the one before: wave 0 left their coordinates in LDS
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                sok[t] = real[t];
+                sq[t][0] = seedq[0][lane + t * 64]; sq[t][1] = seedq[1][lane + t * 64]; sq[t][2] = seedq[2][lane + t * 64];
+            }
+        }
+    } else {
+        __syncthreads();  // the list counter and the exchange minima are reset
+    }
+    const bool apply = cmd != ICP_CMD_MATCH;
+    if (apply) {
+        // every wave re-derives the moved points in registers (same instructions => same bits); wave 0 of the
+        // grid.y == 0 block stores them and accounts the error of the pass that produced (R, t)
+        double err = 0.0;
+        const bool shared_gather = pass > 0 || (fuse.seed_idx != nullptr && fuse.idx_prev == fuse.seed_idx);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
+            apply_rt<float>(rt, x, y, z, x, y, z);
+            if (t) { px.y = x; py.y = y; pz.y = z; } else { px.x = x; py.x = y; pz.x = z; }
+            if (blockIdx.y == 0 && w == 0) {
+                const int i = fresh(pi[t]);
+                fuse.P_out[i] = x;
+                fuse.P_out[(size_t)n_pad + i] = y;
+                fuse.P_out[2 * (size_t)n_pad + i] = z;
+                if (i < fuse.n) {
+                    float qx = sq[t][0], qy = sq[t][1], qz = sq[t][2];
+                    if (!(shared_gather && sok[t])) {
+                        const int j = fuse.idx_prev[i];
+                        const float* Qg = fuse.Q_gather;
+                        qx = Qg[j]; qy = Qg[(size_t)m_pad + j]; qz = Qg[2 * (size_t)m_pad + j];
+                    }
+                    const double ex = (double)qx - (double)x, ey = (double)qy - (double)y, ez = (double)qz - (double)z;
+                    err += ex * ex + ey * ey + ez * ez;
+                }
+            }
+        }
+        if (blockIdx.y == 0 && w == 0) {
+            err_row = wave_sum(err);
+            if (lane == 0) {
+                if constexpr (TAIL != 0) {
+                    // read by whichever block closes this row: agent-scope store, drained before our ticket
+                    if (gridDim.y > 1) __hip_atomic_store(&tail.err_tile[blockIdx.x], err_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    fuse.err_rows[blockIdx.x] = err_row;
+                }
+            }
+        }
+    }
+    if (!apply && pass == 0 && fuse.store_first && blockIdx.y == 0 && w == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = fresh(pi[t]);
+            fuse.P_out[i] = t ? px.y : px.x;
+            fuse.P_out[(size_t)n_pad + i] = t ? py.y : py.x;
+            fuse.P_out[2 * (size_t)n_pad + i] = t ? pz.y : pz.x;
+        }
+    }
+    ICP_PHASE(1)
+    if (cmd == ICP_CMD_TRANSFORM_ONLY) {
+        // the loop's last pass: nothing is matched any more, the row carries the error alone
+        if constexpr (TAIL != 0) {
+            if (w == 0) {
+                double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
+                if (lane < ICP_NMOM - 1) row[lane] = lane == ICP_MOM_ERR ? err_row : 0.0;
+                __threadfence_system();
+                if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], row_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    float best[2];
+    float bq[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // coordinates of the running minimum
+    int bj[2];  // index of the running minimum; -1: this wave has not lowered the bound it started from
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        bj[t] = -1;
+        best[t] = inf_<float>();
+        {
+            // seeded bound: the distance to ANY model point (last pass's match) bumped by one ulp -- the true minimum
+            // is <= that distance < bound, so the seed changes how much work is skipped, never the answer
+            const float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
+            const float d = dist2<float>(x, y, z, sq[t][0], sq[t][1], sq[t][2]);
+            best[t] = (sok[t] && d < inf_<float>()) ? __uint_as_float(__float_as_uint(d) + 1u) : inf_<float>();
+        }
+        // padding lanes never ask for a chunk (their result, "nothing found", is never read)
+        best[t] = real[t] ? best[t] : -1.f;
+    }
+    if (!have_seeds && fuse.samples != nullptr) {
+        // Cold start: no previous match to seed the bounds, so the block measures its points against a thinned-out
+        // model first -- one point per chunk, at most 2048 of them, staged in LDS (over the hit list and the merge
+        // scratch, both idle until later), a share per wave -- and every wave starts from the block-wide minimum
+        // bumped by an ulp.  Any model point gives a valid bound; the scan below is then as selective as a seeded one.
+        constexpr int SMAX = 2048;
+        static_assert(3 * SMAX * 4 <= HITS_BYTES + 2 * MD_BYTES, "the staged samples overlay the hit list and merge scratch");
+        const int ns8 = ((m_pad / 8) + 7) / 8;                 // groups of 8 samples in the array
+        const int ns_pad = ns8 * 8;
+        const int gcap = min(max(fuse.sample_groups, 1), SMAX / 8);
+        const int gs = (ns8 + gcap - 1) / gcap;                // group stride: <= gcap groups are staged
+        const int ng = (ns8 + gs - 1) / gs;
+        float* sl = reinterpret_cast<float*>(lds_raw);         // [3][SMAX]
+        for (int v = threadIdx.x; v < ng * 6; v += SP_NW * 64) {
+            const int gp = v / 6, r = v % 6, a = r >> 1, hh = r & 1;
+            *reinterpret_cast<float4*>(sl + a * SMAX + gp * 8 + hh * 4) =
+                *reinterpret_cast<const float4*>(fuse.samples + (size_t)a * ns_pad + (size_t)gp * gs * 8 + hh * 4);
+        }
+        __syncthreads();
+        float sb[2] = {inf_<float>(), inf_<float>()};
+        for (int gp = w; gp < ng; gp += SP_NW) {
+            const float4* a = reinterpret_cast<const float4*>(sl + gp * 8);
+            const float4* b = reinterpret_cast<const float4*>(sl + SMAX + gp * 8);
+            const float4* c = reinterpret_cast<const float4*>(sl + 2 * SMAX + gp * 8);
+            scan8_min(a[0], a[1], b[0], b[1], c[0], c[1], px, py, pz, sb);
+        }
+        if (real[0]) atomicMin(&smin[lane], __float_as_uint(sb[0]));
+        if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(sb[1]));
+        __syncthreads();  // (also: the staging area is free again)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned int v = smin[lane + t * 64];
+            if (real[t] && v < 0x7f800000u) best[t] = fmin_(best[t], __uint_as_float(v + 1u));
+        }
+    }
+    ICP_PHASE(2)
+
+    // bounding box of the block's 128 moving points (every wave derives the same one)
+    float glo[3] = {__builtin_fminf(px.x, px.y), __builtin_fminf(py.x, py.y), __builtin_fminf(pz.x, pz.y)};
+    float ghi[3] = {__builtin_fmaxf(px.x, px.y), __builtin_fmaxf(py.x, py.y), __builtin_fmaxf(pz.x, pz.y)};
+    wave_box(glo, ghi);
+
+    const int round_chunks = SP_NW * 64 * round_passes;
+    // one find pass: lane l tests chunk c0 + l (box b0 = lo.xyz hi.x, b1 = hi.yz - -) and appends it to the hit list
+    auto find_pass = [&](int c0, const float4 b0, const float4 b1, float B) {
+        const int cidx = c0 + lane;
+        const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - ghi[0], glo[0] - b0.w), 0.f);
+        const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - ghi[1], glo[1] - b1.x), 0.f);
+        const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - ghi[2], glo[2] - b1.y), 0.f);
+        const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;
+        const bool pass = cidx < c_hi && L < B;  // every candidate winner lies strictly below its point's starting bound
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+        if (mask != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(hcount, (int)__builtin_popcountll(mask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (pass) hits[base + rank] = cidx;
+        }
+    };
+    for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
+        // B only shrinks while the block works: refreshed once per round
+        const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
+        if (rb != c_lo) __syncthreads();  // the list is empty and its counter reset (first round: the barrier above)
+        int r = 0;
+        if (rb == c_lo) {  // the first round's first passes use the boxes fetched at kernel entry
+#pragma unroll
+            for (; r < PRE; ++r) {
+                const int c0 = rb + (r * SP_NW + w) * 64;
+                if (r < round_passes && c0 < c_hi) find_pass(c0, pb[r][0], pb[r][1], B);
+            }
+        }
+        for (; r < round_passes; ++r) {
+            const int c0 = rb + (r * SP_NW + w) * 64;
+            if (c0 >= c_hi) break;
+            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
+            find_pass(c0, bp[0], bp[1], B);
+        }
+        __syncthreads();
+        const int H = *hcount;
+        // The hits are dealt round-robin; a wave fetches the box and the coordinates of up to 8 of its hits with ONE
+        // gather -- 8 lanes x 16 bytes per hit -- into its private LDS stage, so a batch of hits costs one trip to
+        // memory instead of three or four each.
+        // (exchanging minima between the batches of a cold pass was measured too: the barriers cost more than they save)
+        {
+            const int h1 = H;
+            for (int hb = 0; hb < h1; hb += SP_NW * 8) {
+                {
+                    const int r = lane >> 3, part = lane & 7;
+                    const int h = hb + r * SP_NW + w;
+                    if (h < h1) {
+                        const int chl = hits[h];
+                        const float* src = part < 2 ? fuse.boxes + (size_t)chl * 8 + part * 4
+                                                    : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)chl * 8 + (part & 1) * 4;
+                        *reinterpret_cast<float4*>(stage + r * STG + part * 4) = *reinterpret_cast<const float4*>(src);
+                    }
+                    // a sorted view: the elements' model indices (the sort permutation) are staged too
+                    if constexpr (PERM) {
+                        const int r2 = lane >> 1, half = lane & 1;
+                        const int h2 = hb + r2 * SP_NW + w;
+                        if (lane < 16 && h2 < h1)
+                            *reinterpret_cast<int4*>(stage + r2 * STG + 32 + half * 4) =
+                                *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)hits[h2] * 8 + half * 4);
+                    }
+                }
+                lds_same_wave_order();
+                const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
+                const int cnt = mine < 8 ? mine : 8;
+                for (int rr = 0; rr < cnt; ++rr) {
+                    if constexpr (PERM) {
+                        scan_hit<true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
+                    } else {
+                        const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * SP_NW + w]);
+                        scan_hit<false>(stage + rr * STG, ch, px, py, pz, best, bj, bq);
+                    }
+                }
+                lds_same_wave_order();
+            }
+            if (rb + round_chunks < c_hi) {
+                // exchange before the next round: every wave goes on from the block's best minimum so far, bumped by
+                // an ulp (d >= 0: the bit patterns order like the values, so this is an integer min)
+                if (real[0]) atomicMin(&smin[lane], __float_as_uint(best[0]));
+                if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(best[1]));
+                __syncthreads();
+                if (threadIdx.x == 0) *hcount = 0;  // the list is consumed
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned int v = smin[lane + t * 64];
+                    if (real[t] && v < 0x7f800000u && v < __float_as_uint(best[t])) { best[t] = __uint_as_float(v + 1u); bj[t] = -1; }
+                }
+            }
+        }
+    }
+    ICP_PHASE(3)
+
+    // in-block merge: every wave that lowered its bound folds its candidate into the point's key
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (bj[t] >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best[t]) << 32) | ((unsigned int)bj[t] << 4) | (unsigned int)w;
+            atomicMin(&mkey[lane + t * 64], key);
+            mq[0][w][lane + t * 64] = bq[t][0]; mq[1][w][lane + t * 64] = bq[t][1]; mq[2][w][lane + t * 64] = bq[t][2];
+        }
+    }
+    ICP_PHASE(4)
+    __syncthreads();
+    ICP_PHASE(5)
+    // wave 0 finishes the row: it holds both of every lane's points in registers
+    if (w != 0) {
+        if (!fuse.resident) return;
+        continue;  // resident: on to the next message (asleep at its barrier while wave 0 works)
+    }
+
+    float fb[2];
+    int fj[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const unsigned long long key = mkey[lane + t * 64];
+        const bool none = key == ~0ull;  // no wave found anything below the bound (padding lanes)
+        const unsigned int lo = (unsigned int)key;
+        fb[t] = none ? inf_<float>() : __uint_as_float((unsigned int)(key >> 32));
+        fj[t] = none ? 0x7fffffff : (int)(lo >> 4);
+        const int bw = none ? 0 : (int)(lo & 15u);
+        sq[t][0] = mq[0][bw][lane + t * 64]; sq[t][1] = mq[1][bw][lane + t * 64]; sq[t][2] = mq[2][bw][lane + t * 64];
+    }
+    if constexpr (TAIL == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const size_t o = (size_t)blockIdx.y * n_pad + (size_t)pi[t];
+            part_d[o] = fb[t];
+            part_idx[o] = fj[t];
+        }
+        return;
+    } else {
+        if (gridDim.y > 1) {
+            // several segment blocks share the row: fold into the 64-bit (d, idx) keys and draw a ticket, the
+            // last arriver closes the row (protocol as in nn_match_f32_v2; only this wave takes part)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(fb[t]) << 32) | (unsigned int)fj[t];
+                __hip_atomic_fetch_min(&tail.keys[(size_t)blockIdx.x * 128 + lane + t * 64], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ICP_PHASE(6)
+            unsigned int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&tail.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            ICP_PHASE(7)
+            if (ticket != gridDim.y - 1) return;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int i = ibase + t * 64;  // keys live per slot
+                const unsigned long long key = __hip_atomic_load(&tail.keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tail.keys[i] = ~0ull;  // ready for the next launch (nobody touches this row again in this one)
+                fj[t] = (int)(unsigned int)(key & 0xffffffffull);
+            }
+            if (lane == 0) tail.tickets[blockIdx.x] = 0u;
+            if (fuse.apply) err_row = __hip_atomic_load(&tail.err_tile[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fj[t] = ((unsigned)fj[t] < (unsigned)fuse.m) ? fj[t] : fuse.m - 1;  // unreachable clamp
+        NNTail tl = tail;
+        tl.tag = row_tag;
+        tl.idx_out = (pass & 1) ? tail.idx_out_odd : tail.idx_out;
+        // (a row closed over several segment blocks may have been won elsewhere: its coordinates are gathered)
+        if (gridDim.y == 1) { ICP_PHASE(6) }
+        tail_close_row<TAIL, DIAG>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gridDim.y > 1, pass);
+        ICP_PHASE(9)
+        if (!fuse.resident) return;
+        // the matches of this pass seed the next one and are what its error is measured against
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            sok[t] = real[t];
+            seedq[0][lane + t * 64] = sq[t][0]; seedq[1][lane + t * 64] = sq[t][1]; seedq[2][lane + t * 64] = sq[t][2];
+        }
+    }
+    }  // pass loop
+}
+#undef ICP_PHASE
+
+// diagnostic (ICP_SELFTEST=1): does a running kernel see a store the host makes AFTER the kernel has started?
+// The kernel reports that it runs (ack = 1), waits for mb->seq == 2 and answers ack = 2 (or -1 when its budget ends).
+__global__ void mailbox_selftest_kernel(const NNMailbox* mb, double* ack)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(ack, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    double s = 0.0;
+    for (int spins = 0; spins < (1 << 20); ++spins) {
+        s = __hip_atomic_load(&mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (s == 2.0) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ack, s == 2.0 ? 2.0 : -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_mailbox_selftest(const NNMailbox* mb, double* ack, hipStream_t st)
+{
+    hipLaunchKernelGGL(mailbox_selftest_kernel, dim3(1), dim3(64), 0, st, mb, ack);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// preparation of a cloud for the sparse kernel, on the device (once per icp_set_model / icp_set_moving):
+// exact-duplicate flags (lexicographic order of the raw coordinate bits: three stable radix passes),
+// Morton order, and the grouped-extent test that decides whether the Morton-ordered view is used.
+// Everything is deterministic (fixed-order reductions): the decision must not change from run to run.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int canon_bits(float v) { return __float_as_uint(v == 0.0f ? 0.0f : v); }
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+    return x - x == 0.f && y - y == 0.f && z - z == 0.f;   // false for NaN and +-inf
+}
+
+// keys[s] = raw bits of coordinate `axis` of point order[s] (order == NULL: identity, and vals is initialised)
+__global__ void prep_axis_keys_kernel(const float* __restrict__ X, int n, int n_pad, int axis, const int32_t* __restrict__ order,
+                                      unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = order ? order[s] : s;
+    keys[s] = canon_bits(X[(size_t)axis * n_pad + i]);
+    if (!order) vals[s] = s;
+}
+
+// lex[s] ascending in (x, y, z, index): a point equal to its predecessor has a lower-index twin
+__global__ void prep_mark_duplicates_kernel(const float* __restrict__ X, int n, int n_pad, const int32_t* __restrict__ lex,
+                                            unsigned char* __restrict__ voided, int* __restrict__ count)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    bool v = false;
+    if (s > 0) {
+        const int a = lex[s - 1], b = lex[s];
+        const float bx = X[b], by = X[(size_t)n_pad + b], bz = X[2 * (size_t)n_pad + b];
+        const bool same = canon_bits(X[a]) == canon_bits(bx) && canon_bits(X[(size_t)n_pad + a]) == canon_bits(by) &&
+                          canon_bits(X[2 * (size_t)n_pad + a]) == canon_bits(bz);
+        const bool nan = bx != bx || by != by || bz != bz;
+        v = same && !nan;
+    }
+    voided[lex[s]] = v ? 1 : 0;
+    if (v) atomicAdd(count, 1);
+}
+
+// scan copy: the cloud with its flagged points (and the padding) voided to +inf
+__global__ void prep_scan_copy_kernel(const float* __restrict__ X, int n, int n_pad, const unsigned char* __restrict__ voided,
+                                      float* __restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    const bool keep = j < n && !voided[j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out[(size_t)a * n_pad + j] = keep ? X[(size_t)a * n_pad + j] : inf_<float>();
+}
+
+// bounding cube of the finite points: box[0..2] = lo, box[3] = largest extent (one block, fixed order)
+__global__ __launch_bounds__(1024) void prep_bbox_kernel(const float* __restrict__ X, int n, int n_pad, float* __restrict__ box)
+{
+    __shared__ float red[6][1024];
+    float lo[3] = {inf_<float>(), inf_<float>(), inf_<float>()}, hi[3] = {-inf_<float>(), -inf_<float>(), -inf_<float>()};
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float x = X[i], y = X[(size_t)n_pad + i], z = X[2 * (size_t)n_pad + i];
+        if (!finite3(x, y, z)) continue;
+        lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+        hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+    }
+    for (int a = 0; a < 3; ++a) { red[a][threadIdx.x] = lo[a]; red[3 + a][threadIdx.x] = hi[a]; }
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int a = 0; a < 3; ++a) {
+                red[a][threadIdx.x] = fminf(red[a][threadIdx.x], red[a][threadIdx.x + w]);
+                red[3 + a][threadIdx.x] = fmaxf(red[3 + a][threadIdx.x], red[3 + a][threadIdx.x + w]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float ext = 0.f;
+        for (int a = 0; a < 3; ++a) { box[a] = red[a][0]; ext = fmaxf(ext, red[3 + a][0] - red[a][0]); }
+        box[3] = ext;   // -inf / NaN when there is no finite point: the codes below then all take the "last" value
+    }
+}
+
+__device__ __forceinline__ unsigned int spread10(unsigned int v)
+{
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// 30-bit Morton codes in one cube for all axes (cells stay cubic); non-finite points go last
+__global__ void prep_morton_keys_kernel(const float* __restrict__ X, int n, int n_pad, const float* __restrict__ box,
+                                        unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = X[i], y = X[(size_t)n_pad + i], z = X[2 * (size_t)n_pad + i];
+    unsigned int code = 0x7fffffffu;
+    const float ext = box[3];
+    if (finite3(x, y, z) && ext >= 0.f) {
+        const double scale = ext > 0.f ? 1023.0 / (double)ext : 0.0;
+        const unsigned int qx = (unsigned int)fmin(1023.0, fmax(0.0, ((double)x - (double)box[0]) * scale));
+        const unsigned int qy = (unsigned int)fmin(1023.0, fmax(0.0, ((double)y - (double)box[1]) * scale));
+        const unsigned int qz = (unsigned int)fmin(1023.0, fmax(0.0, ((double)z - (double)box[2]) * scale));
+        code = spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2);
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
+// per group of `group` consecutive entries of an order (NULL: the cloud's own): extent dx + dy + dz of its finite points.
+// One wave per group (a thread per group walks 128 gathered points one after the other: 50 us for 128 groups).
+__global__ __launch_bounds__(64) void prep_group_extent_kernel(const float* __restrict__ X, int n, int n_pad, const int32_t* __restrict__ order,
+                                                               int group, double* __restrict__ ext)
+{
+    const int g = blockIdx.x, g0 = g * group, lane = threadIdx.x;
+    float lo[3] = {inf_<float>(), inf_<float>(), inf_<float>()}, hi[3] = {-inf_<float>(), -inf_<float>(), -inf_<float>()};
+    for (int k = g0 + lane; k < min(n, g0 + group); k += 64) {
+        const int i = order ? order[k] : k;
+        const float p[3] = {X[i], X[(size_t)n_pad + i], X[2 * (size_t)n_pad + i]};
+        if (!finite3(p[0], p[1], p[2])) continue;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+        }
+    if (lane == 0) ext[g] = hi[0] >= lo[0] ? (double)(hi[0] - lo[0]) + (double)(hi[1] - lo[1]) + (double)(hi[2] - lo[2]) : 0.0;
+}
+
+// out[which] = sum of ext[0..groups) in a fixed order (one block)
+__global__ __launch_bounds__(256) void prep_sum_kernel(const double* __restrict__ ext, int groups, double* __restrict__ out, int which)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int g = threadIdx.x; g < groups; g += 256) s += ext[g];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[which] = red[0];
+}
+
+// Morton-ordered view of a scan copy + its permutation, padded (+inf / 0x7fffffff)
+__global__ void prep_gather_sorted_kernel(const float* __restrict__ Qs, int m, int m_pad, const int32_t* __restrict__ perm,
+                                          float* __restrict__ out, int32_t* __restrict__ perm_pad)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m_pad) return;
+    const int j = k < m ? perm[k] : -1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out[(size_t)a * m_pad + k] = j >= 0 ? Qs[(size_t)a * m_pad + j] : inf_<float>();
+    perm_pad[k] = j >= 0 ? j : 0x7fffffff;
+}
+
+// slot -> point map of the moving cloud: the Morton order, padding slots keep themselves
+__global__ void prep_slot_map_kernel(const int32_t* __restrict__ perm, int n, int n_pad, int32_t* __restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_pad) out[k] = k < n ? perm[k] : k;
+}
+
+size_t prep_sort_temp_bytes(int count)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned int*)nullptr, (unsigned int*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                    (unsigned int)(count > 0 ? count : 1));
+    return bytes;
+}
+
+static hipError_t sort_pairs(const PrepBuffers& b, int count, int from, int end_bit, hipStream_t st)
+{
+    size_t bytes = b.temp_bytes;
+    return rocprim::radix_sort_pairs(b.temp, bytes, b.keys[from], b.keys[from ^ 1], b.vals[from], b.vals[from ^ 1], (unsigned int)count, 0,
+                                     (unsigned int)end_bit, st);
+}
+
+// voided[j] = 1 for every point with an exact lower-index twin, *count_dev += their number; then the scan copy
+hipError_t launch_duplicates_and_scan_copy(const PrepBuffers& b, const float* X, int n, int n_pad, unsigned char* voided, int* count_dev,
+                                           float* scan_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const dim3 blk(256), grd((n + 255) / 256);
+    int cur = 0;
+    for (int axis = 2; axis >= 0; --axis) {   // least significant key first, stable passes
+        hipLaunchKernelGGL(prep_axis_keys_kernel, grd, blk, 0, st, X, n, n_pad, axis, axis == 2 ? (const int32_t*)nullptr : b.vals[cur],
+                           b.keys[cur], b.vals[cur]);
+        if (hipError_t e = sort_pairs(b, n, cur, 32, st)) return e;
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(prep_mark_duplicates_kernel, grd, blk, 0, st, X, n, n_pad, b.vals[cur], voided, count_dev);
+    hipLaunchKernelGGL(prep_scan_copy_kernel, dim3((n_pad + 255) / 256), blk, 0, st, X, n, n_pad, voided, scan_out);
+    return hipGetLastError();
+}
+
+// perm_out[k] = k-th point in Morton order; totals[0] / totals[1] = summed group extents of the given / the Morton order
+hipError_t launch_morton_order(const PrepBuffers& b, const float* X, int n, int n_pad, int group, int32_t* perm_out, double* totals,
+                               hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const dim3 blk(256), grd((n + 255) / 256);
+    hipLaunchKernelGGL(prep_bbox_kernel, dim3(1), dim3(1024), 0, st, X, n, n_pad, b.box);
+    hipLaunchKernelGGL(prep_morton_keys_kernel, grd, blk, 0, st, X, n, n_pad, b.box, b.keys[0], b.vals[0]);
+    if (hipError_t e = sort_pairs(b, n, 0, 31, st)) return e;
+    if (hipError_t e = hipMemcpyAsync(perm_out, b.vals[1], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st)) return e;
+    const int groups = (n + group - 1) / group;
+    const dim3 ggrd(groups);
+    hipLaunchKernelGGL(prep_group_extent_kernel, ggrd, dim3(64), 0, st, X, n, n_pad, (const int32_t*)nullptr, group, b.ext);
+    hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups, totals, 0);
+    hipLaunchKernelGGL(prep_group_extent_kernel, ggrd, dim3(64), 0, st, X, n, n_pad, (const int32_t*)perm_out, group, b.ext);
+    hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups, totals, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_sorted(const float* Qs, int m, int m_pad, const int32_t* perm, float* out, int32_t* perm_pad, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_gather_sorted_kernel, dim3((m_pad + 255) / 256), dim3(256), 0, st, Qs, m, m_pad, perm, out, perm_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_slot_map(const int32_t* perm, int n, int n_pad, int32_t* out, hipStream_t st)
+{
+    if (n_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_slot_map_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, perm, n, n_pad, out);
+    return hipGetLastError();
+}
+
+// bounding box of every 8-point chunk of the duplicate-voided scan copy (voided = +inf entries are ignored; an
+// all-void chunk gets lo = +inf, hi = -inf and is skipped by construction).  Once per model.
+__global__ void model_boxes_kernel(const float* __restrict__ Qs, int m_pad, float* __restrict__ boxes)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * 8 >= m_pad) return;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = inf_<float>(); hi[a] = -inf_<float>(); }
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = Qs[(size_t)a * m_pad + j];
+            if (v < inf_<float>() && v > -inf_<float>()) { lo[a] = __builtin_fminf(lo[a], v); hi[a] = __builtin_fmaxf(hi[a], v); }
+        }
+    }
+    float* o = boxes + (size_t)c * 8;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+}
+
+// one representative per chunk of the scan copy (its first point that is not voided; +inf if there is none),
+// SoA over round_up(m_pad / 8, 8) entries: the thinned-out model of the sparse kernel's cold start
+__global__ void model_samples_kernel(const float* __restrict__ Qs, int m_pad, int ns_pad, float* __restrict__ samples)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ns_pad) return;
+    float v[3] = {inf_<float>(), inf_<float>(), inf_<float>()};
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+        const float x = Qs[j];
+        if (x < inf_<float>() && x > -inf_<float>()) { v[0] = x; v[1] = Qs[(size_t)m_pad + j]; v[2] = Qs[2 * (size_t)m_pad + j]; break; }
+    }
+    samples[c] = v[0];
+    samples[(size_t)ns_pad + c] = v[1];
+    samples[2 * (size_t)ns_pad + c] = v[2];
+}
+
+size_t model_samples_bytes(int m_pad) { return 3 * (size_t)(((m_pad / 8) + 7) / 8 * 8) * sizeof(float); }
+
+hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const int ns_pad = ((m_pad / 8) + 7) / 8 * 8;
+    hipLaunchKernelGGL(model_samples_kernel, dim3((ns_pad + 255) / 256), dim3(256), 0, st, (const float*)Qs_soa, m_pad, ns_pad, samples);
+    return hipGetLastError();
+}
+
+hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const int chunks = (m_pad + 7) / 8;
+    hipLaunchKernelGGL(model_boxes_kernel, dim3((chunks + 255) / 256), dim3(256), 0, st, (const float*)Qs_soa, m_pad, boxes);
+    return hipGetLastError();
+}
+
+// lexicographic (d, j) minimum over the S segment partials: segments are ascending model ranges,
+// so the first strict minimum in segment order is the lowest index.
+template <typename F>
+__device__ __forceinline__ int merge_partials(const F* __restrict__ part_d, const int32_t* __restrict__ part_idx,
+                                              int S, int n_pad, int i)
+{
+    F best = part_d[i];
+    int bi = part_idx[i];
+    int s = 1;
+    for (; s + 8 <= S; s += 8) {  // 16 independent loads in flight, then the ordered compare chain
+        F d[8];
+        int j[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            d[u] = part_d[(size_t)(s + u) * n_pad + i];
+            j[u] = part_idx[(size_t)(s + u) * n_pad + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (d[u] < best) { best = d[u]; bi = j[u]; }
+    }
+    if (s < S) {  // tail: same 16 loads in flight, out-of-range slots replaced by +inf
+        F d[8];
+        int j[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ss = s + u < S ? s + u : S - 1;
+            d[u] = part_d[(size_t)ss * n_pad + i];
+            j[u] = part_idx[(size_t)ss * n_pad + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s + u < S && d[u] < best) { best = d[u]; bi = j[u]; }
+    }
+    return bi;
+}
+
+template <typename F>
+__global__ void merge_kernel(const F* __restrict__ part_d, const int32_t* __restrict__ part_idx, int S, int n_pad,
+                             int n, int m, int32_t* __restrict__ idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int j = merge_partials<F>(part_d, part_idx, S, n_pad, i);
+    idx[i] = j < m ? j : m - 1;  // unreachable clamp (padding never wins); keeps idx in range by construction
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused merge + gather + moments.  HBM-bound: per moving point 12 B (p) + 8*S B (partials)
+// + 4 B (idx store) + 12 B gathered (q) [+ 12 B normals], accumulated in fp64.
+// ------------------------------------------------------------------------------------------------
+constexpr int MOM_BLOCK = 64;  // one wave per block: no LDS, no barrier; 256 blocks already at 16 384 points
+
+template <typename F, int METRIC>
+__global__ __launch_bounds__(MOM_BLOCK) void moments_kernel(const F* __restrict__ P, int n, int n_pad,
+                                                            const F* __restrict__ Q, int m, int m_pad,
+                                                            const F* __restrict__ Nrm,
+                                                            const F* __restrict__ part_d,
+                                                            const int32_t* __restrict__ part_idx, int S,
+                                                            int32_t* __restrict__ idx_out,
+                                                            double* __restrict__ partials, double tag,
+                                                            const double* __restrict__ err_rows, int err_count)
+{
+    constexpr int NACC = (METRIC == ICP_POINT_TO_POINT) ? 18 : 28;
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+
+    for (int i = blockIdx.x * MOM_BLOCK + threadIdx.x; i < n; i += gridDim.x * MOM_BLOCK) {
+        int j = merge_partials<F>(part_d, part_idx, S, n_pad, i);
+        j = j < m ? j : m - 1;
+        idx_out[i] = j;
+        const double px = (double)P[i], py = (double)P[(size_t)n_pad + i], pz = (double)P[2 * (size_t)n_pad + i];
+        const double qx = (double)Q[j], qy = (double)Q[(size_t)m_pad + j], qz = (double)Q[2 * (size_t)m_pad + j];
+        acc[0] += 1.0;
+        if constexpr (METRIC == ICP_POINT_TO_POINT) {
+            acc[1] += px; acc[2] += py; acc[3] += pz;
+            acc[4] += qx; acc[5] += qy; acc[6] += qz;
+            acc[7] += qx * px; acc[8] += qx * py; acc[9] += qx * pz;
+            acc[10] += qy * px; acc[11] += qy * py; acc[12] += qy * pz;
+            acc[13] += qz * px; acc[14] += qz * py; acc[15] += qz * pz;
+            acc[16] += px * px + py * py + pz * pz;
+            acc[17] += qx * qx + qy * qy + qz * qz;
+        } else {
+            const double nx = (double)Nrm[j], ny = (double)Nrm[(size_t)m_pad + j], nz = (double)Nrm[2 * (size_t)m_pad + j];
+            double cn[6];
+            cn[0] = py * nz - pz * ny;
+            cn[1] = pz * nx - px * nz;
+            cn[2] = px * ny - py * nx;
+            cn[3] = nx; cn[4] = ny; cn[5] = nz;
+            const double bi = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
+            int o = 1;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = a; c < 6; ++c) acc[o++] += cn[a] * cn[c];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[22 + a] -= cn[a] * bi;
+        }
+    }
+    // slot 0 of the moment vector is the error of the preceding transform (written by finalize)
+    block_sum_store<NACC, MOM_BLOCK>(acc, partials + (size_t)blockIdx.x * ICP_NMOM + 1);
+    // slot 0: this block's share of the error rows the preceding transform (fused into the matching
+    // kernel, or its own launch) left in device memory -- fixed assignment, fixed order
+    if (threadIdx.x == 0) {
+        double e = 0.0;
+        for (int r = blockIdx.x; r < err_count; r += gridDim.x) e += err_rows[r];
+        partials[(size_t)blockIdx.x * ICP_NMOM + ICP_MOM_ERR] = e;
+    }
+    // completion tag for a host that polls the (pinned, mapped) rows instead of synchronising the
+    // stream: the row's data is released to system scope before the tag becomes visible
+    static_assert(MOM_BLOCK == 64, "the tag protocol assumes one wave per block");
+    __threadfence_system();
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * ICP_NMOM + (ICP_NMOM - 1)] = tag;
+}
+
+// ------------------------------------------------------------------------------------------------
+// in-place transform + error.  HBM-bound: 12 B read + 12 B written per moving point, + 4 B idx
+// + 12 B gathered q.  The products and sums are rounded separately in the storage precision
+// ((r0*x + r1*y) + r2*z) + t, the association of RyT (src/ICP_point_to_point.cu:85).
+// ------------------------------------------------------------------------------------------------
+constexpr int TR_BLOCK = 256;
+
+template <typename F>
+__global__ __launch_bounds__(TR_BLOCK) void transform_error_kernel(F* __restrict__ P, int n, int n_pad, RT<F> rt,
+                                                                    const F* __restrict__ Q, int m_pad,
+                                                                    const int32_t* __restrict__ idx,
+                                                                    double* __restrict__ err_partials)
+{
+    double acc[1] = {0.0};
+    for (int i = blockIdx.x * TR_BLOCK + threadIdx.x; i < n_pad; i += gridDim.x * TR_BLOCK) {
+        const F x = P[i], y = P[(size_t)n_pad + i], z = P[2 * (size_t)n_pad + i];
+        F o[3];
+        apply_rt<F>(rt, x, y, z, o[0], o[1], o[2]);
+        P[i] = o[0];
+        P[(size_t)n_pad + i] = o[1];
+        P[2 * (size_t)n_pad + i] = o[2];
+        if (i < n) {
+            const int j = idx[i];
+            const double dx = (double)Q[j] - (double)o[0];
+            const double dy = (double)Q[(size_t)m_pad + j] - (double)o[1];
+            const double dz = (double)Q[2 * (size_t)m_pad + j] - (double)o[2];
+            acc[0] += dx * dx + dy * dy + dz * dz;
+        }
+    }
+    block_sum_store<1, TR_BLOCK>(acc, err_partials + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: one block, fixed-order sums of the per-block partials -> the ICP_NMOM vector.
+// thread (k = tid % 32, part = tid / 32) sums blocks part, part+8, ... of slot k.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(double* __restrict__ mom, const double* __restrict__ mom_partials,
+                                                       int mom_blocks, const double* __restrict__ err_partials,
+                                                       int err_blocks, int rows_have_err)
+{
+    __shared__ double red[8][ICP_NMOM];
+    const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
+    double s = 0.0;
+    if (k == 0) {
+        for (int b = part; b < err_blocks; b += 8) s += err_partials[b];
+        if (rows_have_err)
+            for (int b = part; b < mom_blocks; b += 8) s += mom_partials[(size_t)b * ICP_NMOM];
+    } else if (k == ICP_NMOM - 1) {
+        s = 0.0;  // the rows' completion-tag slot is not a moment
+    } else {
+        for (int b = part; b < mom_blocks; b += 8) s += mom_partials[(size_t)b * ICP_NMOM + k];
+    }
+    red[part][k] = s;
+    __syncthreads();
+    if (threadIdx.x < ICP_NMOM) {
+        double tot = red[0][k];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) tot += red[p][k];
+        mom[k] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// point-to-plane front end: 4 nearest model neighbours of every model point (self dropped).
+// One lane per model point, whole model streamed through LDS; a sorted (d, j) top-5 lives in
+// registers, insertion happens under a (rare) wave-level branch.  Candidates arrive in ascending
+// j, so "insert after every entry with d_e <= d" reproduces the reference's k+1 passes of
+// first-arg-min with overwrite (src/CUDA/GPU_point_to_plane_real.cu:83-89).
+// ------------------------------------------------------------------------------------------------
+template <typename F, int TQ>
+__global__ __launch_bounds__(NN_BLOCK) void knn4_kernel(const F* __restrict__ Q, int m, int m_pad,
+                                                        int32_t* __restrict__ nbr)
+{
+    using V = typename Vec16<F>::type;
+    constexpr int VN = Vec16<F>::N;
+    __shared__ __attribute__((aligned(16))) F sq[3 * TQ];
+    const int i = blockIdx.x * NN_BLOCK + threadIdx.x;
+    const int is = i < m ? i : m - 1;
+    const F px = Q[is], py = Q[(size_t)m_pad + is], pz = Q[2 * (size_t)m_pad + is];
+    F bd[5];
+    int bj[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) { bd[r] = inf_<F>(); bj[r] = 0; }
+
+    for (int tile = 0; tile < m; tile += TQ) {
+        const int len = min(TQ, m_pad - tile);
+        __syncthreads();
+        for (int e = threadIdx.x * VN; e < len; e += NN_BLOCK * VN) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                *reinterpret_cast<V*>(&sq[a * TQ + e]) =
+                    *reinterpret_cast<const V*>(&Q[(size_t)a * m_pad + tile + e]);
+        }
+        __syncthreads();
+        const int real = min(len, m - tile);  // padded duplicates must not enter a top-k
+        for (int c = 0; c < real; ++c) {
+            const F d = dist2<F>(px, py, pz, sq[c], sq[TQ + c], sq[2 * TQ + c]);
+            if (d < bd[4]) {
+                const int j = tile + c;
+                // insert keeping (d, j) ascending; equal d keeps the earlier (lower) j first
+                F cd = d;
+                int cj = j;
+                bool shifting = false;  // once the new entry is placed, everything below moves down one slot
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const bool sw = shifting || (cd < bd[r]);
+                    shifting = sw;
+                    const F td = bd[r];
+                    const int tj = bj[r];
+                    bd[r] = sw ? cd : td;
+                    bj[r] = sw ? cj : tj;
+                    cd = sw ? td : cd;
+                    cj = sw ? tj : cj;
+                }
+            }
+        }
+    }
+    if (i < m) {
+#pragma unroll
+        for (int r = 1; r < 5; ++r) nbr[(size_t)i * 4 + (r - 1)] = bj[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kNN(4), fp32, v2: the matching kernel's machinery (packed distances over two query points per lane, four
+// waves splitting the block's model segment, grid.y segments, 8-point chunks with a wave-uniform early-out)
+// carrying a sorted (d, j) top-5 per query instead of a single minimum.  A chunk is examined element-wise only
+// when some lane's chunk minimum beats that lane's threshold = min(5th best so far, seeded bound).  The seeded
+// bound is the largest distance to five DISTINCT model points around the query's own index, bumped one ulp: at
+// least five points lie strictly under it, so the exact top-5 survives; the seed only prunes work.
+// Per-wave lists are merged through LDS (ties -> the lower wave = lower indices), per-segment lists by
+// knn4_merge_kernel (ties -> the lower segment).  Rank 0 (self or an equal-distance lower index) is dropped there.
+// ------------------------------------------------------------------------------------------------
+struct Top5 {
+    float d[5];
+    int j[5];
+};
+
+__device__ __forceinline__ void top5_insert(Top5& L, float d, int j)
+{
+    float cd = d;
+    int cj = j;
+    bool shifting = false;  // once placed, everything below moves down one slot (keeps equal-d entries index-ordered)
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const bool sw = shifting || (cd < L.d[r]);
+        shifting = sw;
+        const float td = L.d[r];
+        const int tj = L.j[r];
+        L.d[r] = sw ? cd : td;
+        L.j[r] = sw ? cj : tj;
+        cd = sw ? td : cd;
+        cj = sw ? tj : cj;
+    }
+}
+
+constexpr int KNN_C = 8;
+
+__global__ __launch_bounds__(NN_BLOCK, 4) void knn4_f32_v2(const float* __restrict__ Q, int m, int m_pad, int n_pad,
+                                                           int seg_len, float* __restrict__ part_d,
+                                                           int32_t* __restrict__ part_j)
+{
+    constexpr int C = KNN_C;
+    __shared__ __attribute__((aligned(16))) float sq[4][3][NN2_TQW];
+    __shared__ float ld[4][128][5];
+    __shared__ int lj[4][128][5];
+
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int wseg = seg_len >> 2;
+    const int q0 = blockIdx.y * seg_len;
+    const int my0 = q0 + w * wseg;
+    const int my1 = min(my0 + wseg, m_pad);
+    const int ibase = blockIdx.x * 128 + lane;
+    const int i0 = min(ibase, m - 1), i1 = min(ibase + 64, m - 1);  // queries are model points; padding lanes repeat the last
+
+    const f2 px = f2{Q[i0], Q[i1]}, py = f2{Q[(size_t)m_pad + i0], Q[(size_t)m_pad + i1]},
+             pz = f2{Q[2 * (size_t)m_pad + i0], Q[2 * (size_t)m_pad + i1]};
+    Top5 L[2];
+    float bound[2], thr[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { L[t].d[r] = inf_<float>(); L[t].j[r] = 0x7fffffff; }
+        const int i = t ? i1 : i0;
+        const float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
+        const int lo = max(0, min(i - 2, m - 5));  // five distinct indices around the query's own
+        float mx = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int j = lo + k;
+            mx = fmaxf(mx, dist2<float>(x, y, z, Q[j], Q[(size_t)m_pad + j], Q[2 * (size_t)m_pad + j]));
+        }
+        bound[t] = (mx < inf_<float>()) ? __uint_as_float(__float_as_uint(mx) + 1u) : mx;
+        thr[t] = bound[t];
+    }
+
+    const int ntile = (wseg + NN2_TQW - 1) / NN2_TQW;
+    for (int k = 0; k < ntile; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int v = threadIdx.x + r * NN_BLOCK;
+            const int ww = v / 192, rem = v % 192;
+            const int a = rem / 64, e = (rem % 64) * 4;
+            const int off = k * NN2_TQW + e;
+            const int src = q0 + ww * wseg + off;
+            if (off < wseg && src < m_pad)
+                *reinterpret_cast<float4*>(&sq[ww][a][e]) = *reinterpret_cast<const float4*>(&Q[(size_t)a * m_pad + src]);
+        }
+        __syncthreads();
+        const int tile0 = my0 + k * NN2_TQW;
+        const int len = min(NN2_TQW, my1 - tile0);
+        for (int c = 0; c < len; c += C) {
+            f2 dd[C];
+            float cmin0 = inf_<float>(), cmin1 = inf_<float>();
+#pragma unroll
+            for (int kk = 0; kk < C; kk += 4) {
+                const float4 qx4 = *reinterpret_cast<const float4*>(&sq[w][0][c + kk]);
+                const float4 qy4 = *reinterpret_cast<const float4*>(&sq[w][1][c + kk]);
+                const float4 qz4 = *reinterpret_cast<const float4*>(&sq[w][2][c + kk]);
+                const f2 qxa = f2{qx4.x, qx4.y}, qxb = f2{qx4.z, qx4.w};
+                const f2 qya = f2{qy4.x, qy4.y}, qyb = f2{qy4.z, qy4.w};
+                const f2 qza = f2{qz4.x, qz4.y}, qzb = f2{qz4.z, qz4.w};
+                dd[kk + 0] = pk_dist2<0>(qxa, qya, qza, px, py, pz);
+                dd[kk + 1] = pk_dist2<1>(qxa, qya, qza, px, py, pz);
+                dd[kk + 2] = pk_dist2<0>(qxb, qyb, qzb, px, py, pz);
+                dd[kk + 3] = pk_dist2<1>(qxb, qyb, qzb, px, py, pz);
+                cmin0 = fmin_(fmin_(cmin0, dd[kk].x), dd[kk + 1].x);
+                cmin0 = fmin_(fmin_(cmin0, dd[kk + 2].x), dd[kk + 3].x);
+                cmin1 = fmin_(fmin_(cmin1, dd[kk].y), dd[kk + 1].y);
+                cmin1 = fmin_(fmin_(cmin1, dd[kk + 2].y), dd[kk + 3].y);
+            }
+            const bool need = (cmin0 < thr[0]) | (cmin1 < thr[1]);
+            if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+#pragma unroll
+            for (int kk = 0; kk < C; ++kk) {
+                const int j = tile0 + c + kk;
+                const bool real = j < m;  // padded duplicates of the last point must not enter a top-k
+                if (real && dd[kk].x < thr[0]) { top5_insert(L[0], dd[kk].x, j); thr[0] = fmin_(bound[0], L[0].d[4]); }
+                if (real && dd[kk].y < thr[1]) { top5_insert(L[1], dd[kk].y, j); thr[1] = fmin_(bound[1], L[1].d[4]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            ld[w][lane + t * 64][r] = L[t].d[r];
+            lj[w][lane + t * 64][r] = L[t].j[r];
+        }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        // 4-way merge of sorted lists; on equal d the lower wave (lower indices) goes first
+        int h[4] = {0, 0, 0, 0};
+        const size_t o = ((size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * 128 + threadIdx.x) * 5;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            float bd = inf_<float>();
+            int bw = 0;
+#pragma unroll
+            for (int ww = 3; ww >= 0; --ww) {
+                const float d = h[ww] < 5 ? ld[ww][threadIdx.x][h[ww]] : inf_<float>();
+                if (d <= bd) { bd = d; bw = ww; }   // descending ww with <= : the lowest wave wins ties
+            }
+            const int hj = h[bw] < 5 ? lj[bw][threadIdx.x][h[bw]] : 0x7fffffff;
+            part_d[o + r] = bd;
+            part_j[o + r] = bd < inf_<float>() ? hj : 0x7fffffff;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) h[ww] += (ww == bw) ? 1 : 0;
+        }
+    }
+}
+
+// merge the S per-segment top-5 lists of every query (ascending segments, earlier segment first on equal d),
+// drop rank 0, store the 4 neighbour indices
+__global__ void knn4_merge_kernel(const float* __restrict__ part_d, const int32_t* __restrict__ part_j, int S, int n_pad,
+                                  int m, int32_t* __restrict__ nbr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Top5 L;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) { L.d[r] = part_d[(size_t)i * 5 + r]; L.j[r] = part_j[(size_t)i * 5 + r]; }
+    for (int s = 1; s < S; ++s) {
+        const size_t o = ((size_t)s * n_pad + i) * 5;
+        for (int r = 0; r < 5; ++r) {
+            const float d = part_d[o + r];
+            if (!(d < L.d[4])) break;  // lists are sorted: nothing further in this segment can enter
+            top5_insert(L, d, part_j[o + r]);
+        }
+    }
+#pragma unroll
+    for (int r = 1; r < 5; ++r) nbr[(size_t)i * 4 + (r - 1)] = L.j[r];
+}
+
+// PCA normal of every model point from its 4 neighbours, entirely on the device: float covariance in the
+// order of src/CUDA/CPU_ICP_point_to-plane.cpp:217-246 (bar = sum * 0.25f, A += (x-bar)(y-bar), not divided by
+// k), then a cyclic-Jacobi eigen-solve in fp64 registers (stands in for the reference's HOST loop of
+// LAPACKE_ssyev, src/ICP_point_to_plane.cu:429-438) and the eigenvector of the eigenvalue of smallest magnitude
+// (cblas_isamin over the ascending eigenvalues, first on ties).  Writes the padded SoA normal cloud directly.
+template <typename F>
+__global__ void normals_kernel(const F* __restrict__ Q, int m, int m_pad, const int32_t* __restrict__ nbr,
+                               F* __restrict__ Nrm)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m_pad) return;
+    const int src = i < m ? i : m - 1;  // padding replicates the last point's normal (never referenced)
+    float x[4], y[4], z[4];
+    float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int s = nbr[(size_t)src * 4 + j];
+        x[j] = (float)Q[s];
+        y[j] = (float)Q[(size_t)m_pad + s];
+        z[j] = (float)Q[2 * (size_t)m_pad + s];
+        bx += x[j]; by += y[j]; bz += z[j];
+    }
+    const float qa = 1.0f / 4.0f;
+    bx *= qa; by *= qa; bz *= qa;
+    float A[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dx = x[j] - bx, dy = y[j] - by, dz = z[j] - bz;
+        A[0] += dx * dx; A[1] += dx * dy; A[2] += dx * dz;
+        A[3] += dy * dy; A[4] += dy * dz; A[5] += dz * dz;
+    }
+    // symmetric 3x3 in named scalars (no runtime-indexed arrays -> no scratch)
+    double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
+    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = a01 * a01 + a02 * a02 + a12 * a12;
+        const double dia = a00 * a00 + a11 * a11 + a22 * a22;
+        if (off <= 1e-34 * dia || off == 0.0) break;
+        // rotation (p,q) = (0,1): r = 2
+        if (a01 != 0.0) {
+            const double th = (a11 - a00) / (2.0 * a01);
+            const double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            a00 -= t * a01; a11 += t * a01; a01 = 0.0;
+            const double rp = a02, rq = a12;
+            a02 = c * rp - s * rq; a12 = s * rp + c * rq;
+            double p, q;
+            p = v00; q = v01; v00 = c * p - s * q; v01 = s * p + c * q;
+            p = v10; q = v11; v10 = c * p - s * q; v11 = s * p + c * q;
+            p = v20; q = v21; v20 = c * p - s * q; v21 = s * p + c * q;
+        }
+        // (0,2): r = 1
+        if (a02 != 0.0) {
+            const double th = (a22 - a00) / (2.0 * a02);
+            const double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            a00 -= t * a02; a22 += t * a02; a02 = 0.0;
+            const double rp = a01, rq = a12;
+            a01 = c * rp - s * rq; a12 = s * rp + c * rq;
+            double p, q;
+            p = v00; q = v02; v00 = c * p - s * q; v02 = s * p + c * q;
+            p = v10; q = v12; v10 = c * p - s * q; v12 = s * p + c * q;
+            p = v20; q = v22; v20 = c * p - s * q; v22 = s * p + c * q;
+        }
+        // (1,2): r = 0
+        if (a12 != 0.0) {
+            const double th = (a22 - a11) / (2.0 * a12);
+            const double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            a11 -= t * a12; a22 += t * a12; a12 = 0.0;
+            const double rp = a01, rq = a02;
+            a01 = c * rp - s * rq; a02 = s * rp + c * rq;
+            double p, q;
+            p = v01; q = v02; v01 = c * p - s * q; v02 = s * p + c * q;
+            p = v11; q = v12; v11 = c * p - s * q; v12 = s * p + c * q;
+            p = v21; q = v22; v21 = c * p - s * q; v22 = s * p + c * q;
+        }
+    }
+    // ascending eigenvalues (stable w.r.t. the original slot), then the first of smallest |w| as floats
+    double w0 = a00, w1 = a11, w2 = a22;
+    double e0x = v00, e0y = v10, e0z = v20, e1x = v01, e1y = v11, e1z = v21, e2x = v02, e2y = v12, e2z = v22;
+#define ICP_SWAP_EIG(wa, ax, ay, az, wb, bx_, by_, bz_) \
+    if (wb < wa) { double tw = wa; wa = wb; wb = tw; double tx = ax; ax = bx_; bx_ = tx; double ty = ay; ay = by_; by_ = ty; double tz = az; az = bz_; bz_ = tz; }
+    ICP_SWAP_EIG(w0, e0x, e0y, e0z, w1, e1x, e1y, e1z)
+    ICP_SWAP_EIG(w0, e0x, e0y, e0z, w2, e2x, e2y, e2z)
+    ICP_SWAP_EIG(w1, e1x, e1y, e1z, w2, e2x, e2y, e2z)
+#undef ICP_SWAP_EIG
+    double nx = e0x, ny = e0y, nz = e0z;
+    float wm = fabsf((float)w0);
+    if (fabsf((float)w1) < wm) { wm = fabsf((float)w1); nx = e1x; ny = e1y; nz = e1z; }
+    if (fabsf((float)w2) < wm) { nx = e2x; ny = e2y; nz = e2z; }
+    Nrm[i] = (F)nx;
+    Nrm[(size_t)m_pad + i] = (F)ny;
+    Nrm[2 * (size_t)m_pad + i] = (F)nz;
+}
+
+// ------------------------------------------------------------------------------------------------
+// OS1-16 polar -> Cartesian (mm), one range per lane
+// ------------------------------------------------------------------------------------------------
+__global__ void os1_conversion_kernel(const uint32_t* __restrict__ r, int n, uint32_t encoder0,
+                                      const float* __restrict__ altitude, const float* __restrict__ azimuth,
+                                      float* __restrict__ xyz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int azimuth_block = i / 16, channel = i % 16;
+    const unsigned long long counter = ((unsigned long long)encoder0 + (unsigned long long)azimuth_block * 88ull) % 90112ull;
+    const float theta = (float)(2.0 * M_PI * ((double)counter / 90112.0 + (double)azimuth[channel] / 360.0));
+    const float phi = (float)(2.0 * M_PI * (double)altitude[channel] / 360.0);
+    const float rr = (float)r[i];
+    const float ct = cosf(theta), st = sinf(theta), cp = cosf(phi), sp = sinf(phi);
+    xyz[3 * (size_t)i + 0] = rr * ct * cp;
+    xyz[3 * (size_t)i + 1] = -rr * st * cp;
+    xyz[3 * (size_t)i + 2] = rr * sp;
+}
+
+// raw OS1-16 packets (12 608 B each: 16 azimuth blocks x [16 B header | 64 channels x 12 B | 4 B status]) ->
+// ranges [mm] + Cartesian points [mm] in one pass; one lane per (packet, block, beam).  Replaces the host
+// parse loop + H2D + Conversion of src/CUDA/GPU_point_to_point_real.cu:457-487,538-563.  Byte-granular reads
+// (the 20-bit range sits at an arbitrary byte offset); 3 bytes per lane, ~0.8 MB for the hall dump.
+__global__ void os1_packets_kernel(const uint8_t* __restrict__ packets, int n_packets, const float* __restrict__ altitude,
+                                   const float* __restrict__ azimuth, uint32_t* __restrict__ ranges,
+                                   float* __restrict__ xyz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_packets * 256) return;
+    const int packet = i / 256, blk = (i / 16) % 16, beam = i % 16;
+    const int ch = 2 + 4 * beam;  // the 16 lasers of an OS1-16 sit in channels 2, 6, ..., 62
+    const size_t w = (size_t)packet * 12608 + (size_t)blk * 788 + 16 + 12 * (size_t)ch;
+    const uint32_t r = (uint32_t)packets[w] | ((uint32_t)packets[w + 1] << 8) | (((uint32_t)packets[w + 2] & 0xFu) << 16);
+    const uint32_t encoder0 = (uint32_t)packets[12] | ((uint32_t)packets[13] << 8);  // first block of the first packet
+    ranges[i] = r;
+    const int azimuth_block = i / 16;
+    const unsigned long long counter = ((unsigned long long)encoder0 + (unsigned long long)azimuth_block * 88ull) % 90112ull;
+    const float theta = (float)(2.0 * M_PI * ((double)counter / 90112.0 + (double)azimuth[beam] / 360.0));
+    const float phi = (float)(2.0 * M_PI * (double)altitude[beam] / 360.0);
+    const float rr = (float)r;
+    const float ct = cosf(theta), st = sinf(theta), cp = cosf(phi), sp = sinf(phi);
+    xyz[3 * (size_t)i + 0] = rr * ct * cp;
+    xyz[3 * (size_t)i + 1] = -rr * st * cp;
+    xyz[3 * (size_t)i + 2] = rr * sp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch geometry + launchers
+// ------------------------------------------------------------------------------------------------
+template <typename F> struct NNCfg;
+template <> struct NNCfg<float> { static constexpr int T = 4; static constexpr int TQ = 2048; };
+template <> struct NNCfg<double> { static constexpr int T = 2; static constexpr int TQ = 1024; };
+
+// tuning knobs (read once): ICP_NN_T = points per lane {1,2,4,8}, ICP_NN_SPLITS = forced segment
+// count, ICP_NN_BLOCKS_PER_CU = occupancy target used to derive the segment count.
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+
+NNPlan nn_plan(int n, int m, int precision, int num_cus)
+{
+    NNPlan pl{};
+    pl.precision = precision;
+    pl.n = n;
+    pl.m = m;
+    pl.n_pad = pad_moving(n);
+    pl.m_pad = pad_model(m);
+    static const int env_T = env_int("ICP_NN_T", 0);
+    static const int env_S = env_int("ICP_NN_SPLITS", 0);
+    static const int env_bpc = env_int("ICP_NN_BLOCKS_PER_CU", 0);
+    static const int env_v1 = env_int("ICP_NN_V1", 0);
+    static const int env_C = env_int("ICP_NN_CHUNK", 0);
+    if (num_cus <= 0) num_cus = 256;
+    pl.version = (precision == ICP_F32 && !env_v1) ? 2 : 1;
+    pl.chunk = NN_CHUNK;
+    if (pl.version == 2) {
+        // v2: a block (4 waves) owns 64*T moving points, each wave a quarter of the block's segment.
+        // 8 resident waves per SIMD = 8 blocks per CU saturate the VALU (valu_rate probe).
+        static const int env_sparse = env_int("ICP_NN_SPARSE", 1);
+        static const int env_boxes = env_int("ICP_NN_BOXES", 1);
+        if (env_sparse && env_boxes) {
+            // sparse kernel: a block of 16 waves owns 128 moving points; split the model only while there are
+            // fewer blocks than CUs, and never below 1024 model points per block
+            pl.sparse = 1;
+            pl.cull = 1;
+            pl.chunk = 8;
+            pl.pts_per_thread = 2;
+            pl.blocks_x = pl.n_pad / 128;
+            if (n <= 0 || m <= 0) { pl.splits = 0; pl.seg_len = 0; return pl; }
+            // (an unsplit row closes without the key/ticket exchange, worth ~3 us: prefer it from half a machine up)
+            int S = (num_cus / 2 + pl.blocks_x - 1) / pl.blocks_x;
+            const int max_S = (pl.m_pad + 1023) / 1024;
+            if (S > max_S) S = max_S;
+            if (env_S > 0) S = env_S;
+            if (S < 1) S = 1;
+            int seg = round_up((pl.m_pad + S - 1) / S, 8);
+            S = (pl.m_pad + seg - 1) / seg;
+            pl.splits = S;
+            pl.seg_len = seg;
+            return pl;
+        }
+        const int bpc = env_bpc > 0 ? env_bpc : 8;
+        const int target_blocks = num_cus * bpc;
+        int T = (pl.n_pad / 256 >= target_blocks) ? 4 : 2;   // big clouds: 4 points per lane halve the LDS reads
+        if (env_T == 2 || env_T == 4) T = env_T;
+        pl.chunk = (env_C == 8 || env_C == 16) ? env_C : 16;
+        static const int env_cull = env_int("ICP_NN_CULL", 1);
+        pl.cull = (T == 2 && env_cull) ? 1 : 0;
+        if (pl.cull && env_C == 0) pl.chunk = 8;  // 16 partial sums per chunk would spill under the 64-VGPR cap
+        pl.pts_per_thread = T;
+        pl.blocks_x = pl.n_pad / (64 * T);
+        if (n <= 0 || m <= 0) { pl.splits = 0; pl.seg_len = 0; return pl; }
+        const int gran = 4 * pl.chunk;                        // four wave quarters of whole chunks
+        int S = (target_blocks + pl.blocks_x - 1) / pl.blocks_x;
+        const int max_S = (pl.m_pad + 511) / 512;             // keep >= 128 model points per wave
+        if (S > max_S) S = max_S;
+        if (env_S > 0) S = env_S;
+        if (S < 1) S = 1;
+        int seg = round_up((pl.m_pad + S - 1) / S, gran);
+        S = (pl.m_pad + seg - 1) / seg;
+        pl.splits = S;
+        pl.seg_len = seg;
+        return pl;
+    }
+    int T = precision == ICP_F64 ? NNCfg<double>::T : NNCfg<float>::T;
+    if (env_T == 1 || env_T == 2 || env_T == 4 || env_T == 8) T = env_T;
+    if (precision == ICP_F64 && T > 4) T = 4;
+    pl.pts_per_thread = T;
+    pl.blocks_x = pl.n_pad / (NN_BLOCK * pl.pts_per_thread);
+    if (n <= 0 || m <= 0) { pl.splits = 0; pl.seg_len = 0; return pl; }
+    // small clouds cannot fill 256 CUs along the moving axis alone: split the model range over
+    // grid.y until every CU holds `bpc` blocks of 4 waves.
+    const int bpc = env_bpc > 0 ? env_bpc : 2;
+    const int target_blocks = num_cus * bpc;
+    int S = (target_blocks + pl.blocks_x - 1) / pl.blocks_x;
+    const int max_S = (pl.m_pad + 255) / 256;  // keep >= 256 model points per segment
+    if (S > max_S) S = max_S;
+    if (env_S > 0) S = env_S;
+    if (S < 1) S = 1;
+    int seg = round_up((pl.m_pad + S - 1) / S, NN_CHUNK);
+    S = (pl.m_pad + seg - 1) / seg;
+    pl.splits = S;
+    pl.seg_len = seg;
+    return pl;
+}
+
+template <typename F>
+static hipError_t launch_nn_t(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
+                              hipStream_t st)
+{
+    constexpr int TQ = NNCfg<F>::TQ;
+    dim3 grid(pl.blocks_x, pl.splits);
+#define ICP_LAUNCH_NN(TT)                                                                                          \
+    hipLaunchKernelGGL((nn_match_kernel<F, TT, TQ>), grid, dim3(NN_BLOCK), 0, st, (const F*)P, pl.n_pad, (const F*)Q, \
+                       pl.m_pad, pl.seg_len, (F*)part_d, part_idx)
+    switch (pl.pts_per_thread) {
+        case 1: ICP_LAUNCH_NN(1); break;
+        case 2: ICP_LAUNCH_NN(2); break;
+        case 8: if constexpr (sizeof(F) == 4) { ICP_LAUNCH_NN(8); break; }
+        default: ICP_LAUNCH_NN(4); break;
+    }
+#undef ICP_LAUNCH_NN
+    return hipGetLastError();
+}
+
+bool nn_can_fuse_tail(const NNPlan& pl) { return pl.version == 2 && pl.pts_per_thread == 2 && pl.chunk == 8 && pl.n > 0 && pl.m > 0; }
+
+int nn_block_threads(const NNPlan& pl) { return pl.sparse ? SP_NW * 64 : NN_BLOCK; }
+
+static long long* g_phase_log = nullptr;
+static long long g_phase_log_cap = 0;
+void set_phase_log(long long* dev, long long slots) { g_phase_log = dev; g_phase_log_cap = slots; }
+
+static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
+                               const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st)
+{
+    dim3 grid(pl.blocks_x, pl.splits);
+    RT<float> rt{};
+    NNFuse fuse{};
+    fuse.n = pl.n;
+    fuse.m = pl.m;
+    fuse.Q_gather = (const float*)Q;
+    fuse.tlog = g_phase_log;
+    fuse.tlog_cap = g_phase_log_cap;
+    static const int env_tpass = env_int("ICP_NN_PHASE_PASS", -1);
+    fuse.tlog_pass = env_tpass;
+    const void* Qscan = Q;
+    if (pl.cull && opt && opt->Q_scan) {
+        Qscan = opt->Q_scan;
+        fuse.seed_idx = opt->seed_idx;
+        // (the boxes describe the sparse kernel's view of the model: usable here only if that is the model's own order)
+        fuse.boxes = (pl.chunk == 8 && !opt->Q_scan_sorted) ? (const float*)opt->boxes : nullptr;
+    }
+    if (ft) {
+        if (ft->mailbox) {
+            if (!pl.sparse) return hipErrorInvalidValue;  // only the sparse kernel can be armed
+            fuse.mailbox = ft->mailbox;
+            fuse.relay = ft->relay;
+            fuse.want = ft->want;
+            fuse.resident = ft->resident ? 1 : 0;
+            fuse.store_first = ft->store_first ? 1 : 0;
+        } else {
+            for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
+            for (int k = 0; k < 3; ++k) rt.t[k] = (float)ft->t3[k];
+        }
+        fuse.apply = 1;
+        fuse.n = pl.n;
+        fuse.idx_prev = ft->idx_prev;
+        fuse.P_out = (float*)ft->P_out;
+        fuse.err_rows = ft->err_rows;
+    }
+    NNTail tail{};
+    if (ta) {
+        if (!nn_can_fuse_tail(pl)) return hipErrorInvalidValue;
+        tail.keys = ta->keys;
+        tail.tickets = ta->tickets;
+        tail.err_tile = ta->err_tile;
+        tail.idx_out = ta->idx_out;
+        tail.idx_out_odd = ta->idx_out_odd ? ta->idx_out_odd : ta->idx_out;
+        tail.Nrm = (const float*)ta->Nrm_soa;
+        tail.rows = ta->rows;
+        tail.tag = ta->tag;
+    }
+#define ICP_LAUNCH_NN2T(CU, TL)                                                                                     \
+    hipLaunchKernelGGL((nn_match_f32_v2<2, 8, CU, TL>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,      \
+                       (const float*)Qscan, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse, tail)
+#define ICP_LAUNCH_NN2(TT, CC, CU)                                                                                  \
+    hipLaunchKernelGGL((nn_match_f32_v2<TT, CC, CU, 0>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,     \
+                       (const float*)Qscan, pl.m_pad, pl.seg_len, (float*)part_d, part_idx, rt, fuse, tail)
+    if (pl.sparse) {
+        // the plan's geometry is the sparse kernel's: it needs the scan copy and its chunk boxes
+        if (!(opt && opt->Q_scan && opt->boxes)) return hipErrorInvalidValue;
+        if (pl.m_pad >= (1 << 28)) return hipErrorInvalidValue;  // the in-block merge key carries 28 index bits
+        fuse.seed_idx = opt->seed_idx;
+        fuse.boxes = (const float*)opt->boxes;
+        fuse.q_perm = opt->Q_scan_sorted ? opt->q_perm : nullptr;
+        fuse.p_perm = opt->p_perm;
+        const void* Qsp = opt->Q_scan_sorted ? opt->Q_scan_sorted : opt->Q_scan;
+        static const int env_samples = env_int("ICP_NN_SAMPLES", 1);
+        fuse.samples = env_samples ? (const float*)opt->samples : nullptr;
+        static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 64);
+        fuse.sample_groups = env_sgroups;
+        static const int env_passes = env_int("ICP_NN_PASSES", 0);
+        // seeded: few hits, long rounds; cold: short rounds so that the exchanged minima start pruning early
+        int passes = env_passes > 0 ? env_passes : ((fuse.seed_idx || fuse.samples) ? SP_MAX_PASSES : 1);
+        if (passes > SP_MAX_PASSES) passes = SP_MAX_PASSES;
+        if (fuse.resident) {
+            if (!ta || pl.splits != 1) return hipErrorInvalidValue;
+            const float* Pp = (const float*)P;
+            const float* Qp = (const float*)Qsp;
+            int n_pad = pl.n_pad, m_pad = pl.m_pad, seg = pl.seg_len;
+            float* pd = (float*)part_d;
+            void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
+            const bool diag = fuse.tlog != nullptr, perm = fuse.q_perm != nullptr;
+            const void* fns[2][2][2] = {{{(const void*)nn_match_sparse<1, false, false>, (const void*)nn_match_sparse<1, false, true>},
+                                         {(const void*)nn_match_sparse<1, true, false>, (const void*)nn_match_sparse<1, true, true>}},
+                                        {{(const void*)nn_match_sparse<2, false, false>, (const void*)nn_match_sparse<2, false, true>},
+                                         {(const void*)nn_match_sparse<2, true, false>, (const void*)nn_match_sparse<2, true, true>}}};
+            const void* fn = fns[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0][diag ? 1 : 0][perm ? 1 : 0];
+            // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
+            // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
+            // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that
+            // start late (behind the previous kernel of the stream) only delay the first pass, nothing waits on them
+            // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
+            static const int env_coop = env_int("ICP_COOP", 0);
+            if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
+            static long long capacity[2][2][2] = {{{-1, -1}, {-1, -1}}, {{-1, -1}, {-1, -1}}};   // blocks the machine holds at once, per variant
+            long long& cap = capacity[ta->metric == ICP_POINT_TO_PLANE ? 1 : 0][diag ? 1 : 0][perm ? 1 : 0];
+            if (cap < 0) {
+                int per_cu = 0, dev = 0, cus = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                    return hipErrorCooperativeLaunchTooLarge;
+                cap = (long long)per_cu * cus;
+            }
+            if ((long long)grid.x * grid.y > cap) return hipErrorCooperativeLaunchTooLarge;
+            return hipLaunchKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
+        }
+#define ICP_LAUNCH_SP3(TL, DG, PM)                                                                                 \
+    hipLaunchKernelGGL((nn_match_sparse<TL, DG, PM>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad,     \
+                       (const float*)Qsp, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail)
+#define ICP_LAUNCH_SP(TL)                                                                                          \
+    do {                                                                                                           \
+        const bool dg_ = fuse.tlog != nullptr, pm_ = fuse.q_perm != nullptr;                                       \
+        if (dg_) { if (pm_) ICP_LAUNCH_SP3(TL, true, true); else ICP_LAUNCH_SP3(TL, true, false); }                 \
+        else { if (pm_) ICP_LAUNCH_SP3(TL, false, true); else ICP_LAUNCH_SP3(TL, false, false); }                   \
+    } while (0)
+        if (!ta) ICP_LAUNCH_SP(0);
+        else if (ta->metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_SP(2);
+        else ICP_LAUNCH_SP(1);
+#undef ICP_LAUNCH_SP3
+#undef ICP_LAUNCH_SP
+        return hipGetLastError();
+    }
+    // measured (profiles/r1/03_nn_sweep_cull.txt): without a seed the early-out variant loses to the plain
+    // packed kernel on every cloud (its bound starts at +inf), with one it wins on every cloud
+    const bool cull = pl.cull && Qscan != Q && fuse.seed_idx != nullptr;
+    if (!cull) { Qscan = Q; fuse.seed_idx = nullptr; fuse.boxes = nullptr; }
+    if (ta) {
+        const bool plane = ta->metric == ICP_POINT_TO_PLANE;
+        if (cull) { if (plane) ICP_LAUNCH_NN2T(1, 2); else ICP_LAUNCH_NN2T(1, 1); }
+        else { if (plane) ICP_LAUNCH_NN2T(0, 2); else ICP_LAUNCH_NN2T(0, 1); }
+    } else if (pl.pts_per_thread == 4) {
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(4, 8, 0); else ICP_LAUNCH_NN2(4, 16, 0);
+    } else if (cull) {
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, 1); else ICP_LAUNCH_NN2(2, 16, 1);
+    } else {
+        if (pl.chunk == 8) ICP_LAUNCH_NN2(2, 8, 0); else ICP_LAUNCH_NN2(2, 16, 0);
+    }
+#undef ICP_LAUNCH_NN2
+#undef ICP_LAUNCH_NN2T
+    return hipGetLastError();
+}
+
+bool nn_can_fuse_transform(const NNPlan& pl) { return pl.version == 2 && pl.n > 0 && pl.m > 0; }
+
+hipError_t launch_nn(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
+                     const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st)
+{
+    if (pl.n <= 0 || pl.m <= 0) return hipSuccess;
+    if (pl.version == 2) return launch_nn_v2(pl, P, Q, part_d, part_idx, ft, opt, ta, st);
+    if (ft || ta) return hipErrorInvalidValue;  // only the packed fp32 kernel carries the fused front end
+    return pl.precision == ICP_F64 ? launch_nn_t<double>(pl, P, Q, part_d, part_idx, st)
+                                   : launch_nn_t<float>(pl, P, Q, part_d, part_idx, st);
+}
+
+hipError_t launch_merge(const NNPlan& pl, const void* part_d, const int32_t* part_idx, int32_t* idx, hipStream_t st)
+{
+    if (pl.n <= 0 || pl.m <= 0) return hipSuccess;
+    const int blocks = (pl.n + 255) / 256;
+    if (pl.precision == ICP_F64)
+        hipLaunchKernelGGL((merge_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)part_d, part_idx,
+                           pl.splits, pl.n_pad, pl.n, pl.m, idx);
+    else
+        hipLaunchKernelGGL((merge_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)part_d, part_idx,
+                           pl.splits, pl.n_pad, pl.n, pl.m, idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_moments(const NNPlan& pl, int metric, const void* P, const void* Q, const void* Nrm,
+                          const void* part_d, const int32_t* part_idx, int32_t* idx, double* partials, int* blocks,
+                          double tag, const double* err_rows, int err_count, hipStream_t st)
+{
+    int nb = (pl.n + MOM_BLOCK - 1) / MOM_BLOCK;
+    if (nb > MOM_MAX_BLOCKS) nb = MOM_MAX_BLOCKS;
+    *blocks = nb;
+    if (nb <= 0) return hipSuccess;
+#define ICP_LAUNCH_MOM(F, MET)                                                                                     \
+    hipLaunchKernelGGL((moments_kernel<F, MET>), dim3(nb), dim3(MOM_BLOCK), 0, st, (const F*)P, pl.n, pl.n_pad,      \
+                       (const F*)Q, pl.m, pl.m_pad, (const F*)Nrm, (const F*)part_d, part_idx, pl.splits, idx, partials, tag, err_rows, err_count)
+    if (pl.precision == ICP_F64) {
+        if (metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_MOM(double, ICP_POINT_TO_PLANE);
+        else ICP_LAUNCH_MOM(double, ICP_POINT_TO_POINT);
+    } else {
+        if (metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_MOM(float, ICP_POINT_TO_PLANE);
+        else ICP_LAUNCH_MOM(float, ICP_POINT_TO_POINT);
+    }
+#undef ICP_LAUNCH_MOM
+    return hipGetLastError();
+}
+
+hipError_t launch_transform_error(int precision, void* P, int n, int n_pad, const double* R9, const double* t3,
+                                  const void* Q, int m_pad, const int32_t* idx, double* err_partials, int* blocks,
+                                  hipStream_t st)
+{
+    int nb = (n_pad + TR_BLOCK - 1) / TR_BLOCK;
+    if (nb > MOM_MAX_BLOCKS) nb = MOM_MAX_BLOCKS;
+    *blocks = nb;
+    if (nb <= 0) return hipSuccess;
+    if (precision == ICP_F64) {
+        RT<double> rt;
+        for (int k = 0; k < 9; ++k) rt.r[k] = R9[k];
+        for (int k = 0; k < 3; ++k) rt.t[k] = t3[k];
+        hipLaunchKernelGGL((transform_error_kernel<double>), dim3(nb), dim3(TR_BLOCK), 0, st, (double*)P, n, n_pad, rt,
+                           (const double*)Q, m_pad, idx, err_partials);
+    } else {
+        RT<float> rt;
+        for (int k = 0; k < 9; ++k) rt.r[k] = (float)R9[k];
+        for (int k = 0; k < 3; ++k) rt.t[k] = (float)t3[k];
+        hipLaunchKernelGGL((transform_error_kernel<float>), dim3(nb), dim3(TR_BLOCK), 0, st, (float*)P, n, n_pad, rt,
+                           (const float*)Q, m_pad, idx, err_partials);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_blocks, const double* err_partials,
+                           int err_blocks, int rows_have_err, hipStream_t st)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, mom_out, mom_partials, mom_blocks, err_partials,
+                       err_blocks, rows_have_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int blocks = (n_pad + 255) / 256;
+    if (precision == ICP_F64)
+        hipLaunchKernelGGL((aos_to_soa_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)aos, n, n_pad,
+                           (double*)soa);
+    else
+        hipLaunchKernelGGL((aos_to_soa_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)aos, n, n_pad,
+                           (float*)soa);
+    return hipGetLastError();
+}
+
+hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, void* aos, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int blocks = (n + 255) / 256;
+    if (precision == ICP_F64)
+        hipLaunchKernelGGL((soa_to_aos_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)soa, n, n_pad,
+                           (double*)aos);
+    else
+        hipLaunchKernelGGL((soa_to_aos_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)soa, n, n_pad,
+                           (float*)aos);
+    return hipGetLastError();
+}
+
+void knn4_v2_geometry(int m, int num_cus, int* n_pad, int* blocks_x, int* splits, int* seg_len)
+{
+    const int m_pad = pad_model(m);
+    *n_pad = round_up(m, 128);
+    *blocks_x = *n_pad / 128;
+    if (num_cus <= 0) num_cus = 256;
+    int S = (num_cus * 4 + *blocks_x - 1) / *blocks_x;        // 4 blocks (16 waves) per CU
+    const int max_S = (m_pad + 511) / 512;
+    if (S > max_S) S = max_S;
+    if (S < 1) S = 1;
+    int seg = round_up((m_pad + S - 1) / S, 4 * KNN_C);
+    *splits = (m_pad + seg - 1) / seg;
+    *seg_len = seg;
+}
+
+hipError_t launch_knn4_v2(const void* Q, int m, int num_cus, float* part_d, int32_t* part_j, int32_t* nbr, hipStream_t st)
+{
+    if (m <= 0) return hipSuccess;
+    int n_pad, bx, S, seg;
+    knn4_v2_geometry(m, num_cus, &n_pad, &bx, &S, &seg);
+    hipLaunchKernelGGL(knn4_f32_v2, dim3(bx, S), dim3(NN_BLOCK), 0, st, (const float*)Q, m, pad_model(m), n_pad, seg, part_d,
+                       part_j);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(knn4_merge_kernel, dim3((m + 255) / 256), dim3(256), 0, st, (const float*)part_d,
+                       (const int32_t*)part_j, S, n_pad, m, nbr);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn4(const NNPlan& pl, const void* Q, int32_t* nbr, hipStream_t st)
+{
+    if (pl.m <= 0) return hipSuccess;
+    const int blocks = (pl.m + NN_BLOCK - 1) / NN_BLOCK;
+    if (pl.precision == ICP_F64)
+        hipLaunchKernelGGL((knn4_kernel<double, 1024>), dim3(blocks), dim3(NN_BLOCK), 0, st, (const double*)Q, pl.m,
+                           pl.m_pad, nbr);
+    else
+        hipLaunchKernelGGL((knn4_kernel<float, 2048>), dim3(blocks), dim3(NN_BLOCK), 0, st, (const float*)Q, pl.m,
+                           pl.m_pad, nbr);
+    return hipGetLastError();
+}
+
+hipError_t launch_normals(int precision, const void* Q, int m, int m_pad, const int32_t* nbr, void* Nrm_soa,
+                          hipStream_t st)
+{
+    if (m <= 0) return hipSuccess;
+    const int blocks = (m_pad + 127) / 128;
+    if (precision == ICP_F64)
+        hipLaunchKernelGGL((normals_kernel<double>), dim3(blocks), dim3(128), 0, st, (const double*)Q, m, m_pad, nbr,
+                           (double*)Nrm_soa);
+    else
+        hipLaunchKernelGGL((normals_kernel<float>), dim3(blocks), dim3(128), 0, st, (const float*)Q, m, m_pad, nbr,
+                           (float*)Nrm_soa);
+    return hipGetLastError();
+}
+
+hipError_t launch_os1_packets(const uint8_t* packets, int n_packets, const float* alt16, const float* az16,
+                              uint32_t* ranges, float* xyz_aos, hipStream_t st)
+{
+    if (n_packets <= 0) return hipSuccess;
+    const int n = n_packets * 256;
+    hipLaunchKernelGGL(os1_packets_kernel, dim3((n + 255) / 256), dim3(256), 0, st, packets, n_packets, alt16, az16, ranges,
+                       xyz_aos);
+    return hipGetLastError();
+}
+
+hipError_t launch_os1_conversion(const uint32_t* ranges, int n, uint32_t encoder0, const float* alt16,
+                                 const float* az16, float* xyz_aos, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(os1_conversion_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ranges, n, encoder0, alt16, az16,
+                       xyz_aos);
+    return hipGetLastError();
+}
+
+}  // namespace icp
