@@ -23,7 +23,9 @@
 #include <atomic>
 #include <chrono>
 #include <unistd.h>
+#include <sched.h>
 #include <limits>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -388,6 +390,44 @@ static void mailbox_selftest(icp_ctx* c, int slot, const char* when)
     bar_fence();
 }
 
+// The loop is a conversation between one host thread and the GPU (mailbox through the PCIe BAR, moment rows through pinned
+// host memory): on a two-socket machine every message of a thread running on the other socket crosses the socket link
+// too -- measured on the hall loop 13.05 us per iteration from the GPU's own NUMA node, 14.4-14.6 us from the other one,
+// and a coin toss when the scheduler chooses (tools/numa_probe.py).  So the thread that creates a context is
+// restricted to the CPUs sysfs lists as local to the device (a whole socket; ICP_PIN=0 leaves the affinity alone; nothing
+// happens when sysfs has no answer, when the thread's mask has no local CPU, or when it is already inside).
+static void pin_thread_to_device_node(int device)
+{
+    const char* v = std::getenv("ICP_PIN");
+    if (v && v[0] == '0') return;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char* p = bus; *p; ++p) *p = (char)std::tolower((unsigned char)*p);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+    std::FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[4096] = {0};
+    const bool got = std::fgets(line, sizeof line, f) != nullptr;
+    std::fclose(f);
+    if (!got) return;
+    cpu_set_t local, cur, both;
+    CPU_ZERO(&local);
+    for (const char* p = line; *p;) {                      // "0-63,128-191"
+        char* end = nullptr;
+        const long a = std::strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') { b = std::strtol(p + 1, &end, 10); p = end; }
+        for (long k = a; k <= b && k < CPU_SETSIZE; ++k) if (k >= 0) CPU_SET((int)k, &local);
+        if (*p == ',') ++p; else break;
+    }
+    if (sched_getaffinity(0, sizeof cur, &cur) != 0) return;
+    CPU_AND(&both, &cur, &local);
+    if (CPU_COUNT(&both) == 0 || CPU_COUNT(&both) == CPU_COUNT(&cur)) return;
+    (void)sched_setaffinity(0, sizeof both, &both);
+}
+
 int icp_create(int device, icp_ctx** out)
 {
     if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
@@ -404,6 +444,7 @@ int icp_create(int device, icp_ctx** out)
     if (!c) return fail(ICP_ERR_NOMEM, "context allocation failed");
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    pin_thread_to_device_node(device);   // (before the pinned host buffers are allocated and first touched)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
