@@ -160,7 +160,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx.set_profiling(7)   # HIP events around every 7th launch of the loop's kernel (with a resident kernel: every 7th registration)
+    STRIDE = int(os.environ.get("ICP_BENCH_TIMING_STRIDE", "7"))
+    ctx.set_profiling(STRIDE)   # HIP events around every 7th launch of the loop's kernel (with a resident kernel: every 7th registration)
     in_library = not (use_dist and not native_comm)   # nothing Python has to do between the steps
     TOL, MAX_ITER = 1e-6, 100   # src/CUDA/GPU_point_to_point_real.cu:18,404-405
     stats = {"registrations": 0, "iterations": 0}
@@ -185,7 +186,7 @@ def main():
             stats["iterations"] += k
 
     run_steps(W)
-    ctx.set_profiling(7)    # restart the kernel-time accumulators for the timed region
+    ctx.set_profiling(STRIDE)    # restart the kernel-time accumulators for the timed region
     stats = {"registrations": 0, "iterations": 0}
     sync()
     t0 = time.perf_counter()
@@ -246,7 +247,7 @@ def main():
                                  "a step = one iteration of such a registration",
                        "registrations_timed": stats["registrations"],
                        "iterations_per_registration": stats["iterations"] / max(1, stats["registrations"]),
-                       "collective": (("sum of 32 doubles per iteration over the node's ranks through shared host memory "
+                       "collective": (("sum of the loop's moment vector (the 19 doubles point-to-point uses) per iteration over the node's ranks through shared host memory "
                                        "(icp_comm_init_local), rank order, every rank keeps its resident kernel") if local_comm else
                                       ("1 RCCL all-reduce of 32 doubles per iteration, issued by "
                                        + ("libicp_mi355x on the loop's stream" if native_comm else "torch.distributed"))) if use_dist else "none"},

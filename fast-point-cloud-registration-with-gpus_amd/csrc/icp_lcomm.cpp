@@ -120,14 +120,23 @@ int lcomm_allreduce_sum_f64(LocalComm* c, double* v, int count, std::string& err
     for (int k = 0; k < count; ++k) sum[k] = 0.0;
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
+    // Wait for ALL slots first, sweeping over them: the lines of the ranks that are already there are pulled into
+    // this core's cache while the last rank is still on its way, so what is left after its arrival is one line
+    // transfer, not world - 1 of them one after the other.  The sum is then taken in rank order.
+    for (int pending = c->world; pending > 0;) {
+        pending = 0;
+        for (int r = 0; r < c->world; ++r) {
+            const Slot* sl = c->slot(buf, r);
+            if (sl->seq.load(std::memory_order_acquire) != s) { ++pending; continue; }
+            __builtin_prefetch(&sl->v[7]); __builtin_prefetch(&sl->v[15]); __builtin_prefetch(&sl->v[23]); __builtin_prefetch(&sl->v[31]);
+        }
+        if (pending && (++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+            err = "a rank did not reach the exchange (30 s)";
+            return ICP_ERR_HIP;
+        }
+    }
     for (int r = 0; r < c->world; ++r) {
         const Slot* sl = c->slot(buf, r);
-        while (sl->seq.load(std::memory_order_acquire) != s) {
-            if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
-                err = "a rank did not reach the exchange (30 s)";
-                return ICP_ERR_HIP;
-            }
-        }
         for (int k = 0; k < count; ++k) sum[k] += sl->v[k];   // rank order: the same bits on every rank
     }
     std::memcpy(v, sum, (size_t)count * sizeof(double));
