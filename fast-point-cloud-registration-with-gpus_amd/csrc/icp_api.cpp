@@ -69,6 +69,35 @@ static inline void bar_fence()
 #endif
 }
 
+// One message = one 64-byte line (layout: icp_kernels.h, NNMailbox): each 32-byte half is written by ONE vector store
+// and carries the tag in its last word, then one fence pushes the line out.  rt may be NULL (commands that carry no
+// transform); seq = 0 clears the mailbox (no tag ever equals 0).
+#if defined(__x86_64__)
+__attribute__((target("avx")))
+#endif
+static inline void post_message(icp::NNMailbox* mb, const double* R9, const double* t3, int cmd, double seq)
+{
+    alignas(32) uint32_t line[16];
+    std::memset(line, 0, sizeof line);
+    const uint32_t tag = seq == 0.0 ? 0u : icp::mailbox_tag(seq);
+    if (R9 && t3) {
+        for (int k = 0; k < 12; ++k) {
+            const float f = (float)(k < 9 ? R9[k] : t3[k - 9]);
+            std::memcpy(&line[icp::mailbox_rt_word(k)], &f, sizeof f);
+        }
+    }
+    line[icp::ICP_MB_CMD] = (uint32_t)cmd;
+    line[icp::ICP_MB_TAG0] = tag;
+    line[icp::ICP_MB_TAG1] = tag;
+#if defined(__x86_64__)
+    _mm256_store_si256(reinterpret_cast<__m256i*>(&mb->w[0]), _mm256_load_si256(reinterpret_cast<const __m256i*>(&line[0])));
+    _mm256_store_si256(reinterpret_cast<__m256i*>(&mb->w[8]), _mm256_load_si256(reinterpret_cast<const __m256i*>(&line[8])));
+#else
+    std::memcpy((void*)mb->w, line, sizeof line);
+#endif
+    bar_fence();
+}
+
 static constexpr int kMailSlots = 4;  // armed launches: ring of mailboxes (one is live at a time)
 static constexpr size_t kPhaseSlots = 512 * 1024;  // ICP_NN_PHASES: 10 stamps per wave
 
@@ -373,21 +402,18 @@ static void mailbox_selftest(icp_ctx* c, int slot, const char* when)
     icp::NNMailbox* mb = c->h_mail + slot;
     volatile double* ack = c->h_mom;
     *ack = 0.0;
-    *(volatile double*)&mb->seq = 1.0;
-    bar_fence();
+    post_message(mb, nullptr, nullptr, icp::ICP_CMD_MATCH, 1.0);
     (void)icp::launch_mailbox_selftest(mb, c->h_mom, c->stream);
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     while (*ack != 1.0 && since() < 5.0) {}
     const double t_start = since();
-    *(volatile double*)&mb->seq = 2.0;
-    bar_fence();
+    post_message(mb, nullptr, nullptr, icp::ICP_CMD_MATCH, 2.0);
     while (*ack != 2.0 && *ack != -1.0 && since() < 10.0) {}
     std::fprintf(stderr, "[icp selftest %s slot %d] kernel running after %.6f s; live store %s after %.6f s (ack %.0f)\n", when, slot, t_start,
                  *ack == 2.0 ? "SEEN" : "NOT seen", since() - t_start, *ack);
     (void)hipStreamSynchronize(c->stream);
-    *(volatile double*)&mb->seq = 0.0;
-    bar_fence();
+    post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, 0.0);
 }
 
 // The loop is a conversation between one host thread and the GPU (mailbox through the PCIe BAR, moment rows through pinned
@@ -1163,8 +1189,7 @@ int loop_arm(icp_ctx* c)
     const int slot = (int)(c->mail_seq++ % kMailSlots);
     icp::NNMailbox* mb = c->h_mail + slot;
     const double tag = (double)(++c->tag_seq);
-    *(volatile double*)&mb->seq = 0.0;
-    bar_fence();
+    post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, 0.0);   // cleared: nothing to act on yet
     icp::NNTailArgs ta{};
     ta.metric = L.H.prm.metric;
     ta.keys = (unsigned long long*)c->keys.p;
@@ -1191,12 +1216,7 @@ void loop_release_armed(icp_ctx* c)
 {
     LoopState& L = c->loop;
     icp::NNMailbox* mb = c->h_mail + L.armed_slot;
-    for (int k = 0; k < 9; ++k) mb->rt[k] = (float)L.H.R[k];
-    for (int k = 0; k < 3; ++k) mb->rt[9 + k] = (float)L.H.t[k];
-    mb->cmd = icp::ICP_CMD_TRANSFORM_MATCH;
-    bar_fence();
-    *(volatile double*)&mb->seq = L.armed_tag;
-    bar_fence();
+    post_message(mb, L.H.R, L.H.t, icp::ICP_CMD_TRANSFORM_MATCH, L.armed_tag);
     L.applied_idx = L.armed_prev_cur;
     L.H.note_applied();
     L.mom_blocks = c->plan.blocks_x;
@@ -1215,8 +1235,7 @@ void loop_withdraw_armed(icp_ctx* c)
     LoopState& L = c->loop;
     if (!L.armed) return;
     icp::NNMailbox* mb = c->h_mail + L.armed_slot;
-    *(volatile double*)&mb->seq = -L.armed_tag;
-    bar_fence();
+    post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, L.armed_tag);
     std::swap(c->P, c->P2);
     c->cur = L.armed_prev_cur;
     L.armed = false;
@@ -1253,8 +1272,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     const int pass_cap = L.H.prm.max_iter + 2;
     const double base = (double)(c->tag_seq + 1);
     c->tag_seq += (uint64_t)pass_cap + 1;
-    *(volatile double*)&mb->seq = 0.0;
-    bar_fence();
+    post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, 0.0);   // cleared
     const int c0 = c->cur;
     const icp::NNCullInputs cull = make_cull(c, L.matched ? (const int32_t*)c->idx[c0].p : nullptr);
     icp::NNTailArgs ta{};
@@ -1285,12 +1303,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     *fell_back = false;
     if (time_this) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     if (c->trace_passes) std::fprintf(stderr, "[icp trace] resident launch: mailbox %p relay %p base %.0f\n", (void*)mb, (void*)c->relay, base);
-    auto send = [&](int cmd, double seq) {
-        mb->cmd = cmd;
-        bar_fence();
-        *(volatile double*)&mb->seq = seq;
-        bar_fence();
-    };
+    auto send = [&](int cmd, double seq) { post_message(mb, L.H.R, L.H.t, cmd, seq); };   // (R, t: ignored by a plain MATCH)
     int k = *k_io, d = *d_io, sent = 0, matched = 0, rc = ICP_OK;
     bool alive = true;
     while (!d && k < max_steps && sent < pass_cap) {
@@ -1299,8 +1312,6 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
         const bool final_only = L.H.next_is_final();
         const int cmd = !apply ? icp::ICP_CMD_MATCH : (final_only ? icp::ICP_CMD_TRANSFORM_ONLY : icp::ICP_CMD_TRANSFORM_MATCH);
         if (apply) {
-            for (int q = 0; q < 9; ++q) mb->rt[q] = (float)L.H.R[q];
-            for (int q = 0; q < 3; ++q) mb->rt[9 + q] = (float)L.H.t[q];
             L.applied_idx = c->cur;
             L.H.note_applied();
         }
@@ -1329,14 +1340,15 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
             std::fprintf(stderr, "[icp trace] resident pass %d cmd %d: %.2f us from message to reduced rows + solve (row 0 after %.2f us, all rows after %.2f us)\n", sent - 1, cmd,
                          1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count(), 1e6 * c->tr_first_row, 1e6 * c->tr_last_row);
         if (rc != ICP_OK) {
-            if (c->trace) std::fprintf(stderr, "[icp trace] resident pass %d failed: mailbox %p reads back seq %.0f cmd %d (sent seq %.0f)\n",
-                                       sent - 1, (void*)mb, *(volatile double*)&mb->seq, *(volatile int*)&mb->cmd, base + (double)(sent - 1));
+            if (c->trace) std::fprintf(stderr, "[icp trace] resident pass %d failed: mailbox %p reads back tags %08x %08x cmd %d (sent tag %08x)\n",
+                                       sent - 1, (void*)mb, *(volatile uint32_t*)&mb->w[icp::ICP_MB_TAG0], *(volatile uint32_t*)&mb->w[icp::ICP_MB_TAG1],
+                                       (int)*(volatile uint32_t*)&mb->w[icp::ICP_MB_CMD], icp::mailbox_tag(base + (double)(sent - 1)));
             break;
         }
         ++k;
         if (cmd == icp::ICP_CMD_TRANSFORM_ONLY) { alive = false; break; }  // the kernel ends itself after that pass
     }
-    if (alive) send(icp::ICP_CMD_EXIT, -(base + (double)sent));
+    if (alive) send(icp::ICP_CMD_EXIT, base + (double)sent);
     if (time_this && rc == ICP_OK) {
         float ms = 0.f;
         // the kernel ends within microseconds of the exit message: spin on the event instead of a blocking wait

@@ -2,6 +2,7 @@
 // Internal to libicp_mi355x.so; the public surface is include/icp_mi355x.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include <stdint.h>
 
 #include "../../include/icp_mi355x.h"
@@ -43,15 +44,27 @@ size_t elem_size(int precision);
 
 // the transform of the previous pass, fused into the front of the matching kernel (fp32 kernel only):
 // P_out <- R * P_in + t, err_rows[block_x] <- sum |p_new - q[idx_prev]|^2
-// mailbox of an armed / resident launch, in pinned mapped host memory: the host stores rt and cmd, then (fenced)
-// seq = +tag to let the waiting kernel go, or seq = -tag to withdraw it.  Block 0 polls it and relays the message to
-// the other blocks through a copy in device memory (`relay`).
-struct NNMailbox {
-    float rt[12];  // R row-major, then t -- already rounded to the storage precision
-    double seq;
-    int cmd;       // ICP_CMD_*
-    int pad_;
+// Mailbox of an armed / resident launch: ONE 64-byte line, written whole by the host and read whole by ONE load of the
+// waiting wave (16 lanes x 4 bytes) -- detecting the message and receiving it are the same memory round trip.
+// The line is two 32-byte halves, each carrying the message's tag in its last word next to its share of the payload:
+//   w[0..6] = rt[0..6]   w[7] = tag   |   w[8..12] = rt[7..11]   w[13] = cmd   w[14] = tag   w[15] = 0
+// (rt = R row-major, then t, rounded to the storage precision).  The host writes each half with one 32-byte vector
+// store; whatever the fabric does with the line on its way (a write-combining buffer flushed in two pieces, a read split
+// into sectors), a half whose tag is new carries new payload, and the reader accepts the line only when BOTH tags are
+// the one it waits for.  tag = low 31 bits of the pass's sequence number, top bit set (a cleared mailbox never
+// matches); cmd = ICP_CMD_EXIT under the awaited tag withdraws the kernel.  Where the mailbox lives in host memory,
+// block 0 polls it and relays the line to the other blocks through a copy in device memory (`relay`).
+#if defined(__HIPCC__)
+#define ICP_HOST_DEVICE __host__ __device__
+#else
+#define ICP_HOST_DEVICE
+#endif
+struct alignas(64) NNMailbox {
+    uint32_t w[16];
 };
+enum { ICP_MB_TAG0 = 7, ICP_MB_CMD = 13, ICP_MB_TAG1 = 14 };
+ICP_HOST_DEVICE inline uint32_t mailbox_tag(double seq) { return (uint32_t)(unsigned long long)seq | 0x80000000u; }
+ICP_HOST_DEVICE inline int mailbox_rt_word(int k) { return k < 7 ? k : k + 1; }   // the word rt[k] travels in
 enum { ICP_CMD_EXIT = 0, ICP_CMD_MATCH = 1, ICP_CMD_TRANSFORM_MATCH = 2, ICP_CMD_TRANSFORM_ONLY = 3 };
 hipError_t launch_mailbox_selftest(const NNMailbox* mb, double* ack, hipStream_t st);
 struct NNFusedTransform {

@@ -459,7 +459,9 @@ struct NNFuse {
     int resident;            // resident launch: after a pass the block waits for the next message instead of ending
     NNMailbox* relay;        // ... relayed by block 0 to the other blocks through this device-memory copy
     const NNMailbox* mailbox; // armed launch (sparse kernel): (R, t) arrive here from the host AFTER the kernel was enqueued
-    double want;             // ... under this sequence number (+want: go, -want: withdrawn)
+    double want;             // ... under this sequence number (it also tags the rows the pass writes)
+    unsigned int want_lo;    // its low 32 bits (the mailbox tag of pass p is mailbox_tag(want + p) = (want_lo + p) | top bit:
+                             // integer arithmetic -- a double -> integer conversion on the device expands to f64 fma code)
     const float* samples;    // sparse kernel: one point per chunk of the scan copy (SoA, round_up(m_pad/8, 8) entries) or NULL
     long long* tlog;         // diagnostic (ICP_NN_PHASES): per-wave s_memrealtime stamps, 10 slots per wave, or NULL
     long long tlog_cap;      // slots available
@@ -1159,50 +1161,38 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     if (fuse.mailbox != nullptr) {
         const double want = fuse.want + (double)pass;
         if (w == 0) {
-            // Block 0 alone talks to the host: it polls the mailbox in pinned host memory (one reader: ~1.3 us each
-            // way; 128 readers would queue up to ~20 us, tools/mailbox_probe.hip) and relays the message through
-            // device memory, where the other blocks wait for it with agent-scope loads.
-            // (no relay: the mailbox itself is device memory the host writes through the BAR, every block polls it)
+            // One load fetches the whole line (lane l reads word l & 15): the message is there when both halves carry
+            // the awaited tag, and then it has been received as well -- no second trip for the payload.
+            // Where the mailbox is host memory, block 0 alone talks to the host (one reader: ~1.3 us each way; 128
+            // readers would queue up to ~20 us, tools/mailbox_probe.hip) and relays the line through device memory,
+            // where the other blocks wait for it with agent-scope loads.  (no relay: the mailbox itself is device
+            // memory the host writes through the BAR, every block polls it)
             const bool first = (blockIdx.x == 0 && blockIdx.y == 0) || fuse.relay == nullptr;
-            const NNMailbox* src = first ? fuse.mailbox : fuse.relay;
-            double sq_ = 0.0;
+            const uint32_t* src = (first ? fuse.mailbox : fuse.relay)->w + (lane & 15);
+            const uint32_t want32 = (fuse.want_lo + (uint32_t)pass) | 0x80000000u;
+            uint32_t word = 0u;
+            bool ok = false;
             for (int spins = 0; spins < (1 << 22); ++spins) {
-                sq_ = first ? __hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                            : __hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sq_ == want || sq_ == -want) break;
+                word = first ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                             : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (uint32_t)__builtin_amdgcn_readlane((int)word, ICP_MB_TAG0) == want32 &&
+                     (uint32_t)__builtin_amdgcn_readlane((int)word, ICP_MB_TAG1) == want32;
+                if (ok) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            // the message was written before its sequence number
-            if (first) __atomic_thread_fence(__ATOMIC_ACQUIRE); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const bool go = sq_ == want;
-            float v = 0.f;
-            int cm = ICP_CMD_EXIT;
-            if (first) {
-                if (lane < 12) v = __hip_atomic_load(&src->rt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (go) cm = __hip_atomic_load(&src->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                // relay (also a withdrawal or a time-out: the other blocks must end too)
-                if (fuse.relay != nullptr) {
-                    NNMailbox* dst = fuse.relay;
-                    if (lane < 12) __hip_atomic_store(&dst->rt[lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane == 0) __hip_atomic_store(&dst->cmd, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    if (lane == 0) __hip_atomic_store(&dst->seq, go ? want : -want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                }
-            } else {
-                if (lane < 12) v = __hip_atomic_load(&src->rt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (go) cm = __hip_atomic_load(&src->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (lane < 12) msg[lane] = v;
-            if (lane == 0) reinterpret_cast<int*>(msg)[12] = cm;
+            // (a time-out reads as a withdrawal: the other blocks must end too)
+            if (!ok) word = (lane & 15) == ICP_MB_CMD ? (uint32_t)ICP_CMD_EXIT : ((lane & 15) == ICP_MB_TAG0 || (lane & 15) == ICP_MB_TAG1) ? want32 : 0u;
+            if (first && fuse.relay != nullptr && lane < 16)
+                __hip_atomic_store(&fuse.relay->w[lane], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one line, one store
+            if (lane < 16) reinterpret_cast<uint32_t*>(msg)[lane] = word;
         }
         __syncthreads();
-        cmd = reinterpret_cast<const int*>(msg)[12];
+        cmd = reinterpret_cast<const int*>(msg)[ICP_MB_CMD];
         if (cmd == ICP_CMD_EXIT) return;  // withdrawn (the loop stopped) or timed out: nothing more is touched
 #pragma unroll
-        for (int k = 0; k < 9; ++k) rt.r[k] = msg[k];
+        for (int k = 0; k < 9; ++k) rt.r[k] = msg[mailbox_rt_word(k)];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) rt.t[k] = msg[9 + k];
+        for (int k = 0; k < 3; ++k) rt.t[k] = msg[mailbox_rt_word(9 + k)];
         row_tag = want;
         if (pass > 0) {
             // the seeds of a resident pass are the matches of the one before: wave 0 left their coordinates in LDS
@@ -1631,13 +1621,14 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
 __global__ void mailbox_selftest_kernel(const NNMailbox* mb, double* ack)
 {
     if (threadIdx.x == 0) __hip_atomic_store(ack, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    double s = 0.0;
-    for (int spins = 0; spins < (1 << 20); ++spins) {
-        s = __hip_atomic_load(&mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (s == 2.0) break;
-        __builtin_amdgcn_s_sleep(2);
+    const uint32_t want32 = mailbox_tag(2.0);
+    bool ok = false;
+    for (int spins = 0; spins < (1 << 20) && !ok; ++spins) {
+        const uint32_t word = __hip_atomic_load(&mb->w[threadIdx.x & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ok = (uint32_t)__builtin_amdgcn_readlane((int)word, ICP_MB_TAG0) == want32 && (uint32_t)__builtin_amdgcn_readlane((int)word, ICP_MB_TAG1) == want32;
+        if (!ok) __builtin_amdgcn_s_sleep(2);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(ack, s == 2.0 ? 2.0 : -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(ack, ok ? 2.0 : -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 hipError_t launch_mailbox_selftest(const NNMailbox* mb, double* ack, hipStream_t st)
 {
@@ -2694,6 +2685,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             fuse.mailbox = ft->mailbox;
             fuse.relay = ft->relay;
             fuse.want = ft->want;
+            fuse.want_lo = (unsigned int)(unsigned long long)ft->want;
             fuse.resident = ft->resident ? 1 : 0;
             fuse.store_first = ft->store_first ? 1 : 0;
         } else {
