@@ -92,7 +92,15 @@ def attach_local_comm(ctx, dist):
     summed over the ranks through shared memory (~1 us) and icp_loop_run keeps its resident kernel."""
     rank, world = dist.get_rank(), dist.get_world_size()
     box = [ctx.comm_random_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
+    # the 128 bytes travel over a host-side (gloo) group where one can be made: nothing about this communicator
+    # needs the device collective library to be up
+    group = None
+    if dist.get_backend() != "gloo":
+        try:
+            group = dist.new_group(backend="gloo")
+        except Exception:  # noqa: BLE001
+            group = None
+    dist.broadcast_object_list(box, src=0, group=group)
     ctx.comm_init_local(box[0], rank, world)
 
 
