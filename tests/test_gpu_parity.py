@@ -649,3 +649,92 @@ def test_million_point_self_match_is_the_identity(ctx, pkg):
     for i in np.random.default_rng(5).integers(0, W * W, 64):
         d = (D[i][None, :] - M) ** 2
         assert int(((d[:, 0] + d[:, 1]) + d[:, 2]).argmin()) == int(idx[i])
+
+
+def test_two_ranks_large_model_sharded_like_configs4(pkg, orc):
+    """BASELINE configs[4] in small: a synthetic grid cloud large enough for the hierarchical search (131 769 model points,
+    replicated), the MOVING cloud split over two ranks (both on cuda:0 here; too many rows for a resident kernel each is
+    not required; here 2 x 96 rows so that both resident kernels fit the one GPU they share), one sum per iteration through the node-local communicator:
+    both ranks end with the same bits, the run equals the oracle's on the whole cloud, indices bit-exact"""
+    import subprocess, sys, json
+    code = (
+        "import sys, os, json, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from __graft_entry__ import load_package\n"
+        "pkg = load_package()\n"
+        "rank, world, idh = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]\n"
+        "M = pkg.datasets.synthetic_grid(363, np.float32)\n"
+        "D = pkg.datasets.make_model_gpu(M[np.random.default_rng(7).integers(0, 363 * 363, 24000)], (0.03, -0.02, 0.01), (0.02, -0.01, 0.015))\n"
+        "Ds, begin = pkg.distributed.shard(D, rank, world)\n"
+        "with pkg.Context(0) as ctx:\n"
+        "    ctx.set_model(M); ctx.set_moving(Ds)\n"
+        "    ctx.comm_init_local(bytes.fromhex(idh), rank, world)\n"
+        "    ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=4, tol=1e-9, fixed_iterations=True)\n"
+        "    done = False\n"
+        "    while not done:\n"
+        "        _, done = ctx.loop_run(1 << 20)\n"
+        "    st = ctx.loop_state(); idx = ctx.loop_indices()\n"
+        "    ctx.comm_destroy()\n"
+        "print(json.dumps(dict(it=st['iterations'], T=st['T'].tolist(), err=st['err'].tolist(), begin=int(begin), idx=idx.tolist())))\n")
+    idh = pkg.Context.comm_random_id().hex()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", idh], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    got = [json.loads(o.strip().splitlines()[-1]) for o, _ in outs]
+    assert got[0]["it"] == got[1]["it"] and got[0]["T"] == got[1]["T"] and got[0]["err"] == got[1]["err"]
+    M = pkg.datasets.synthetic_grid(363, np.float32)
+    D = pkg.datasets.make_model_gpu(M[np.random.default_rng(7).integers(0, 363 * 363, 24000)], (0.03, -0.02, 0.01), (0.02, -0.01, 0.015))
+    want = orc.icp_p2p_f32x(D, M, 4, 1e-9, fixed=True)
+    assert_same_run(got[0]["it"], np.array(got[0]["err"]), np.array(got[0]["T"]), want, 1e-9, fp32=True)
+    if got[0]["it"] == want["iterations"]:
+        assert np.array_equal(np.concatenate([got[0]["idx"], got[1]["idx"]]), want["idx"])
+
+
+def test_creating_thread_lands_on_the_device_numa_node(pkg):
+    """icp_create narrows the calling thread to the CPUs sysfs lists as local to the device; ICP_PIN=0 does not"""
+    import subprocess, sys, json
+    code = (
+        "import os, sys, json, ctypes\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from __graft_entry__ import load_package\n"
+        "pkg = load_package()\n"
+        "before = sorted(os.sched_getaffinity(0))\n"
+        "with pkg.Context(0) as ctx:\n"
+        "    after = sorted(os.sched_getaffinity(0))\n"
+        "hip = ctypes.CDLL('libamdhip64.so'); buf = ctypes.create_string_buffer(64); hip.hipDeviceGetPCIBusId(buf, 64, 0)\n"
+        "p = '/sys/bus/pci/devices/' + buf.value.decode().lower() + '/local_cpulist'\n"
+        "local = open(p).read().strip() if os.path.exists(p) else ''\n"
+        "print(json.dumps(dict(before=before, after=after, local=local)))\n")
+    def run(env):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    def parse(s):
+        cpus = set()
+        for part in filter(None, s.split(",")):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        return cpus
+    r = run({"ICP_PIN": "0"})
+    assert r["after"] == r["before"]
+    r = run({"ICP_PIN": "1"})
+    local = parse(r["local"])
+    want = sorted(set(r["before"]) & local)
+    if local and want and len(want) < len(r["before"]):
+        assert r["after"] == want
+    else:
+        assert r["after"] == r["before"]      # nothing to narrow on this machine
+
+
+def test_large_model_and_too_many_rows_for_a_resident_kernel(ctx, pkg, orc):
+    """hierarchical search on the one-launch-per-pass path: 33 000 moving points are 264 rows, more blocks than the machine
+    holds at once, so every pass is its own (armed) launch of the hierarchical kernel: same run as the oracle"""
+    M = pkg.datasets.synthetic_grid(363, np.float32)
+    D = pkg.datasets.make_model_gpu(M[np.random.default_rng(11).integers(0, 363 * 363, 33000)], (0.03, -0.02, 0.01), (0.02, -0.01, 0.015))
+    res = ctx.point_to_point(D, M, max_iter=2, tol=1e-9, fixed_iterations=True)
+    want = orc.icp_p2p_f32x(D, M, 2, 1e-9, fixed=True)
+    assert_same_run(res.iterations, res.err, res.T, want, 1e-9, fp32=True)
+    if res.iterations == want["iterations"]:
+        assert np.array_equal(res.idx, want["idx"])
