@@ -201,6 +201,12 @@ int orc_solve6(const double* C, const double* b, double* x)
     return 0;
 }
 
+/* threads of the matching loops (orc_nn_*): 1 = the reference's scalar loop (default); bench.py's all-cores baseline
+ * raises it.  Every moving point is independent, the results do not depend on it. */
+static int orc_threads_ = 1;
+void orc_set_threads(int k) { orc_threads_ = k > 0 ? k : 1; }
+int orc_get_threads(void) { return orc_threads_; }
+
 /* ---- precision-generic point-to-point path ------------------------------------------------ */
 #define REAL double
 #define SUF f64

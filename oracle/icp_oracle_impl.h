@@ -24,6 +24,11 @@ void FN(orc_nn)(const REAL* pt, int n, const REAL* q, int m, int* q_idx)
     const REAL* qx = q;
     const REAL* qy = q + (size_t)m;
     const REAL* qz = q + 2 * (size_t)m;
+    /* (the moving points are independent: orc_set_threads(k > 1) spreads them over k threads for the all-cores CPU
+     * baseline of bench.py; the default, 1, is the reference's scalar loop) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(orc_threads_)
+#endif
     for (int j = 0; j < n; j++) {
         const REAL px = pt[j], py = pt[j + (size_t)n], pz = pt[j + 2 * (size_t)n];
         REAL best = 0;

@@ -42,6 +42,10 @@ class Oracle:
         return "f64" if np.dtype(dtype) == np.float64 else "f32"
 
     # ---- matching -------------------------------------------------------------------------------
+    def set_threads(self, k):
+        """threads of the matching loops (default 1: the reference's scalar loop); results do not depend on it"""
+        self.lib.orc_set_threads(int(k))
+
     def nn(self, P, Q):
         """P, Q (N,3)/(M,3) AoS of one dtype -> idx (N,) int32; first minimum of (dx^2+dy^2)+dz^2"""
         P = np.ascontiguousarray(P)
