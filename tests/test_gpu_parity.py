@@ -556,7 +556,7 @@ def test_matching_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier):
     monkeypatch.setenv("ICP_NN_HIER", hier)
     rng = np.random.default_rng(20260210 + int(sort))
     with pkg.Context(0) as c:
-        for case in range(40):
+        for case in range(int(os.environ.get("ICP_FUZZ_CASES", "40"))):     # (a longer soak: ICP_FUZZ_CASES=1000)
             n, m = int(rng.integers(1, 700)), int(rng.integers(1, 900))
             kp, km = rng.choice(["uniform", "clustered", "lattice", "line"], 2)
             scale = float(rng.choice([1e-3, 1.0, 1e3]))
@@ -573,7 +573,7 @@ def test_registration_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier)
     monkeypatch.setenv("ICP_NN_HIER", hier)
     rng = np.random.default_rng(7300 + int(sort))
     with pkg.Context(0) as c:
-        for case in range(8):
+        for case in range(max(1, int(os.environ.get("ICP_FUZZ_CASES", "40")) // 5)):
             m = int(rng.integers(300, 2500))
             n = int(rng.integers(200, 2500))
             M = _fuzz_cloud(rng, m, str(rng.choice(["uniform", "clustered", "lattice"])), 1.0)
