@@ -1289,34 +1289,53 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         // model first -- one point per chunk, at most 2048 of them, staged in LDS (over the hit list and the merge
         // scratch, both idle until later), a share per wave -- and every wave starts from the block-wide minimum
         // bumped by an ulp.  Any model point gives a valid bound; the scan below is then as selective as a seeded one.
+        // A round measures the points against up to 2048 samples (a 10 M-point model: 7.4 -> 6.5 ms for the cold pass
+        // with 2048 instead of 512).  On a small model that many samples cost as much as they save unless the
+        // relative-index seeds are poor (hall scan against its slightly moved self: 13.8 -> 12.0 us with 64 samples;
+        // a 128 x 128 grid against a copy 0.8 away: 73 -> 53 us with 2048), so a probe round of 8 groups decides.
         constexpr int SMAX = 2048;
         static_assert(3 * SMAX * 4 <= HITS_BYTES + 2 * MD_BYTES, "the staged samples overlay the hit list and merge scratch");
         const int ns8 = ((m_pad / 8) + 7) / 8;                 // groups of 8 samples in the array
         const int ns_pad = ns8 * 8;
-        const int gcap = min(max(fuse.sample_groups, 1), SMAX / 8);
-        const int gs = (ns8 + gcap - 1) / gcap;                // group stride: <= gcap groups are staged
-        const int ng = (ns8 + gs - 1) / gs;
         float* sl = reinterpret_cast<float*>(lds_raw);         // [3][SMAX]
-        for (int v = threadIdx.x; v < ng * 6; v += SP_NW * 64) {
-            const int gp = v / 6, r = v % 6, a = r >> 1, hh = r & 1;
-            *reinterpret_cast<float4*>(sl + a * SMAX + gp * 8 + hh * 4) =
-                *reinterpret_cast<const float4*>(fuse.samples + (size_t)a * ns_pad + (size_t)gp * gs * 8 + hh * 4);
-        }
-        __syncthreads();
-        float sb[2] = {inf_<float>(), inf_<float>()};
-        for (int gp = w; gp < ng; gp += SP_NW) {
-            const float4* a = reinterpret_cast<const float4*>(sl + gp * 8);
-            const float4* b = reinterpret_cast<const float4*>(sl + SMAX + gp * 8);
-            const float4* c = reinterpret_cast<const float4*>(sl + 2 * SMAX + gp * 8);
-            scan8_min(a[0], a[1], b[0], b[1], c[0], c[1], px, py, pz, sb);
-        }
-        if (real[0]) atomicMin(&smin[lane], __float_as_uint(sb[0]));
-        if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(sb[1]));
-        __syncthreads();  // (also: the staging area is free again)
+        const int gfull = min(max(fuse.sample_groups, 1), SMAX / 8);
+        constexpr int GPROBE = 8;
+        // Small models (the full round would cost a good part of the pass itself): probe first -- did 64 samples cut
+        // the bound of an eighth of the block's points to a quarter?  then the seeds were poor and the full round
+        // follows.  Larger models: 64 samples are too coarse to tell, and the full round is cheap next to the pass.
+        int gcap = (m_pad <= 32768 && gfull > GPROBE) ? GPROBE : gfull;
+        for (;;) {   // (one body for both rounds: inlined twice it spilled registers in the sorted-view variant)
+            // one round over <= gcap groups spread evenly over the model
+            const int gs = (ns8 + gcap - 1) / gcap;            // group stride: <= gcap groups are staged
+            const int ng = (ns8 + gs - 1) / gs;
+            for (int v = threadIdx.x; v < ng * 6; v += SP_NW * 64) {
+                const int gp = v / 6, r = v % 6, a = r >> 1, hh = r & 1;
+                *reinterpret_cast<float4*>(sl + a * SMAX + gp * 8 + hh * 4) =
+                    *reinterpret_cast<const float4*>(fuse.samples + (size_t)a * ns_pad + (size_t)gp * gs * 8 + hh * 4);
+            }
+            __syncthreads();
+            float sb[2] = {inf_<float>(), inf_<float>()};
+            for (int gp = w; gp < ng; gp += SP_NW) {
+                const float4* a = reinterpret_cast<const float4*>(sl + gp * 8);
+                const float4* b = reinterpret_cast<const float4*>(sl + SMAX + gp * 8);
+                const float4* c = reinterpret_cast<const float4*>(sl + 2 * SMAX + gp * 8);
+                scan8_min(a[0], a[1], b[0], b[1], c[0], c[1], px, py, pz, sb);
+            }
+            if (real[0]) atomicMin(&smin[lane], __float_as_uint(sb[0]));
+            if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(sb[1]));
+            __syncthreads();  // (also: the staging area is free again)
+            int helped = 0;   // points whose bound fell to a quarter or less
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const unsigned int v = smin[lane + t * 64];
-            if (real[t] && v < 0x7f800000u) best[t] = fmin_(best[t], __uint_as_float(v + 1u));
+            for (int t = 0; t < 2; ++t) {
+                const unsigned int v = smin[lane + t * 64];
+                const bool better = real[t] && v < 0x7f800000u && __uint_as_float(v + 1u) < best[t];
+                const bool much = better && !(__uint_as_float(v + 1u) >= 0.25f * best[t]);
+                if (better) best[t] = __uint_as_float(v + 1u);
+                helped += (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(much));
+            }
+            // (every wave holds the same points and reads the same minima: the same count, the same decision everywhere)
+            if (gcap == gfull || helped < 16) break;
+            gcap = gfull;
         }
     }
     ICP_PHASE(2)
@@ -2727,7 +2746,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         const void* Qsp = opt->Q_scan_sorted ? opt->Q_scan_sorted : opt->Q_scan;
         static const int env_samples = env_int("ICP_NN_SAMPLES", 1);
         fuse.samples = env_samples ? (const float*)opt->samples : nullptr;
-        static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 64);
+        static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 256);   // the cold start's full round (its probe round is 8 groups)
         fuse.sample_groups = env_sgroups;
         static const int env_passes = env_int("ICP_NN_PASSES", 0);
         // seeded: few hits, long rounds; cold: short rounds so that the exchanged minima start pruning early
