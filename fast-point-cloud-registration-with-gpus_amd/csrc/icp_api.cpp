@@ -865,11 +865,14 @@ int icp_nn_match_bench_ex(icp_ctx* c, int reps, int seeded, float* total_ms)
 int icp_nn_launch_info(icp_ctx* c, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad)
 {
     if (!c) return fail(ICP_ERR_INVALID, "null context");
-    if (splits) *splits = c->plan.splits;
-    if (blocks) *blocks = c->plan.blocks_x * c->plan.splits;
-    if (threads) *threads = icp::nn_block_threads(c->plan);
-    if (n_pad) *n_pad = c->plan.n_pad;
-    if (m_pad) *m_pad = c->plan.m_pad;
+    // (the geometry of the resident clouds, also before their first launch has fixed the plan)
+    const icp::NNPlan pl = (c->plan.n == c->n && c->plan.m == c->m && c->plan.precision == c->prec) ? c->plan
+                                                                                                       : icp::nn_plan(c->n, c->m, c->prec, c->num_cus);
+    if (splits) *splits = pl.splits;
+    if (blocks) *blocks = pl.blocks_x * pl.splits;
+    if (threads) *threads = icp::nn_block_threads(pl);
+    if (n_pad) *n_pad = pl.n_pad;
+    if (m_pad) *m_pad = pl.m_pad;
     return ICP_OK;
 }
 
