@@ -73,9 +73,13 @@ static inline void bar_fence()
 // and carries the tag in its last word, then one fence pushes the line out.  rt may be NULL (commands that carry no
 // transform); seq = 0 clears the mailbox (no tag ever equals 0).
 #if defined(__x86_64__)
-__attribute__((target("avx")))
+__attribute__((target("avx"))) static void store_line_avx(uint32_t* dst, const uint32_t* line)
+{
+    _mm256_store_si256(reinterpret_cast<__m256i*>(dst), _mm256_load_si256(reinterpret_cast<const __m256i*>(line)));
+    _mm256_store_si256(reinterpret_cast<__m256i*>(dst + 8), _mm256_load_si256(reinterpret_cast<const __m256i*>(line + 8)));
+}
 #endif
-static inline void post_message(icp::NNMailbox* mb, const double* R9, const double* t3, int cmd, double seq)
+static inline void post_message(icp::NNMailbox* mb, const double* R9, const double* t3, int cmd, double seq, bool wide_stores = true)
 {
     alignas(32) uint32_t line[16];
     std::memset(line, 0, sizeof line);
@@ -90,11 +94,21 @@ static inline void post_message(icp::NNMailbox* mb, const double* R9, const doub
     line[icp::ICP_MB_TAG0] = tag;
     line[icp::ICP_MB_TAG1] = tag;
 #if defined(__x86_64__)
-    _mm256_store_si256(reinterpret_cast<__m256i*>(&mb->w[0]), _mm256_load_si256(reinterpret_cast<const __m256i*>(&line[0])));
-    _mm256_store_si256(reinterpret_cast<__m256i*>(&mb->w[8]), _mm256_load_si256(reinterpret_cast<const __m256i*>(&line[8])));
-#else
-    std::memcpy((void*)mb->w, line, sizeof line);
+    static const bool have_avx = __builtin_cpu_supports("avx");
+    if (have_avx && wide_stores) {
+        store_line_avx(mb->w, line);
+        bar_fence();
+        return;
+    }
 #endif
+    // no 32-byte stores: the payload first, then (fenced) the two tags -- the reader still accepts only a line whose
+    // tags both match, so the order of the words within a half does not matter
+    volatile uint32_t* dst = mb->w;
+    for (int k = 0; k < 16; ++k)
+        if (k != icp::ICP_MB_TAG0 && k != icp::ICP_MB_TAG1) dst[k] = line[k];
+    bar_fence();
+    dst[icp::ICP_MB_TAG0] = tag;
+    dst[icp::ICP_MB_TAG1] = tag;
     bar_fence();
 }
 
@@ -177,6 +191,7 @@ struct icp_ctx {
     size_t rows_cap = 0;               // rows available in mom_partials / h_mom_partials
     bool fused_tail = true;            // ICP_FUSED_TAIL=0 keeps matching and moments as two kernels
     bool use_boxes = true;             // ICP_NN_BOXES=0 disables the bounding-box level of the early-out
+    bool mail_wide = true;             // ICP_MAILBOX_AVX=0: write the mailbox line word by word (payload, fence, tags) -- the path of a CPU without AVX
     double* mom_dev = nullptr;
     double* h_mom = nullptr;  // pinned: the reduced ICP_NMOM vector as the host solve reads it
     // single-GPU fast path: the moments / transform kernels store their per-block partial rows straight
@@ -510,6 +525,7 @@ int icp_create(int device, icp_ctx** out)
     if (const char* v = std::getenv("ICP_TRACE")) { c->trace = v[0] == '1' || v[0] == '2'; c->trace_passes = v[0] == '2'; }
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_MAILBOX_AVX")) c->mail_wide = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_PHASES")) {
         // diagnostic: the matching kernel stamps its phases per wave; the last launch's stamps are written to the
         // named file (raw int64) when the context is destroyed -- tools/phase_report.py reads it
@@ -1219,7 +1235,7 @@ void loop_release_armed(icp_ctx* c)
 {
     LoopState& L = c->loop;
     icp::NNMailbox* mb = c->h_mail + L.armed_slot;
-    post_message(mb, L.H.R, L.H.t, icp::ICP_CMD_TRANSFORM_MATCH, L.armed_tag);
+    post_message(mb, L.H.R, L.H.t, icp::ICP_CMD_TRANSFORM_MATCH, L.armed_tag, c->mail_wide);
     L.applied_idx = L.armed_prev_cur;
     L.H.note_applied();
     L.mom_blocks = c->plan.blocks_x;
@@ -1238,7 +1254,7 @@ void loop_withdraw_armed(icp_ctx* c)
     LoopState& L = c->loop;
     if (!L.armed) return;
     icp::NNMailbox* mb = c->h_mail + L.armed_slot;
-    post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, L.armed_tag);
+    post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, L.armed_tag, c->mail_wide);
     std::swap(c->P, c->P2);
     c->cur = L.armed_prev_cur;
     L.armed = false;
@@ -1306,7 +1322,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     *fell_back = false;
     if (time_this) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     if (c->trace_passes) std::fprintf(stderr, "[icp trace] resident launch: mailbox %p relay %p base %.0f\n", (void*)mb, (void*)c->relay, base);
-    auto send = [&](int cmd, double seq) { post_message(mb, L.H.R, L.H.t, cmd, seq); };   // (R, t: ignored by a plain MATCH)
+    auto send = [&](int cmd, double seq) { post_message(mb, L.H.R, L.H.t, cmd, seq, c->mail_wide); };   // (R, t: ignored by a plain MATCH)
     int k = *k_io, d = *d_io, sent = 0, matched = 0, rc = ICP_OK;
     bool alive = true;
     while (!d && k < max_steps && sent < pass_cap) {

@@ -384,13 +384,14 @@ def test_fused_and_two_kernel_forms_agree(pkg, orc, golden, tail):
 LOOP_FORMS = {
     "resident": {},
     "resident_host_mailbox": {"ICP_MAILBOX": "host"},
+    "resident_plain_stores": {"ICP_MAILBOX_AVX": "0"},   # the mailbox line written word by word (a CPU without AVX)
     "armed": {"ICP_RESIDENT": "0"},
     "stepwise": {"ICP_RESIDENT": "0", "ICP_ARMED": "0"},
 }
 
 
 def _run_form(pkg, monkeypatch, env, fn):
-    for k in ("ICP_MAILBOX", "ICP_RESIDENT", "ICP_ARMED"):
+    for k in ("ICP_MAILBOX", "ICP_MAILBOX_AVX", "ICP_RESIDENT", "ICP_ARMED"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)           # read by icp_create
