@@ -1521,6 +1521,8 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 if (slot_ + 9 < fuse.tlog_cap) {
                     fuse.tlog[slot_ + 6] = dg_t[0]; fuse.tlog[slot_ + 7] = dg_t[1]; fuse.tlog[slot_ + 8] = dg_t[2];
                     fuse.tlog[slot_ + 9] = ((long long)dg_sh << 32) | (long long)dg_h;
+                    // wave 2: where the block ran (XCC_ID << 32 | HW_ID) -- tools/cu_gaps.py builds per-CU timelines from it
+                    if (w == 2) fuse.tlog[slot_ + 6] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
                 }
             }
         }

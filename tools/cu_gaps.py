@@ -1,3 +1,6 @@
+"""Per-CU timeline of a phase log of the hierarchical kernel (ICP_NN_PHASES=file, large models): wave 2 of every block
+leaves XCC_ID << 32 | HW_ID in its slot 6; prints the duration of the blocks and the gap between the end of one block and the
+start of the next on the same CU.   usage: python tools/cu_gaps.py ph.bin"""
 import sys, numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.int64); a = a[:len(a)//10*10].reshape(-1,10)
 nb = len(a)//16
