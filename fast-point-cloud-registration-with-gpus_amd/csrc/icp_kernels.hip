@@ -1539,11 +1539,16 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 if (r < round_passes && c0 < c_hi) find_pass(c0, pb[r][0], pb[r][1], B);
             }
         }
-        for (; r < round_passes; ++r) {
-            const int c0 = rb + (r * SP_NW + w) * 64;
+        // (the boxes of two passes are requested together: one memory latency for both)
+        for (; r < round_passes; r += 2) {
+            const int c0 = rb + (r * SP_NW + w) * 64, c1 = c0 + SP_NW * 64;
             if (c0 >= c_hi) break;
-            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
-            find_pass(c0, bp[0], bp[1], B);
+            const bool two = r + 1 < round_passes && c1 < c_hi;
+            const float4* bp0 = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
+            const float4* bp1 = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(two && c1 + lane < c_hi ? c1 + lane : c_lo) * 8);
+            const float4 a0 = bp0[0], a1 = bp0[1], d0 = bp1[0], d1 = bp1[1];
+            find_pass(c0, a0, a1, B);
+            if (two) find_pass(c1, d0, d1, B);
         }
         __syncthreads();
         process_hits(*hcount);
