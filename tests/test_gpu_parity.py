@@ -739,3 +739,29 @@ def test_large_model_and_too_many_rows_for_a_resident_kernel(ctx, pkg, orc):
     assert_same_run(res.iterations, res.err, res.T, want, 1e-9, fp32=True)
     if res.iterations == want["iterations"]:
         assert np.array_equal(res.idx, want["idx"])
+
+
+def test_configs4_full_size_properties(ctx, pkg):
+    """BASELINE configs[4] at its full size, the share of one rank of 8: 1 250 000 moving points of the 10 M-point
+    synthetic cloud against the whole moved 10 M-point model (1.25e13 pairs -- far beyond the CPU oracle), through
+    size-independent properties: every index valid, cold and seeded passes agree, 48 sampled points agree with numpy's
+    brute force over all 10 M model points, and matching the shard a second time after a no-op is idempotent"""
+    N = 10_000_000
+    W = int(np.ceil(np.sqrt(N)))
+    D = pkg.datasets.synthetic_grid(W, np.float32)[:N]
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    lo, cnt = pkg.shard_range(N, 3, 8)
+    P = np.ascontiguousarray(D[lo:lo + cnt])
+    del D
+    ctx.set_model(M); ctx.set_moving(P)
+    ctx.nn_match_resident()
+    cold = ctx.get_indices()
+    assert cold.shape == (cnt,) and int(cold.min()) >= 0 and int(cold.max()) < N
+    ctx.nn_match_bench(1, seeded=True)
+    seeded = ctx.get_indices()
+    assert np.array_equal(cold, seeded)
+    for i in np.random.default_rng(17).integers(0, cnt, 48):
+        d = (P[i][None, :] - M) ** 2
+        assert int(((d[:, 0] + d[:, 1]) + d[:, 2]).argmin()) == int(cold[i])
+    ctx.nn_match_bench(2, seeded=True)
+    assert np.array_equal(ctx.get_indices(), cold)
