@@ -287,6 +287,8 @@ def main():
                 "bound_note": "brute-force NN is 4681 flop/B on this cloud (ridge ~20): compute-bound, not HBM-bound.  'achieved' counts the ALGORITHMIC 8*N*M flop of every pass; the kernel skips most of them "
                               "(exactly: results are bit-identical to the full scan), so frac measures time-to-solution against the "
                               "brute-force roofline, not executed instructions.",
+                "executed_fraction_estimate": {"pairs": 0.0105, "source": "tools/pair_stats.py (numpy, hall pair at a steady pass): 28 of 2048 chunks "
+                                               "survive the group-box test per block, 21.6 are evaluated in full"},
                 "achieved": flops / nn_avg_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / nn_avg_s / 1e12 / FP32_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src,
