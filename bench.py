@@ -241,7 +241,7 @@ def main():
         # back-to-back launches of the stand-alone matching kernel, no other work between: the kernel-quality figure
         b2b_ms = ctx.nn_match_bench(50) / 50.0
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1", "13_pmc_hbm_traffic_sparse.json")
+        pmc = os.path.join(ROOT, "profiles", "r1", "17_pmc_hbm_traffic_sparse.json")
         if world == 1 and os.path.exists(pmc):
             # HBM bytes per launch of the seeded stand-alone matching kernel from the committed rocprofv3 PMC passes
             # (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units, FETCH doubled: gfx950 correction), scaled to the
@@ -249,7 +249,7 @@ def main():
             rec = next((v for k, v in json.load(open(pmc)).items() if "nn_match_sparse" in k), None)
             if rec:
                 traffic = rec["hbm_bytes_corrected"] * passes_per_launch
-                traffic_src = ("profiles/r1/13_pmc_hbm_traffic_sparse.json: per pass FETCH_SIZE %.0f B raw (x2 corrected) + WRITE_SIZE %.0f B, "
+                traffic_src = ("profiles/r1/17_pmc_hbm_traffic_sparse.json: per pass FETCH_SIZE %.0f B raw (x2 corrected) + WRITE_SIZE %.0f B, "
                                "times %.2f passes per launch" % (rec["fetch_bytes_raw"], rec["write_bytes"], passes_per_launch))
         out = {
             "metric": "ICP iterations/sec + NN HBM GB/s (% roofline), hall cloud",
