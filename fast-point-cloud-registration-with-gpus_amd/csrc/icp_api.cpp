@@ -150,6 +150,7 @@ struct LoopState {
     double wait_tag = 0.0;      // completion tag of the pending enqueue's rows
     // armed launch: the matching pass AFTER the pending one is already enqueued and waits for its (R, t)
     bool armed = false;
+    bool slot_written = false;   // the pending (or last completed) pass was an armed launch that left points and matches in slot order
     double armed_tag = 0.0;
     int armed_slot = 0;
     int armed_prev_cur = 0;
@@ -174,6 +175,7 @@ struct icp_ctx {
     DevBuf Qss;   // Morton-ordered scan copy (sparse kernel), when the model's own order has no locality
     DevBuf Qperm; // ... and its permutation: sorted position -> model index
     DevBuf Pperm; // slot -> moving point (Morton order of the initial positions), when the cloud's own order has no locality
+    DevBuf slot_state; // armed launches: moving points + matched model points in slot order (6 x n_pad floats)
     bool model_sorted = false, moving_sorted = false;
     // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
     DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
@@ -560,7 +562,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->slot_state, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -1054,6 +1056,7 @@ int icp_loop_enqueue(icp_ctx* c)
     L.host_reduce = host_reduce;
     L.wait_tag = (double)c->tag_seq;
     L.pending = true;
+    L.slot_written = false;   // (a plain launch: nothing in slot order)
     if (c->trace) c->tr_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
     return ICP_OK;
 }
@@ -1219,6 +1222,12 @@ int loop_arm(icp_ctx* c)
     ta.rows = c->h_mom_partials;
     ta.tag = tag;
     icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[prev_cur].p, c->P2.p, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, tag};
+    // every armed pass leaves its points and matches in slot order; the next one starts from them (one level of
+    // coalesced loads instead of slot -> point -> seed -> model point) if the pass before it was such a pass
+    if (pl.splits == 1 && c->slot_state.ensure(6 * (size_t)pl.n_pad * sizeof(float)) == hipSuccess) {
+        ft.slot_state = c->slot_state.p;
+        ft.slot_valid = L.slot_written;
+    }
     if (c->profile_stride > 0) c->nn_launch_count++;
     HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream));
     std::swap(c->P, c->P2);
@@ -1246,6 +1255,7 @@ void loop_release_armed(icp_ctx* c)
     L.wait_tag = L.armed_tag;
     L.pending = true;
     L.armed = false;
+    L.slot_written = c->plan.splits == 1 && c->slot_state.p != nullptr;
 }
 
 // the loop ended (or failed): the waiting kernel exits without touching anything; undo the bookkeeping

@@ -78,6 +78,8 @@ struct NNFusedTransform {
     double want = 0.0;                   // sequence number of the (first) message
     bool resident = false;               // the kernel stays for the whole registration: pass p is message want + p
     bool store_first = false;            // resident: the input is not P_out (pristine copy): store the cloud in pass 0 as well
+    void* slot_state = nullptr;          // armed launches: 6 x n_pad floats, points and matched model points in slot order (or NULL)
+    bool slot_valid = false;             // ... the previous pass wrote them
 };
 bool nn_can_fuse_transform(const NNPlan& pl);
 

@@ -463,6 +463,10 @@ struct NNFuse {
     unsigned int want_lo;    // its low 32 bits (the mailbox tag of pass p is mailbox_tag(want + p) = (want_lo + p) | top bit:
                              // integer arithmetic -- a double -> integer conversion on the device expands to f64 fma code)
     const float* samples;    // sparse kernel: one point per chunk of the scan copy (SoA, round_up(m_pad/8, 8) entries) or NULL
+    float* slot_state;       // sparse kernel, one launch per pass: the moving points and the matched model points IN SLOT ORDER
+                             // (6 arrays of n_pad floats: p.xyz, q.xyz), written by every such pass for the next one -- its front
+                             // end is then one level of coalesced loads instead of slot -> point -> seed -> model point; or NULL
+    int slot_valid;          // ... the previous pass wrote them: read them
     long long* tlog;         // diagnostic (ICP_NN_PHASES): per-wave s_memrealtime stamps, 10 slots per wave, or NULL
     long long tlog_cap;      // slots available
     int tlog_pass;           // resident launch: stamp this pass only (-1: every pass, the last one survives)
@@ -1095,13 +1099,18 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     // ordinary loop -- the same gathered q serves the error of that pass
     bool real[2], sok[2];
     float sq[2][3];
+    const bool from_slots = fuse.slot_state != nullptr && fuse.slot_valid != 0;   // (the same values, without the chain of gathers)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int i = fresh(pi[t]);
         real[t] = i < fuse.n;
         sok[t] = false;
         sq[t][0] = sq[t][1] = sq[t][2] = 0.f;
-        {
+        if (from_slots) {
+            const float* ss = fuse.slot_state + 3 * (size_t)n_pad + (ibase + t * 64);
+            sq[t][0] = ss[0]; sq[t][1] = ss[(size_t)n_pad]; sq[t][2] = ss[2 * (size_t)n_pad];
+            sok[t] = real[t];
+        } else {
             // no previous match (cold start): the model point at the same RELATIVE index -- consecutive scans of one
             // sensor, or a cloud and its moved copy, keep their order, and any valid index is a valid bound
             int j = !real[t] ? -1 : fuse.seed_idx ? fuse.seed_idx[i] : (int)(((long long)i * fuse.m) / fuse.n);
@@ -1112,9 +1121,16 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         }
     }
     f2 px, py, pz;
-    px = f2{P[pi[0]], P[pi[1]]};
-    py = f2{P[(size_t)n_pad + pi[0]], P[(size_t)n_pad + pi[1]]};
-    pz = f2{P[2 * (size_t)n_pad + pi[0]], P[2 * (size_t)n_pad + pi[1]]};
+    if (from_slots) {
+        const float* ss = fuse.slot_state + ibase;
+        px = f2{ss[0], ss[64]};
+        py = f2{ss[(size_t)n_pad], ss[(size_t)n_pad + 64]};
+        pz = f2{ss[2 * (size_t)n_pad], ss[2 * (size_t)n_pad + 64]};
+    } else {
+        px = f2{P[pi[0]], P[pi[1]]};
+        py = f2{P[(size_t)n_pad + pi[0]], P[(size_t)n_pad + pi[1]]};
+        pz = f2{P[2 * (size_t)n_pad + pi[0]], P[2 * (size_t)n_pad + pi[1]]};
+    }
     // ---- the pass loop: one turn for an ordinary launch, one per ICP pass for a resident one -------------------
     // Armed launch: the kernel was enqueued while the previous pass was still running, so the launch and dispatch
     // latencies are behind it; what it lacks is the (R, t) the host is solving for.  Resident launch: the same,
@@ -1210,7 +1226,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         // every wave re-derives the moved points in registers (same instructions => same bits); wave 0 of the
         // grid.y == 0 block stores them and accounts the error of the pass that produced (R, t)
         double err = 0.0;
-        const bool shared_gather = pass > 0 || (fuse.seed_idx != nullptr && fuse.idx_prev == fuse.seed_idx);
+        const bool shared_gather = pass > 0 || from_slots || (fuse.seed_idx != nullptr && fuse.idx_prev == fuse.seed_idx);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
@@ -1221,6 +1237,10 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 fuse.P_out[i] = x;
                 fuse.P_out[(size_t)n_pad + i] = y;
                 fuse.P_out[2 * (size_t)n_pad + i] = z;
+                if (fuse.slot_state != nullptr) {   // (and in slot order, for the next pass's front end)
+                    float* ss = fuse.slot_state + (fresh((int)blockIdx.x * 128) + lane + t * 64);   // (recomputed: no register held for it)
+                    ss[0] = x; ss[(size_t)n_pad] = y; ss[2 * (size_t)n_pad] = z;
+                }
                 if (i < fuse.n) {
                     float qx = sq[t][0], qy = sq[t][1], qz = sq[t][2];
                     if (!(shared_gather && sok[t])) {
@@ -1630,6 +1650,13 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         if (gridDim.y == 1) { ICP_PHASE(6) }
         tail_close_row<TAIL, DIAG>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gridDim.y > 1, pass);
         ICP_PHASE(9)
+        if (fuse.slot_state != nullptr && gridDim.y == 1) {   // the matched model points, in slot order, for the next pass
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float* ss = fuse.slot_state + 3 * (size_t)n_pad + (fresh((int)blockIdx.x * 128) + lane + t * 64);
+                ss[0] = sq[t][0]; ss[(size_t)n_pad] = sq[t][1]; ss[2 * (size_t)n_pad] = sq[t][2];
+            }
+        }
         if (!fuse.resident) return;
         // the matches of this pass seed the next one and are what its error is measured against
 #pragma unroll
@@ -2712,6 +2739,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             fuse.relay = ft->relay;
             fuse.want = ft->want;
             fuse.want_lo = (unsigned int)(unsigned long long)ft->want;
+            fuse.slot_state = (pl.sparse && pl.splits == 1 && !ft->resident) ? (float*)ft->slot_state : nullptr;
+            fuse.slot_valid = (fuse.slot_state && ft->slot_valid) ? 1 : 0;
             fuse.resident = ft->resident ? 1 : 0;
             fuse.store_first = ft->store_first ? 1 : 0;
         } else {
