@@ -765,3 +765,33 @@ def test_configs4_full_size_properties(ctx, pkg):
         assert int(((d[:, 0] + d[:, 1]) + d[:, 2]).argmin()) == int(cold[i])
     ctx.nn_match_bench(2, seeded=True)
     assert np.array_equal(ctx.get_indices(), cold)
+
+
+def test_armed_loop_in_single_steps_equals_one_run(pkg, orc, golden, monkeypatch):
+    """one launch per pass (ICP_RESIDENT=0: armed launches that start from the previous pass's slot-ordered points and matches):
+    driving the loop one step per call -- the pass armed ahead is withdrawn and armed again every time -- gives the bits of one
+    uninterrupted run, and both equal the oracle's run"""
+    P, Q = orc.hall_clouds(golden)
+    def whole(c):
+        c.set_model(Q); c.set_moving(P)
+        c.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=100, tol=1e-6)
+        done = False
+        while not done:
+            _, done = c.loop_run(1 << 20)
+        return c.loop_state(), c.loop_indices()
+    def stepped(c):
+        c.set_model(Q); c.set_moving(P)
+        c.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=100, tol=1e-6)
+        done, calls = False, 0
+        while not done:
+            _, done = c.loop_run(1 if calls % 3 else 2)
+            calls += 1
+        return c.loop_state(), c.loop_indices()
+    a, ia = _run_form(pkg, monkeypatch, {"ICP_RESIDENT": "0"}, whole)
+    b, ib = _run_form(pkg, monkeypatch, {"ICP_RESIDENT": "0"}, stepped)
+    assert a["iterations"] == b["iterations"] and np.array_equal(a["T"], b["T"]) and np.array_equal(a["err"], b["err"])
+    assert np.array_equal(ia, ib)
+    want = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
+    assert_same_run(a["iterations"], a["err"], a["T"], want, 1e-6, fp32=True)
+    if a["iterations"] == want["iterations"]:
+        assert np.array_equal(ia, want["idx"])
