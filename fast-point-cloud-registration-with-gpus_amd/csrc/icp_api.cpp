@@ -180,6 +180,8 @@ struct icp_ctx {
     // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
     DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
     struct PrepSmall { float box[4]; double totals[4]; int voided; int pad_; };
+    DevBuf work;             // icp_set_work_counting: NN_WORK_SLOTS counters of the work the sparse kernel executes
+    bool count_work = false;
     DevBuf phase_log;        // ICP_NN_PHASES diagnostic
     std::string phase_path;
     DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
@@ -562,7 +564,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->slot_state, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->work, &c->slot_state, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -678,6 +680,34 @@ int icp_set_profiling(icp_ctx* c, int enable)
     c->prof_seconds_nn = 0.0;
     c->prof_nn_launches = 0;
     c->prof_nn_passes = 0;
+    // the stride counts from here: the first launch after this call is a timed one
+    c->nn_launch_count = 0;
+    c->resident_launch_count = 0;
+    return ICP_OK;
+}
+
+int icp_set_work_counting(icp_ctx* c, int enable)
+{
+    if (int rc = use(c)) return rc;
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (enable) {
+        HIP_TRY(c->work.ensure(icp::NN_WORK_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->work.p, 0, icp::NN_WORK_SLOTS * sizeof(unsigned long long)));
+    }
+    c->count_work = enable != 0;
+    return ICP_OK;
+}
+
+int icp_get_work_counters(icp_ctx* c, uint64_t* out, int reset)
+{
+    if (int rc = use(c)) return rc;
+    if (!out) return fail(ICP_ERR_INVALID, "out == NULL");
+    if (!c->work.p) return fail(ICP_ERR_STATE, "work counting was never enabled");
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->work.p, icp::NN_WORK_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->work.p, 0, icp::NN_WORK_SLOTS * sizeof(unsigned long long)));
     return ICP_OK;
 }
 
@@ -789,6 +819,7 @@ static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
     icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
+    if (c->count_work) o.work = (unsigned long long*)c->work.p;
     return o;
 }
 
@@ -877,6 +908,53 @@ int icp_nn_match_bench_ex(icp_ctx* c, int reps, int seeded, float* total_ms)
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventElapsedTime(total_ms, c->ev0, c->ev1));
+    return ICP_OK;
+}
+
+// the reference's methodology (src/CUDA/Matching_opt.cu:213-226): events around EVERY launch, warm-ups first, the caller
+// takes the minimum (and the mean) of the `reps` durations
+int icp_nn_match_bench_launches(icp_ctx* c, int reps, int warmups, int mode, float* each_ms)
+{
+    if (int rc = use(c)) return rc;
+    if (int rc = require_clouds(c)) return rc;
+    if (reps <= 0 || warmups < 0 || !each_ms || mode < 0 || mode > 2) return fail(ICP_ERR_INVALID, "reps/warmups/mode/each_ms");
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    if (int rc = ensure_work_buffers(c)) return rc;
+    if (int rc = materialize_moving(c)) return rc;
+    icp::NNPlan pl = c->plan;
+    const bool dense = mode == 2;
+    if (dense) {
+        if (c->prec != ICP_F32) return fail(ICP_ERR_INVALID, "the dense packed kernel is fp32");
+        pl = icp::nn_plan(c->n, c->m, c->prec, c->num_cus, 1);
+        const size_t S = pl.splits > 0 ? (size_t)pl.splits : 1;
+        HIP_TRY(c->part_d.ensure(S * (size_t)pl.n_pad * sizeof(float)));
+        HIP_TRY(c->part_idx.ensure(S * (size_t)pl.n_pad * sizeof(int32_t)));
+    }
+    const icp::NNCullInputs cull = make_cull(c, (mode == 0 && c->idx_valid) ? (const int32_t*)c->idx[c->cur].p : nullptr);
+    for (int r = -warmups; r < reps; ++r) {
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, dense ? nullptr : &cull, nullptr, c->stream));
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        if (r >= 0) each_ms[r] = ms;
+    }
+    if (dense) {   // the partial buffers may have grown: nothing else depends on the dense plan
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ICP_OK;
+}
+
+int icp_nn_launch_info_ex(icp_ctx* c, int dense, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    const icp::NNPlan pl = icp::nn_plan(c->n, c->m, c->prec, c->num_cus, dense ? 1 : 0);
+    if (splits) *splits = pl.splits;
+    if (blocks) *blocks = pl.blocks_x * pl.splits;
+    if (threads) *threads = icp::nn_block_threads(pl);
+    if (n_pad) *n_pad = pl.n_pad;
+    if (m_pad) *m_pad = pl.m_pad;
     return ICP_OK;
 }
 

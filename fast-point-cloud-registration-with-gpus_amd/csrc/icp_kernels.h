@@ -38,7 +38,8 @@ inline int pad_moving(int n) { return n <= 0 ? 0 : round_up(n, NN_POINT_ALIGN); 
 inline int pad_model(int m) { return m <= 0 ? 0 : round_up(m, NN_CHUNK); }
 
 // Choose the launch geometry.  `num_cus` comes from hipDeviceProp_t::multiProcessorCount.
-NNPlan nn_plan(int n, int m, int precision, int num_cus);
+// force_dense != 0: the geometry of the dense packed kernel (every pair executed) even where the sparse kernel would run
+NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense = 0);
 
 size_t elem_size(int precision);
 
@@ -99,6 +100,22 @@ struct NNCullInputs {
     const void* Q_scan_sorted = nullptr;
     const int32_t* q_perm = nullptr;
     const int32_t* p_perm = nullptr;
+    // diagnostic (sparse kernel): NN_WORK_SLOTS device counters of the work the kernel executes -- the launch then uses
+    // the instrumented instantiation.  NULL (the default): the production kernel, nothing is counted.
+    unsigned long long* work = nullptr;
+};
+// What the sparse kernel EXECUTED (it returns the brute-force answer without evaluating most pairs): wave-level tallies.
+// One "hit" = one 8-point model chunk processed by one wave = 64 lanes x 2 moving points against that chunk.
+enum {
+    NN_WORK_FIND_BOXES = 0,       // chunk boxes tested against a block's group box (one lane each, ~12 flop)
+    NN_WORK_UPPER_BOXES = 1,      // boxes of the upper hierarchy levels tested the same way
+    NN_WORK_HITS_BOX = 2,         // hits that went through the per-point box test (128 points x 12 flop)
+    NN_WORK_HITS_XY = 3,          // ... that went on to the xy half of the distances (128 x 8 x 5 flop)
+    NN_WORK_HITS_FULL = 4,        // ... whose 128 x 8 distances were evaluated in full (128 x 8 x 3 flop more)
+    NN_WORK_SAMPLE_GROUPS = 5,    // cold start: groups of 8 samples scanned by a wave (128 x 8 x 8 flop)
+    NN_WORK_BLOCK_PASSES = 6,     // (block, pass) pairs, for normalisation
+    NN_WORK_BLOCK_TRANSFORMS = 7, // ... of which applied a transform first (16 waves x 128 points x 15 flop, redundantly)
+    NN_WORK_SLOTS = 8
 };
 // device-side preparation of the sparse kernel's views (icp_set_model / icp_set_moving): scratch owned by the caller
 struct PrepBuffers {

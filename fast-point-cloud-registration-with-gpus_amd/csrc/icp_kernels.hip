@@ -470,6 +470,7 @@ struct NNFuse {
     long long* tlog;         // diagnostic (ICP_NN_PHASES): per-wave s_memrealtime stamps, 10 slots per wave, or NULL
     long long tlog_cap;      // slots available
     int tlog_pass;           // resident launch: stamp this pass only (-1: every pass, the last one survives)
+    unsigned long long* work; // diagnostic (icp_set_work_counting): NN_WORK_SLOTS device counters of the work the sparse kernel EXECUTES, or NULL
 };
 
 // phase stamp of the diagnostic log: one scalar branch when the log is off
@@ -808,15 +809,17 @@ constexpr int SP_MAX_PASSES = SP_HCAP / (SP_NW * 64);
 // PERM: the scan copy is a sorted view, element k of the chunk is model point qo[k] (looked at only on the rare path
 // where the chunk's minimum reaches the running one); else it is point ch * 8 + k and "lowest model index" is
 // simply "lowest k".
+// Returns how far the hit got (wave-uniform; only the work-counting instantiation looks at it): 0 = rejected by the
+// per-point box test, 1 = by the xy early-out, 2 = the eight distances were evaluated in full.
 template <bool PERM>
-__device__ __forceinline__ void scan_hit(const float* sb, int ch, const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
-                                         float (&bq)[2][3])
+__device__ __forceinline__ int scan_hit(const float* sb, int ch, const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
+                                        float (&bq)[2][3])
 {
     constexpr int C = 8;
     {
         // level 0: the chunk's bounding box against each of the lane's points (ties pass: the hits are unordered)
         const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
-        if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull) return;
+        if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull) return 0;
     }
     const float *qxp = sb + 8, *qyp = sb + 16, *qzp = sb + 24;
     f2 d[C];  // first dx*dx + dy*dy (the inner sum of the reference's association), then the distances
@@ -842,7 +845,7 @@ __device__ __forceinline__ void scan_hit(const float* sb, int ch, const f2 px, c
         mxy1 = fmin_(fmin_(mxy1, d[kk + 2].y), d[kk + 3].y);
     }
     // d = fl(pxy + dz*dz) >= pxy: a chunk whose smallest pxy is above every lane's minimum cannot matter (ties pass)
-    if (__builtin_amdgcn_ballot_w64((mxy0 <= best[0]) | (mxy1 <= best[1])) == 0ull) return;
+    if (__builtin_amdgcn_ballot_w64((mxy0 <= best[0]) | (mxy1 <= best[1])) == 0ull) return 1;
     float c0 = inf_<float>(), c1 = inf_<float>();  // the chunk's own minima
 #pragma unroll
     for (int kk = 0; kk < C; kk += 4) {
@@ -901,6 +904,7 @@ __device__ __forceinline__ void scan_hit(const float* sb, int ch, const f2 px, c
             if (take1) { bq[1][0] = qxp[k1]; bq[1][1] = qyp[k1]; bq[1][2] = qzp[k1]; }
         }
     }
+    return 2;
 }
 
 // distances from the lane's packed pair to 8 model points, folded into running minima (no index)
@@ -1161,6 +1165,8 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     }
     for (int pass = 0;; ++pass) {
     phase_pass_ = pass;
+    // (work-counting instantiation only) what this wave executes in this pass -- wave-uniform tallies, flushed once per pass
+    unsigned int wk_find = 0, wk_upper = 0, wk_hit[3] = {0, 0, 0}, wk_samp = 0;
     double err_row = 0.0;
     RT<float> rt = rt_arg;
     int cmd = fuse.apply ? ICP_CMD_TRANSFORM_MATCH : ICP_CMD_MATCH;
@@ -1340,6 +1346,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 const float4* b = reinterpret_cast<const float4*>(sl + SMAX + gp * 8);
                 const float4* c = reinterpret_cast<const float4*>(sl + 2 * SMAX + gp * 8);
                 scan8_min(a[0], a[1], b[0], b[1], c[0], c[1], px, py, pz, sb);
+                if constexpr (DIAG) ++wk_samp;
             }
             if (real[0]) atomicMin(&smin[lane], __float_as_uint(sb[0]));
             if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(sb[1]));
@@ -1374,6 +1381,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - ghi[2], glo[2] - b1.y), 0.f);
         const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;
         const bool pass = cidx < c_hi && L < B;  // every candidate winner lies strictly below its point's starting bound
+        if constexpr (DIAG) wk_find += (unsigned int)max(0, min(64, c_hi - c0));
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
         if (mask != 0ull) {
             int base = 0;
@@ -1411,11 +1419,17 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
             const int cnt = mine < 8 ? mine : 8;
             for (int rr = 0; rr < cnt; ++rr) {
+                int stage_reached;
                 if constexpr (PERM) {
-                    scan_hit<true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
+                    stage_reached = scan_hit<true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
                 } else {
                     const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * SP_NW + w]);
-                    scan_hit<false>(stage + rr * STG, ch, px, py, pz, best, bj, bq);
+                    stage_reached = scan_hit<false>(stage + rr * STG, ch, px, py, pz, best, bj, bq);
+                }
+                if constexpr (DIAG) {
+                    ++wk_hit[0];
+                    wk_hit[1] += stage_reached >= 1 ? 1u : 0u;
+                    wk_hit[2] += stage_reached >= 2 ? 1u : 0u;
                 }
             }
             lds_same_wave_order();
@@ -1488,6 +1502,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                     b0 = bp[0]; b1 = bp[1];
                 }
                 append(tidx < t_hi && near_box(b0, b1, Bt), tidx, thits, tcount);
+                if constexpr (DIAG) wk_upper += (unsigned int)max(0, min(64, t_hi - (tb + w * 64)));
             }
             __syncthreads();   // the level-3 list is complete
             const int TH = *tcount;
@@ -1500,6 +1515,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                     const bool in = sidx >= s_lo && sidx < s_hi;
                     const float4* bp = reinterpret_cast<const float4*>(sboxes + (size_t)(in ? sidx : s_lo) * 8);
                     append(in && near_box(bp[0], bp[1], Bs), sidx, shits, scount);
+                    if constexpr (DIAG) wk_upper += 64u;
                 }
                 __syncthreads();   // the super list is complete (and, after a processed round, the chunk list's reset is seen)
                 const int SH = *scount;
@@ -1576,6 +1592,19 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     }
     }
     ICP_PHASE(3)
+    if constexpr (DIAG) {
+        if (fuse.work != nullptr && lane == 0) {
+            // slots: NN_WORK_* (icp_kernels.h)
+            if (wk_find) atomicAdd(&fuse.work[NN_WORK_FIND_BOXES], (unsigned long long)wk_find);
+            if (wk_upper) atomicAdd(&fuse.work[NN_WORK_UPPER_BOXES], (unsigned long long)wk_upper);
+            if (wk_hit[0]) atomicAdd(&fuse.work[NN_WORK_HITS_BOX], (unsigned long long)wk_hit[0]);
+            if (wk_hit[1]) atomicAdd(&fuse.work[NN_WORK_HITS_XY], (unsigned long long)wk_hit[1]);
+            if (wk_hit[2]) atomicAdd(&fuse.work[NN_WORK_HITS_FULL], (unsigned long long)wk_hit[2]);
+            if (wk_samp) atomicAdd(&fuse.work[NN_WORK_SAMPLE_GROUPS], (unsigned long long)wk_samp);
+            if (w == 0) atomicAdd(&fuse.work[NN_WORK_BLOCK_PASSES], 1ull);
+            if (w == 0 && apply) atomicAdd(&fuse.work[NN_WORK_BLOCK_TRANSFORMS], 1ull);
+        }
+    }
 
     // in-block merge: every wave that lowered its bound folds its candidate into the point's key
 #pragma unroll
@@ -2594,7 +2623,7 @@ static int env_int(const char* name, int dflt)
     return atoi(v);
 }
 
-NNPlan nn_plan(int n, int m, int precision, int num_cus)
+NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense)
 {
     NNPlan pl{};
     pl.precision = precision;
@@ -2615,7 +2644,7 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus)
         // 8 resident waves per SIMD = 8 blocks per CU saturate the VALU (valu_rate probe).
         static const int env_sparse = env_int("ICP_NN_SPARSE", 1);
         static const int env_boxes = env_int("ICP_NN_BOXES", 1);
-        if (env_sparse && env_boxes) {
+        if (env_sparse && env_boxes && !force_dense) {
             // sparse kernel: a block of 16 waves owns 128 moving points; split the model only while there are
             // fewer blocks than CUs, and never below 1024 model points per block
             pl.sparse = 1;
@@ -2725,6 +2754,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     fuse.tlog_cap = g_phase_log_cap;
     static const int env_tpass = env_int("ICP_NN_PHASE_PASS", -1);
     fuse.tlog_pass = env_tpass;
+    fuse.work = opt ? opt->work : nullptr;
     const void* Qscan = Q;
     if (pl.cull && opt && opt->Q_scan) {
         Qscan = opt->Q_scan;
@@ -2795,7 +2825,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             int n_pad = pl.n_pad, m_pad = pl.m_pad, seg = pl.seg_len;
             float* pd = (float*)part_d;
             void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
-            const bool diag = fuse.tlog != nullptr, perm = fuse.q_perm != nullptr, hier = pl.hier != 0;
+            const bool diag = fuse.tlog != nullptr || fuse.work != nullptr, perm = fuse.q_perm != nullptr, hier = pl.hier != 0;
 #define ICP_SP_FN(TL, DG, PM) {(const void*)nn_match_sparse<TL, DG, PM, false>, (const void*)nn_match_sparse<TL, DG, PM, true>}
             const void* fns[2][2][2][2] = {{{ICP_SP_FN(1, false, false), ICP_SP_FN(1, false, true)}, {ICP_SP_FN(1, true, false), ICP_SP_FN(1, true, true)}},
                                            {{ICP_SP_FN(2, false, false), ICP_SP_FN(2, false, true)}, {ICP_SP_FN(2, true, false), ICP_SP_FN(2, true, true)}}};
@@ -2828,7 +2858,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     do { if (pl.hier) ICP_LAUNCH_SP4(TL, DG, PM, true); else ICP_LAUNCH_SP4(TL, DG, PM, false); } while (0)
 #define ICP_LAUNCH_SP(TL)                                                                                          \
     do {                                                                                                           \
-        const bool dg_ = fuse.tlog != nullptr, pm_ = fuse.q_perm != nullptr;                                       \
+        const bool dg_ = fuse.tlog != nullptr || fuse.work != nullptr, pm_ = fuse.q_perm != nullptr;                                       \
         if (dg_) { if (pm_) ICP_LAUNCH_SP3(TL, true, true); else ICP_LAUNCH_SP3(TL, true, false); }                 \
         else { if (pm_) ICP_LAUNCH_SP3(TL, false, true); else ICP_LAUNCH_SP3(TL, false, false); }                   \
     } while (0)

@@ -159,6 +159,30 @@ class Context:
         capi.check(self._lib.icp_nn_match_bench_ex(self._h, int(reps), 1 if seeded else 0, C.byref(ms)), "icp_nn_match_bench_ex")
         return ms.value
 
+    def nn_match_bench_launches(self, reps=10, warmups=2, mode=0):
+        """per-launch hipEvent durations [ms] of the matching kernel (reference method: Matching_opt.cu:213-226);
+        mode 0 seeded, 1 cold, 2 the dense packed kernel that executes every pair"""
+        out = np.zeros(int(reps), dtype=np.float32)
+        capi.check(self._lib.icp_nn_match_bench_launches(self._h, int(reps), int(warmups), int(mode),
+                                                         out.ctypes.data_as(C.POINTER(C.c_float))), "icp_nn_match_bench_launches")
+        return out
+
+    def nn_launch_info_ex(self, dense=False):
+        v = [C.c_int(0) for _ in range(5)]
+        capi.check(self._lib.icp_nn_launch_info_ex(self._h, 1 if dense else 0, *[C.byref(x) for x in v]), "icp_nn_launch_info_ex")
+        return dict(zip(("splits", "blocks", "threads", "n_pad", "m_pad"), (x.value for x in v)))
+
+    WORK_SLOTS = ("find_boxes", "upper_boxes", "hits_box", "hits_xy", "hits_full", "sample_groups", "block_passes", "block_transforms")
+
+    def set_work_counting(self, enable=True):
+        capi.check(self._lib.icp_set_work_counting(self._h, 1 if enable else 0), "icp_set_work_counting")
+
+    def get_work_counters(self, reset=True):
+        out = np.zeros(8, dtype=np.uint64)
+        capi.check(self._lib.icp_get_work_counters(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if reset else 0),
+                   "icp_get_work_counters")
+        return dict(zip(self.WORK_SLOTS, (int(x) for x in out)))
+
     def nn_launch_info(self):
         v = [C.c_int(0) for _ in range(5)]
         capi.check(self._lib.icp_nn_launch_info(self._h, *[C.byref(x) for x in v]), "icp_nn_launch_info")

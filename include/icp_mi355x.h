@@ -126,8 +126,28 @@ int icp_nn_match_bench(icp_ctx* ctx, int reps, float* total_ms);
 /* same; seeded != 0 hands the kernel the most recent correspondences as its starting bound (what the ICP
  * loop does from its second pass on), seeded == 0 starts it cold (what icp_nn_match_* does) */
 int icp_nn_match_bench_ex(icp_ctx* ctx, int reps, int seeded, float* total_ms);
+/* The reference's own kernel-timing method (src/CUDA/Matching_opt.cu:213-226: cudaEventRecord around every launch,
+ * minimum of 10 after warm-up): `warmups` untimed launches, then `reps` launches with a hipEvent pair around each one;
+ * each_ms[r] receives the duration of launch r.  mode 0: the matching kernel as the loop launches it (seeded with the
+ * most recent correspondences), 1: cold (no seed), 2: the dense packed kernel, which EXECUTES every one of the
+ * n_pad x m_pad pairs (fp32 only; no boxes, no early-out) -- the brute-force scan the roofline arithmetic is about. */
+int icp_nn_match_bench_launches(icp_ctx* ctx, int reps, int warmups, int mode, float* each_ms);
 /* geometry of the last matching launch, for the roofline arithmetic in bench.py */
 int icp_nn_launch_info(icp_ctx* ctx, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad);
+/* ... of the launch the resident clouds get from the production plan (dense == 0) or from the dense packed kernel */
+int icp_nn_launch_info_ex(icp_ctx* ctx, int dense, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad);
+/* Executed-work accounting of the sparse matching kernel (it returns the brute-force answer of Matching<<<>>> without
+ * evaluating most pairs, so the roofline of EXECUTED arithmetic needs a count).  enable != 0: every following sparse
+ * launch of this context runs its instrumented instantiation and adds wave-level tallies to 8 device counters;
+ * icp_get_work_counters reads them (uint64 x ICP_WORK_SLOTS) and optionally zeroes them.  Slots:
+ *   0 chunk boxes tested against a block's group box (one lane each)      1 upper-level boxes (large models)
+ *   2 hits = (wave, 8-point chunk) pairs through the per-point box test   3 ... through the xy half of the distances
+ *   4 ... evaluated in full (each hit: 64 lanes x 2 moving points x 8 model points)
+ *   5 cold-start sample groups scanned (128 x 8 pairs each)   6 (block, pass) pairs   7 ... that applied a transform
+ * Timing with counting on is not representative (atomics, extra registers): count in a separate run. */
+#define ICP_WORK_SLOTS 8
+int icp_set_work_counting(icp_ctx* ctx, int enable);
+int icp_get_work_counters(icp_ctx* ctx, uint64_t* out_slots, int reset);
 
 /* ---- model normals: replaces knn + Normals + host ssyev loop
  *      src/CUDA/GPU_point_to_plane_real.cu:54-188,391-423 (k = 4 neighbours, self excluded).
