@@ -113,6 +113,17 @@ static inline void post_message(icp::NNMailbox* mb, const double* R9, const doub
 }
 
 static constexpr int kMailSlots = 4;  // armed launches: ring of mailboxes (one is live at a time)
+// Time budgets of a kernel that waits for the host, ordered so that a late host and a waiting kernel can never disagree:
+//   * a waiting block gives up (and reads that as EXIT) only after ICP_MAILBOX_BUDGET_S of WALL-CLOCK time (icp_kernels.h);
+//   * the host posts a message only while at most kMailLeaseS have passed since it last knew the kernel to be waiting (the
+//     rows of the previous pass complete / the launch); when it is later than that -- descheduled, or held up in the
+//     inter-rank exchange, whose own limit is longer -- it sends EXIT instead (an EXIT is consistent at any time: a block
+//     that has already given up did exactly that) and relaunches.  kMailLeaseS < budget / 2;
+//   * the host's wait for a pass's rows (kRowPollS) is shorter than the budget too: when it gives up it withdraws the
+//     kernel and lets the runtime report what happened.
+static constexpr double kMailLeaseS = 1.5;
+static constexpr double kRowPollS = 2.0;
+static_assert(kMailLeaseS * 2.0 < (double)ICP_MAILBOX_BUDGET_S && kRowPollS < (double)ICP_MAILBOX_BUDGET_S, "host budgets must stay inside the kernel's");
 static constexpr size_t kPhaseSlots = 512 * 1024;  // ICP_NN_PHASES: 10 stamps per wave
 
 struct DevBuf {
@@ -154,6 +165,18 @@ struct LoopState {
     double armed_tag = 0.0;
     int armed_slot = 0;
     int armed_prev_cur = 0;
+    std::chrono::steady_clock::time_point armed_at{};   // when the armed pass was launched (mailbox lease)
+    icp::NNMailbox* live_mailbox = nullptr;             // a resident kernel is running and listens here
+};
+
+// the calling thread's affinity, narrowed to the device's NUMA node for the duration of one entry point (see icp_create)
+struct ScopedPin {
+    bool restore = false;
+    cpu_set_t saved;
+    explicit ScopedPin(const icp_ctx* c);
+    ~ScopedPin() { if (restore) (void)sched_setaffinity(0, sizeof saved, &saved); }
+    ScopedPin(const ScopedPin&) = delete;
+    ScopedPin& operator=(const ScopedPin&) = delete;
 };
 
 }  // namespace
@@ -220,6 +243,14 @@ struct icp_ctx {
     uint64_t tr_n = 0;
     void* comm = nullptr;              // RCCL communicator (icp_comm_init): the loop all-reduces its vector itself
     icp::LocalComm* lcomm = nullptr;   // host-memory communicator (icp_comm_init_local): the vector is summed over the node's ranks on the host
+    // test hook (ICP_DEBUG_STALL="pass:seconds", read by icp_create): the host sleeps once, right before it would publish
+    // the message of that pass of a registration -- a descheduled host thread, as the mailbox lease has to survive it
+    int debug_stall_pass = -1;
+    double debug_stall_s = 0.0;
+    int pin_mode = 1;                  // ICP_PIN: 0 never, 1 scoped (default), 2 narrowed once and kept
+    bool have_local_cpus = false;
+    cpu_set_t local_cpus;              // CPUs of the device's NUMA node (sysfs local_cpulist)
+    std::chrono::steady_clock::time_point rows_done_at{};   // when the host last saw a pass's rows complete (mailbox lease)
     bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
     bool arm = true;                   // ICP_ARMED=0: icp_loop_run never enqueues a pass ahead of its (R, t)
     bool resident = true;              // ICP_RESIDENT=0: icp_loop_run never keeps one kernel for a whole registration
@@ -241,6 +272,18 @@ struct icp_ctx {
 };
 
 namespace {
+
+ScopedPin::ScopedPin(const icp_ctx* c)
+{
+    if (!c || c->pin_mode != 1 || !c->have_local_cpus) return;
+    const int cpu = sched_getcpu();
+    if (cpu >= 0 && cpu < CPU_SETSIZE && CPU_ISSET(cpu, &c->local_cpus)) return;   // already next to the device: nothing to do
+    cpu_set_t both;
+    if (sched_getaffinity(0, sizeof saved, &saved) != 0) return;
+    CPU_AND(&both, &saved, &c->local_cpus);
+    if (CPU_COUNT(&both) == 0) return;                                              // the caller may not run there at all
+    if (sched_setaffinity(0, sizeof both, &both) == 0) restore = true;
+}
 
 int use(icp_ctx* c)
 {
@@ -438,25 +481,26 @@ static void mailbox_selftest(icp_ctx* c, int slot, const char* when)
 // The loop is a conversation between one host thread and the GPU (mailbox through the PCIe BAR, moment rows through pinned
 // host memory): on a two-socket machine every message of a thread running on the other socket crosses the socket link
 // too -- measured on the hall loop 13.05 us per iteration from the GPU's own NUMA node, 14.4-14.6 us from the other one,
-// and a coin toss when the scheduler chooses (tools/numa_probe.py).  So the thread that creates a context is
-// restricted to the CPUs sysfs lists as local to the device (a whole socket; ICP_PIN=0 leaves the affinity alone; nothing
-// happens when sysfs has no answer, when the thread's mask has no local CPU, or when it is already inside).
-static void pin_thread_to_device_node(int device)
+// and a coin toss when the scheduler chooses (tools/numa_probe.py).  The library therefore wants the calling thread on a
+// CPU that sysfs lists as local to the device -- but a drop-in library must not leave its caller's affinity changed.
+// So the narrowing is SCOPED: an entry point that talks to the GPU in a loop (icp_create while it allocates and first
+// touches the pinned buffers, icp_loop_run, icp_loop_complete, icp_point_to_*) narrows the mask only if the thread is
+// currently running on a remote CPU, and puts the caller's mask back before it returns.
+//   ICP_PIN=0  never touch the affinity;  ICP_PIN=1 (default) scoped as above;
+//   ICP_PIN=2  narrow once in icp_create and leave it narrowed (the behaviour of round 1; a dedicated worker thread).
+static bool parse_local_cpus(int device, cpu_set_t* local)
 {
-    const char* v = std::getenv("ICP_PIN");
-    if (v && v[0] == '0') return;
     char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return false; }
     for (char* p = bus; *p; ++p) *p = (char)std::tolower((unsigned char)*p);
     const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
     std::FILE* f = std::fopen(path.c_str(), "r");
-    if (!f) return;
+    if (!f) return false;
     char line[4096] = {0};
     const bool got = std::fgets(line, sizeof line, f) != nullptr;
     std::fclose(f);
-    if (!got) return;
-    cpu_set_t local, cur, both;
-    CPU_ZERO(&local);
+    if (!got) return false;
+    CPU_ZERO(local);
     for (const char* p = line; *p;) {                      // "0-63,128-191"
         char* end = nullptr;
         const long a = std::strtol(p, &end, 10);
@@ -464,13 +508,10 @@ static void pin_thread_to_device_node(int device)
         long b = a;
         p = end;
         if (*p == '-') { b = std::strtol(p + 1, &end, 10); p = end; }
-        for (long k = a; k <= b && k < CPU_SETSIZE; ++k) if (k >= 0) CPU_SET((int)k, &local);
+        for (long k = a; k <= b && k < CPU_SETSIZE; ++k) if (k >= 0) CPU_SET((int)k, local);
         if (*p == ',') ++p; else break;
     }
-    if (sched_getaffinity(0, sizeof cur, &cur) != 0) return;
-    CPU_AND(&both, &cur, &local);
-    if (CPU_COUNT(&both) == 0 || CPU_COUNT(&both) == CPU_COUNT(&cur)) return;
-    (void)sched_setaffinity(0, sizeof both, &both);
+    return CPU_COUNT(local) > 0;
 }
 
 int icp_create(int device, icp_ctx** out)
@@ -489,7 +530,16 @@ int icp_create(int device, icp_ctx** out)
     if (!c) return fail(ICP_ERR_NOMEM, "context allocation failed");
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    pin_thread_to_device_node(device);   // (before the pinned host buffers are allocated and first touched)
+    if (const char* v = std::getenv("ICP_PIN")) c->pin_mode = (v[0] == '0') ? 0 : (v[0] == '2') ? 2 : 1;
+    c->have_local_cpus = c->pin_mode != 0 && parse_local_cpus(device, &c->local_cpus);
+    if (c->pin_mode == 2 && c->have_local_cpus) {   // narrowed once and kept (a thread dedicated to this context)
+        cpu_set_t cur, both;
+        if (sched_getaffinity(0, sizeof cur, &cur) == 0) {
+            CPU_AND(&both, &cur, &c->local_cpus);
+            if (CPU_COUNT(&both) != 0 && CPU_COUNT(&both) != CPU_COUNT(&cur)) (void)sched_setaffinity(0, sizeof both, &both);
+        }
+    }
+    ScopedPin pin(c);   // (the pinned host buffers below are allocated and first touched next to the device)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -523,6 +573,11 @@ int icp_create(int device, icp_ctx** out)
         return fail(ICP_ERR_HIP, msg);
     }
     c->stream = c->own_stream;
+    if (const char* v = std::getenv("ICP_DEBUG_STALL")) {
+        int pass = -1;
+        double sec = 0.0;
+        if (std::sscanf(v, "%d:%lf", &pass, &sec) == 2 && pass >= 0 && sec > 0.0 && sec < 30.0) { c->debug_stall_pass = pass; c->debug_stall_s = sec; }
+    }
     if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
     if (const char* v = std::getenv("ICP_ARMED")) c->arm = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = !(v[0] == '0');
@@ -1157,6 +1212,7 @@ int icp_loop_set_moments_dev(icp_ctx* c, void* dev_ptr)
 int icp_loop_complete(icp_ctx* c, int* done)
 {
     if (int rc = use(c)) return rc;
+    ScopedPin pin(c);
     LoopState& L = c->loop;
     if (!L.active || !L.pending) return fail(ICP_ERR_STATE, "complete without enqueue");
     const auto tr0 = std::chrono::steady_clock::now();
@@ -1192,10 +1248,11 @@ int icp_loop_complete(icp_ctx* c, int* done)
                     continue;
                 }
                 if ((++spins & 0x3ff) == 0 &&
-                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kRowPollS)
                     break;  // something is wrong (fault, hang): let the runtime report it
             }
             polled = b == L.mom_blocks;
+            c->rows_done_at = std::chrono::steady_clock::now();
             if (c->trace_passes) { c->tr_last_row = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); c->tr_rows_done = std::chrono::steady_clock::now(); }
             if (!polled && c->trace) {
                 std::fprintf(stderr, "[icp trace]   poll gave up at row %d; rows still missing:", b);
@@ -1207,6 +1264,8 @@ int icp_loop_complete(icp_ctx* c, int* done)
         }
         tr1 = std::chrono::steady_clock::now();
         if (!polled) {
+            // a resident kernel would go on waiting for its next message: withdraw it (under the tag it will wait for)
+            if (L.live_mailbox) post_message(L.live_mailbox, nullptr, nullptr, icp::ICP_CMD_EXIT, L.wait_tag + 1.0, c->mail_wide);
             HIP_TRY(hipStreamSynchronize(c->stream));
             tr1 = std::chrono::steady_clock::now();
             for (int b = 0; b < L.mom_blocks; ++b)
@@ -1311,6 +1370,7 @@ int loop_arm(icp_ctx* c)
     std::swap(c->P, c->P2);
     c->cur = prev_cur ^ 1;
     L.armed = true;
+    L.armed_at = std::chrono::steady_clock::now();
     L.armed_tag = tag;
     L.armed_slot = slot;
     L.armed_prev_cur = prev_cur;
@@ -1413,8 +1473,22 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     auto send = [&](int cmd, double seq) { post_message(mb, L.H.R, L.H.t, cmd, seq, c->mail_wide); };   // (R, t: ignored by a plain MATCH)
     int k = *k_io, d = *d_io, sent = 0, matched = 0, rc = ICP_OK;
     bool alive = true;
+    c->rows_done_at = std::chrono::steady_clock::now();   // (the launch: the kernel waits from now on at the earliest)
+    L.live_mailbox = mb;
     while (!d && k < max_steps && sent < pass_cap) {
+        if (c->debug_stall_pass >= 0 && L.H.applied == c->debug_stall_pass) {
+            c->debug_stall_pass = -1;
+            usleep((useconds_t)(c->debug_stall_s * 1e6));
+        }
         const auto tr0 = std::chrono::steady_clock::now();
+        if (std::chrono::duration<double>(tr0 - c->rows_done_at).count() > kMailLeaseS) {
+            // this thread was away for too long (descheduled, or held up in the inter-rank exchange): the kernel may have
+            // given up waiting.  EXIT is consistent whatever each block has decided; icp_loop_run launches a new kernel,
+            // which resumes from the state the last complete pass left (P in place, idx ping-pong).
+            if (c->trace) std::fprintf(stderr, "[icp trace] resident kernel withdrawn: the host was %.2f s late\n",
+                                       std::chrono::duration<double>(tr0 - c->rows_done_at).count());
+            break;
+        }
         const bool apply = L.H.have_rt;
         const bool final_only = L.H.next_is_final();
         const int cmd = !apply ? icp::ICP_CMD_MATCH : (final_only ? icp::ICP_CMD_TRANSFORM_ONLY : icp::ICP_CMD_TRANSFORM_MATCH);
@@ -1456,6 +1530,19 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
         if (cmd == icp::ICP_CMD_TRANSFORM_ONLY) { alive = false; break; }  // the kernel ends itself after that pass
     }
     if (alive) send(icp::ICP_CMD_EXIT, base + (double)sent);
+    L.live_mailbox = nullptr;
+    if (rc != ICP_OK) {
+        // a pass did not complete: blocks may have applied its transform to their part of the cloud and others not.
+        // Nothing of that state is offered to the caller: the loop is over, the moving cloud goes back to what
+        // icp_set_moving uploaded (materialised from the pristine copy on its next use), the matches are void.
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+        c->moving_is_pristine = true;
+        c->idx_valid = false;
+        L.active = false;
+        L.pending = false;
+        g_last_error += " [the loop was abandoned; the moving cloud is reset to its uploaded state]";
+    }
     if (time_this && rc == ICP_OK) {
         float ms = 0.f;
         // the kernel ends within microseconds of the exit message: spin on the event instead of a blocking wait
@@ -1482,7 +1569,9 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
 int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
 {
     if (max_steps < 0) return fail(ICP_ERR_INVALID, "max_steps < 0");
-    int d = c && c->loop.active && c->loop.H.done ? 1 : 0, k = 0;
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    ScopedPin pin(c);
+    int d = c->loop.active && c->loop.H.done ? 1 : 0, k = 0;
     while (!d && k < max_steps) {
         if (can_reside(c)) {
             bool fell_back = false;
@@ -1495,7 +1584,14 @@ int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
             if (int rc = loop_arm(c)) return rc;
         if (int rc = icp_loop_complete(c, &d)) { loop_withdraw_armed(c); return rc; }
         if (c->loop.armed) {
-            if (d) loop_withdraw_armed(c);
+            // (a host that comes back too late may not publish any more: the waiting kernel may have given up -- it is
+            // withdrawn, which is consistent either way, and the pass is launched afresh)
+            if (c->debug_stall_pass >= 0 && c->loop.H.applied == c->debug_stall_pass) {
+                c->debug_stall_pass = -1;
+                usleep((useconds_t)(c->debug_stall_s * 1e6));
+            }
+            const bool late = std::chrono::duration<double>(std::chrono::steady_clock::now() - c->loop.armed_at).count() > kMailLeaseS;
+            if (d || late) loop_withdraw_armed(c);
             else loop_release_armed(c);
         }
         ++k;
@@ -1544,6 +1640,7 @@ int icp_loop_indices(icp_ctx* c, int32_t* out)
 
 static int run_loop(icp_ctx* c, const icp_params* prm, icp_result* out)
 {
+    ScopedPin pin(c);
     if (int rc = icp_loop_begin(c, prm)) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     int done = 0;

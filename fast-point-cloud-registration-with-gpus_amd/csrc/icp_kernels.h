@@ -67,6 +67,12 @@ enum { ICP_MB_TAG0 = 7, ICP_MB_CMD = 13, ICP_MB_TAG1 = 14 };
 ICP_HOST_DEVICE inline uint32_t mailbox_tag(double seq) { return (uint32_t)(unsigned long long)seq | 0x80000000u; }
 ICP_HOST_DEVICE inline int mailbox_rt_word(int k) { return k < 7 ? k : k + 1; }   // the word rt[k] travels in
 enum { ICP_CMD_EXIT = 0, ICP_CMD_MATCH = 1, ICP_CMD_TRANSFORM_MATCH = 2, ICP_CMD_TRANSFORM_ONLY = 3 };
+// How long a block waits for a message before it gives up (which reads as EXIT), in WALL-CLOCK seconds of the device's
+// constant 100 MHz counter -- the same budget whatever memory the poll goes to.  Blocks that listen to block 0's relay
+// wait twice as long: block 0 decides, and publishes its verdict (message or EXIT) through the relay.  The host side of
+// the contract (icp_api.cpp, kMailLeaseS) never posts a message a block might no longer be waiting for.
+#define ICP_MAILBOX_BUDGET_S 4
+constexpr long long ICP_MAILBOX_BUDGET_TICKS = (long long)ICP_MAILBOX_BUDGET_S * 100000000ll;
 hipError_t launch_mailbox_selftest(const NNMailbox* mb, double* ack, hipStream_t st);
 struct NNFusedTransform {
     const double* R9;  // NULL with a mailbox

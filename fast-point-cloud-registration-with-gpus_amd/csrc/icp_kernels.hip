@@ -20,6 +20,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #pragma clang fp contract(off)
@@ -1194,12 +1197,17 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             const uint32_t want32 = (fuse.want_lo + (uint32_t)pass) | 0x80000000u;
             uint32_t word = 0u;
             bool ok = false;
-            for (int spins = 0; spins < (1 << 22); ++spins) {
+            // the wait is bounded in wall-clock time (the device's constant 100 MHz counter, read every 64th poll): the
+            // same budget whether the poll goes to host memory, to BAR-visible device memory or to the relay.  A block that
+            // listens to the relay waits twice as long -- block 0 decides and publishes its verdict there.
+            const long long give_up = (long long)wall_clock64() + (first ? ICP_MAILBOX_BUDGET_TICKS : 2 * ICP_MAILBOX_BUDGET_TICKS);
+            for (unsigned int spins = 1;; ++spins) {
                 word = first ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                              : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = (uint32_t)__builtin_amdgcn_readlane((int)word, ICP_MB_TAG0) == want32 &&
                      (uint32_t)__builtin_amdgcn_readlane((int)word, ICP_MB_TAG1) == want32;
                 if (ok) break;
+                if ((spins & 63u) == 0u && (long long)wall_clock64() > give_up) break;
                 __builtin_amdgcn_s_sleep(2);
             }
             // (a time-out reads as a withdrawal: the other blocks must end too)
@@ -2839,14 +2847,24 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
             static const int env_coop = env_int("ICP_COOP", 0);
             if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
-            static long long capacity[16];   // blocks the machine holds at once, per variant (0: not asked yet)
-            long long& cap = capacity[variant];
-            if (cap <= 0) {
-                int per_cu = 0, dev = 0, cus = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
-                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-                    return hipErrorCooperativeLaunchTooLarge;
-                cap = (long long)per_cu * cus;
+            // blocks the machine holds at once, per (device, variant): asked once, remembered under a lock (contexts of
+            // several devices and threads share this table)
+            long long cap = 0;
+            {
+                static std::mutex mu;
+                static std::map<std::pair<int, int>, long long> capacity;
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess) return hipErrorCooperativeLaunchTooLarge;
+                std::lock_guard<std::mutex> lock(mu);
+                long long& slot = capacity[std::make_pair(dev, variant)];
+                if (slot <= 0) {
+                    int per_cu = 0, cus = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess ||
+                        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                        return hipErrorCooperativeLaunchTooLarge;
+                    slot = (long long)per_cu * cus;
+                }
+                cap = slot;
             }
             if ((long long)grid.x * grid.y > cap) return hipErrorCooperativeLaunchTooLarge;
             return hipLaunchKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);

@@ -552,6 +552,103 @@ int orc_icp_p2plane_f32(const float* D, const float* M, int n, int m, const floa
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Point-to-plane with fp32 matching and fp64 minimisation -- the point-to-plane sibling of
+ * orc_icp_p2p_f32x, and for the same reason: the letter-faithful fp32 twin above accumulates the
+ * 6x6 system, evaluates the Euler rotation and sums the error norm in float (1e-4 .. 1e-3 of noise
+ * in the motion of one pass), which no tight gate can be hung on.  Here the float cloud and the
+ * float normals are widened, c = p x n, C = sum [c;n][c;n]^T and b = -sum [c;n]((p - q).n) are formed
+ * and summed in double (statements of CPU_ICP_point_to-plane.cpp:338-376), the 6x6 system is solved
+ * in double, R = Rz Ry Rx (:379-387) is evaluated in double and rounded to float together with t,
+ * the cloud is moved in float (orc_transform_f32: the arithmetic of RyT) and the error norm
+ * (src/ICP_CPU.c:257-266) is taken in double.  Matching stays orc_nn_f32: the indices -- the part
+ * that has to be bit-exact -- are decided by float arithmetic alone.
+ * ---------------------------------------------------------------------------------------- */
+int orc_p2plane_minimize_f32x(const float* p, int n, const float* q, int m, const int* q_idx,
+                              const float* normals, double* R /*9, row-major*/, double* t /*3*/,
+                              double* C_out /*36 or NULL*/, double* b_out /*6 or NULL*/)
+{
+    const size_t ns = (size_t)n, ms = (size_t)m;
+    double Cd[36], bd[6];
+    for (int e = 0; e < 36; e++) Cd[e] = 0;
+    for (int e = 0; e < 6; e++) bd[e] = 0;
+    for (int i = 0; i < n; i++) {
+        const int s = q_idx[i];
+        const double px = (double)p[i], py = (double)p[i + ns], pz = (double)p[i + 2 * ns];
+        const double nx = (double)normals[s], ny = (double)normals[s + ms], nz = (double)normals[s + 2 * ms];
+        double cn[6];
+        cn[0] = py * nz - pz * ny;
+        cn[1] = pz * nx - px * nz;
+        cn[2] = px * ny - py * nx;
+        cn[3] = nx; cn[4] = ny; cn[5] = nz;
+        const double bi = (px - (double)q[s]) * nx + (py - (double)q[s + ms]) * ny + (pz - (double)q[s + 2 * ms]) * nz;
+        for (int a = 0; a < 6; a++) {
+            for (int c = 0; c < 6; c++) Cd[a * 6 + c] += cn[a] * cn[c];
+            bd[a] -= cn[a] * bi;
+        }
+    }
+    if (C_out) memcpy(C_out, Cd, sizeof Cd);
+    if (b_out) memcpy(b_out, bd, sizeof bd);
+    double x[6];
+    const int info = orc_solve6(Cd, bd, x);
+    if (info) return info;
+    const double cx = cos(x[0]), cy = cos(x[1]), cz = cos(x[2]);
+    const double sx = sin(x[0]), sy = sin(x[1]), sz = sin(x[2]);
+    R[0] = cy * cz; R[1] = cz * sx * sy - cx * sz; R[2] = cx * cz * sy + sx * sz;
+    R[3] = cy * sz; R[4] = cx * cz + sx * sy * sz; R[5] = cx * sy * sz - cz * sx;
+    R[6] = -sy; R[7] = cy * sx; R[8] = cx * cy;
+    t[0] = x[3]; t[1] = x[4]; t[2] = x[5];
+    return 0;
+}
+
+int orc_icp_p2plane_f32x(const float* D, const float* M, int n, int m, const float* normals, int max_iter,
+                         double tol, int fixed, double* E, double* T_total, int* idx_last, float* pt_out, int* passes)
+{
+    const size_t ns = (size_t)n, ms = (size_t)m;
+    float* p = (float*)malloc(3 * ns * sizeof(float));
+    double* pd = (double*)malloc(3 * ns * sizeof(double));
+    double* qd = (double*)malloc(3 * ms * sizeof(double));
+    int* q_idx = (int*)malloc(ns * sizeof(int));
+    if (!p || !pd || !qd || !q_idx) { free(p); free(pd); free(qd); free(q_idx); return -1; }
+    memcpy(p, D, 3 * ns * sizeof(float));
+    for (size_t i = 0; i < 3 * ms; i++) qd[i] = (double)M[i];
+    for (int k = 0; k <= max_iter; k++) E[k] = 0;
+    double T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    int it = 0, npass = 0, rc = 0;
+    while (it < max_iter) {   /* CPU_ICP_point_to-plane.cpp:309 */
+        orc_nn_f32(p, n, M, m, q_idx);
+        npass++;
+        double Rd[9], td[3];
+        rc = orc_p2plane_minimize_f32x(p, n, M, m, q_idx, normals, Rd, td, NULL, NULL);
+        if (rc) break;
+        float R[9], t[3];
+        for (int k = 0; k < 9; k++) R[k] = (float)Rd[k];
+        for (int k = 0; k < 3; k++) t[k] = (float)td[k];
+        orc_transform_f32(p, n, R, t);
+        {
+            double Tk[16] = {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2], 0, 0, 0, 1};
+            double Tn[16];
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++) {
+                    double s = 0;
+                    for (int k = 0; k < 4; k++) s += Tk[a * 4 + k] * T[k * 4 + b];
+                    Tn[a * 4 + b] = s;
+                }
+            memcpy(T, Tn, sizeof T);
+        }
+        for (size_t k = 0; k < 3 * ns; k++) pd[k] = (double)p[k];
+        E[it + 1] = orc_rms_error_f64(pd, n, qd, m, q_idx);
+        if (!fixed && ((E[it + 1] < tol) || (fabs(E[it + 1] - E[it]) < tol))) break;   /* :420-421 */
+        it++;
+    }
+    if (T_total) memcpy(T_total, T, sizeof T);
+    if (idx_last) memcpy(idx_last, q_idx, ns * sizeof(int));
+    if (pt_out) memcpy(pt_out, p, 3 * ns * sizeof(float));
+    if (passes) *passes = npass;
+    free(p); free(pd); free(qd); free(q_idx);
+    return rc ? -rc : it;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Hall ingest: GPU_point_to_point_real.cu:432-623.
  * ---------------------------------------------------------------------------------------- */
 

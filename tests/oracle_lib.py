@@ -204,6 +204,38 @@ class Oracle:
         return dict(iterations=it, passes=passes.value, err=E[: passes.value + 1].astype(np.float64), T=T.reshape(4, 4),
                     idx=idx, moved=aos(pt, n))
 
+    def icp_p2plane_f32x(self, D, M, normals, max_iter, tol, fixed=False):
+        """fp32 matching + fp64 minimisation, point-to-plane (see oracle/icp_oracle.c, orc_icp_p2plane_f32x)"""
+        D = np.ascontiguousarray(D, dtype=np.float32)
+        M = np.ascontiguousarray(M, dtype=np.float32)
+        n, m = D.shape[0], M.shape[0]
+        ds, ms, ns = soa(D), soa(M), soa(np.asarray(normals, dtype=np.float32))
+        E = np.zeros(max_iter + 1, dtype=np.float64)
+        T = np.zeros(16)
+        idx = np.zeros(n, dtype=np.int32)
+        pt = np.zeros(3 * n, dtype=np.float32)
+        passes = C.c_int(0)
+        self.lib.orc_icp_p2plane_f32x.restype = C.c_int
+        it = self.lib.orc_icp_p2plane_f32x(ds.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p), n, m,
+                                           ns.ctypes.data_as(C.c_void_p), int(max_iter), C.c_double(tol), 1 if fixed else 0,
+                                           E.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p),
+                                           idx.ctypes.data_as(C.c_void_p), pt.ctypes.data_as(C.c_void_p), C.byref(passes))
+        assert it >= 0, it
+        return dict(iterations=it, passes=passes.value, err=E[: passes.value + 1].copy(), T=T.reshape(4, 4), idx=idx, moved=aos(pt, n))
+
+    def p2plane_minimize_f32x(self, P, Q, idx, normals):
+        P = np.ascontiguousarray(P, dtype=np.float32)
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        ps, qs, ns = soa(P), soa(Q), soa(np.asarray(normals, dtype=np.float32))
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        R, t, Cm, b = np.zeros(9), np.zeros(3), np.zeros(36), np.zeros(6)
+        self.lib.orc_p2plane_minimize_f32x.restype = C.c_int
+        rc = self.lib.orc_p2plane_minimize_f32x(ps.ctypes.data_as(C.c_void_p), P.shape[0], qs.ctypes.data_as(C.c_void_p), Q.shape[0],
+                                                idx.ctypes.data_as(C.c_void_p), ns.ctypes.data_as(C.c_void_p),
+                                                R.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p),
+                                                Cm.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+        return rc, R.reshape(3, 3), t, Cm.reshape(6, 6), b
+
     # ---- hall ingest ----------------------------------------------------------------------------
     def os1_ranges_from_lines(self, lines, cap=16384):
         lines = np.ascontiguousarray(lines, dtype=np.int32)

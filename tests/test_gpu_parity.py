@@ -236,6 +236,28 @@ def test_icp_hall(ctx, pkg, orc, golden):
     assert abs(res.T[1, 0] - np.sin(ang[2])) < 5e-3
 
 
+def test_icp_hall_against_the_fp64_cpu_path(ctx, pkg, orc, golden):
+    """north_star's literal comparator on the headline cloud: "outputs must match the reference CPU path in
+    src/ICP_CPU.c" (:217-271 -- fp64, tol 1e-5, MAX_ITER 200).  (a) the hall pair, widened, through ICP_F64: indices of
+    every pass from the captured P_k, iteration count, error series, composed transform; (b) the fp32 run of the same
+    pair -- the configuration the metric is quoted on -- against that same fp64 oracle run."""
+    P, Q = orc.hall_clouds(golden)
+    P64, Q64 = P.astype(np.float64), Q.astype(np.float64)
+    want = orc.icp_p2p(P64, Q64, 200, 1e-5)
+    st = _stepwise(ctx, pkg, orc, P64, Q64, 200, 1e-5)            # asserts idx_k == oracle(P_k) for every pass k
+    assert st["iterations"] == want["iterations"]
+    assert np.abs(st["err"] - want["err"]).max() < TOL_E and rel(st["T"], want["T"]) < TOL_T
+    res = ctx.point_to_point(P64, Q64, max_iter=200, tol=1e-5)
+    assert res.iterations == want["iterations"] and np.array_equal(res.idx, want["idx"])
+    assert rel(res.T, want["T"]) < TOL_T and rel(res.moved, want["moved"]) < TOL_T
+    # (b) fp32 arithmetic on the device, fp64 CPU path as the judge
+    r32 = ctx.point_to_point(P, Q, max_iter=200, tol=1e-5)
+    assert r32.iterations == want["iterations"]
+    assert rel(r32.T, want["T"]) < TOL_T                          # measured: 7e-8
+    assert np.abs(r32.err - want["err"]).max() < TOL_E            # measured: 8e-7
+    assert np.array_equal(r32.idx, want["idx"])                   # the final correspondences agree point for point
+
+
 def test_icp_bunny(ctx, pkg, orc, golden):
     B = np.fromfile(os.path.join(golden, "bunny_res_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
     M = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
@@ -693,8 +715,10 @@ def test_two_ranks_large_model_sharded_like_configs4(pkg, orc):
         assert np.array_equal(np.concatenate([got[0]["idx"], got[1]["idx"]]), want["idx"])
 
 
-def test_creating_thread_lands_on_the_device_numa_node(pkg):
-    """icp_create narrows the calling thread to the CPUs sysfs lists as local to the device; ICP_PIN=0 does not"""
+def test_sticky_pin_lands_on_the_device_numa_node(pkg):
+    """ICP_PIN=2 (opt-in, a thread dedicated to the context): icp_create narrows the calling thread to the CPUs sysfs lists
+    as local to the device and leaves it there; ICP_PIN=0 and the default (scoped narrowing) hand the caller's mask back
+    (tests/test_gpu_runtime.py checks that after every entry point)"""
     import subprocess, sys, json
     code = (
         "import os, sys, json, ctypes\n"
@@ -718,9 +742,10 @@ def test_creating_thread_lands_on_the_device_numa_node(pkg):
             a, _, b = part.partition("-")
             cpus.update(range(int(a), int(b or a) + 1))
         return cpus
-    r = run({"ICP_PIN": "0"})
-    assert r["after"] == r["before"]
-    r = run({"ICP_PIN": "1"})
+    for pin in ("0", "1"):
+        r = run({"ICP_PIN": pin})
+        assert r["after"] == r["before"], pin
+    r = run({"ICP_PIN": "2"})
     local = parse(r["local"])
     want = sorted(set(r["before"]) & local)
     if local and want and len(want) < len(r["before"]):

@@ -47,26 +47,66 @@ def test_knn4_with_coincident_points(ctx, pkg, orc, golden):
     assert np.array_equal(nbr, orc.knn4(Q))
 
 
-@pytest.mark.parametrize("which", ["grid", "bunny"])
+# fraction of model points whose normal is DEFINED (the two smallest eigenvalues of the neighbourhood covariance are
+# separated by more than 1e-3 of the largest): measured from the oracle's covariances -- grid 40x40 0.9625, Bunny_res
+# 1.0, hall 0.7175 (another 0.266 of the hall points are the 4361 no-return points at the origin, whose four nearest
+# neighbours coincide with them: zero covariance, every direction is an eigenvector).  The gate sits just below.
+NORMAL_DEFINED_MIN = {"grid": 0.95, "bunny": 0.99, "hall": 0.70}
+
+
+@pytest.mark.parametrize("which", ["grid", "bunny", "hall"])
 def test_normals_match_oracle_up_to_sign(ctx, pkg, orc, golden, which):
-    _, M = _clouds(pkg, golden, which)
+    M = orc.hall_clouds(golden)[1] if which == "hall" else _clouds(pkg, golden, which)[1]
     ctx.set_model(M)
     nrm, nbr = ctx.estimate_normals(want_neighbours=True)
+    assert np.array_equal(nbr, orc.knn4(M))
     want, A = orc.normals(M, nbr)
-    # the eigenvector is defined up to sign (and is arbitrary when the two smallest eigenvalues coincide)
     Af = A.reshape(-1, 3, 3).astype(np.float64)
     Af = np.triu(Af) + np.transpose(np.triu(Af, 1), (0, 2, 1))
     w = np.linalg.eigvalsh(Af)
+    scale = np.maximum(np.abs(w).max(1), 1e-30)
+    # (1) EVERY point: the vector is a unit eigenvector of the eigenvalue of smallest magnitude -- checked through its
+    # Rayleigh quotient, which does not care which vector of a degenerate eigenspace was picked, and its residual
+    n64 = nrm.astype(np.float64)
+    assert np.abs(np.linalg.norm(n64, axis=1) - 1.0).max() < 1e-5
+    w_min = w[np.arange(len(w)), np.abs(w).argmin(1)]
+    ray = np.einsum("ni,nij,nj->n", n64, Af, n64)
+    assert (np.abs(ray - w_min) <= 1e-5 * scale + 1e-12).all()
+    resid = np.linalg.norm(np.einsum("nij,nj->ni", Af, n64) - ray[:, None] * n64, axis=1)
+    assert (resid <= 1e-4 * scale + 1e-12).all()
+    # (2) where the direction is defined it is the oracle's, up to sign; the share of such points is asserted
     ok = (w[:, 1] - w[:, 0]) > 1e-3 * np.maximum(w[:, 2], 1e-30)
-    assert ok.mean() > 0.5
+    assert ok.mean() >= NORMAL_DEFINED_MIN[which], ok.mean()
     dots = np.abs((nrm * want).sum(1))
     assert np.abs(dots[ok] - 1.0).max() < 1e-4
-    assert np.abs(np.linalg.norm(nrm, axis=1) - 1.0).max() < 1e-5
+    # (3) zero covariance (coincident neighbourhood): both sides fall back to the same axis
+    zero = np.abs(Af).max((1, 2)) == 0
+    if zero.any():
+        assert np.abs(np.abs((nrm[zero] * want[zero]).sum(1)) - 1.0).max() < 1e-6
 
 
 # ---------------------------------------------------------------------------------------------------
 # point-to-plane minimisation and loop  (src/ICP_point_to_plane.cu:517-631)
 # ---------------------------------------------------------------------------------------------------
+TOL_T = 1e-5      # relative, composed 4x4 transform (BASELINE.json north_star)
+TOL_E = 1e-5      # absolute, RMS error series
+
+
+def assert_same_plane_run(res, want, tol):
+    """the gate of the point-to-point loops (tests/test_gpu_parity.py, assert_same_run): error series and composed
+    transform within 1e-5, the same iteration count -- one apart only if the deciding |dE| (or E) sits within 5e-7 of
+    the stop threshold, where the last bits of a sum may decide"""
+    n = min(len(res.err), len(want["err"]))
+    assert np.abs(np.asarray(res.err)[:n] - want["err"][:n]).max() < TOL_E
+    if res.iterations != want["iterations"]:
+        assert abs(res.iterations - want["iterations"]) == 1, (res.iterations, want["iterations"])
+        k = min(res.iterations, want["iterations"]) + 1
+        dE = abs(want["err"][k] - want["err"][k - 1])
+        assert abs(dE - tol) < 5e-7 or abs(want["err"][k] - tol) < 5e-7, f"stop rule disagreed away from the threshold: dE={dE}"
+    else:
+        assert rel(res.T, want["T"]) < TOL_T
+
+
 @pytest.mark.parametrize("which", ["grid", "bunny"])
 def test_point_to_plane_single_pass(ctx, pkg, orc, golden, which):
     D, M = _clouds(pkg, golden, which)
@@ -74,9 +114,13 @@ def test_point_to_plane_single_pass(ctx, pkg, orc, golden, which):
     res = ctx.point_to_plane(D, M, normals=normals, max_iter=1, tol=1e-6)
     idx = orc.nn(D, M)
     assert res.passes == 1 and np.array_equal(res.idx, idx)
+    # the same statements in the same precision (fp64 sums of fp64 terms, fp64 solve): the same 6x6 system, the same motion
+    rc, R, t, Cm, b = orc.p2plane_minimize_f32x(D, M, idx, normals)
+    assert rc == 0
+    assert rel(res.T[:3, :3], R) < 1e-6 and np.abs(res.T[:3, 3] - t).max() < 1e-6 * max(1.0, np.abs(t).max())
+    # float terms summed in double (the oracle's other variant): float noise of the terms only
     rc, R, t, Cm, b = orc.p2plane_minimize(D, M, idx, normals, accumulate_f64=True)
     assert rc == 0
-    # same 6x6 system (fp64 accumulation on both sides) -> same motion
     assert rel(res.T[:3, :3], R) < 1e-5 and np.abs(res.T[:3, 3] - t).max() < 1e-5 * max(1.0, np.abs(t).max())
     # the letter-faithful twin accumulates C and b in float: agreement inside its noise band
     rc, Rf, tf, _, _ = orc.p2plane_minimize(D, M, idx, normals, accumulate_f64=False)
@@ -88,11 +132,16 @@ def test_point_to_plane_loop(ctx, pkg, orc, golden, which):
     D, M = _clouds(pkg, golden, which)
     normals, _ = orc.normals(M, orc.knn4(M))
     res = ctx.point_to_plane(D, M, normals=normals, max_iter=50, tol=1e-6)
-    want = orc.icp_p2plane(D, M, normals, 50, 1e-6, accumulate_f64=True)
-    assert abs(res.iterations - want["iterations"]) <= 1
-    n = min(len(res.err), len(want["err"]))
-    assert np.abs(res.err[:n] - want["err"][:n]).max() < 1e-4
-    assert rel(res.T, want["T"]) < 1e-4
+    # tight: fp32 matching + fp64 minimisation, the arithmetic the product uses (oracle/icp_oracle.c, orc_icp_p2plane_f32x)
+    want = orc.icp_p2plane_f32x(D, M, normals, 50, 1e-6)
+    assert_same_plane_run(res, want, 1e-6)
+    assert np.array_equal(res.idx, want["idx"]) or res.iterations != want["iterations"]
+    # the letter-faithful fp32 twin (float accumulators, float error norm; CPU_ICP_point_to-plane.cpp) and its variant
+    # with double accumulators: the three oracle loops agree among themselves to 1e-7 in T and 3e-6 in E on these
+    # clouds (measured), so the same 1e-5 gate holds against each of them
+    for acc64 in (True, False):
+        twin = orc.icp_p2plane(D, M, normals, 50, 1e-6, accumulate_f64=acc64)
+        assert_same_plane_run(res, twin, 1e-6)
     assert res.err[-1] < 0.5 * res.err[1]                     # and it actually converges
     # normals estimated on the device give the same registration (sign of a normal does not matter)
     res2 = ctx.point_to_plane(D, M, normals=None, max_iter=50, tol=1e-6)
@@ -264,10 +313,14 @@ def test_point_to_plane_hall(ctx, pkg, orc, golden):
     nrm, nbr = ctx.estimate_normals(want_neighbours=True)
     assert np.array_equal(nbr, orc.knn4(Q))
     res = ctx.point_to_plane(P, Q, normals=nrm, max_iter=100, tol=1e-6)
-    want = orc.icp_p2plane(P, Q, nrm, 100, 1e-6, accumulate_f64=True)      # same normals on both sides
-    assert abs(res.iterations - want["iterations"]) <= 1
-    k = min(len(res.err), len(want["err"]))
-    assert np.abs(res.err[:k] - want["err"][:k]).max() < 1e-4
-    assert rel(res.T, want["T"]) < 1e-4
+    want = orc.icp_p2plane_f32x(P, Q, nrm, 100, 1e-6)                     # same normals on both sides
+    assert_same_plane_run(res, want, 1e-6)
+    assert np.array_equal(res.idx, want["idx"]) or res.iterations != want["iterations"]
+    for acc64 in (True, False):                                          # the fp32 twin and its double-accumulating variant
+        assert_same_plane_run(res, orc.icp_p2plane(P, Q, nrm, 100, 1e-6, accumulate_f64=acc64), 1e-6)
     ang, t_mm = pkg.datasets.HALL_MM
     assert np.abs(res.T[:3, 3] - np.array(t_mm) / 1000.0).max() < 5e-3 and abs(res.T[1, 0] - np.sin(ang[2])) < 5e-3
+    # the oracle's own normals (host eigen-solve) instead of the device's: the registration is the same
+    onrm, _ = orc.normals(Q, nbr)
+    res_o = ctx.point_to_plane(P, Q, normals=onrm, max_iter=100, tol=1e-6)
+    assert_same_plane_run(res_o, orc.icp_p2plane_f32x(P, Q, onrm, 100, 1e-6), 1e-6)

@@ -1,0 +1,194 @@
+"""GPU: behaviour of the library around the hot path -- the caller's CPU affinity, the mailbox time budgets (a host thread
+that comes back late), the executed-work counters, and bench.py under the driver's own command lines."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _child(code, env=None, timeout=300):
+    pre = ("import sys, os, json, numpy as np\n"
+           f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))\n"
+           "from __graft_entry__ import load_package\n"
+           "pkg = load_package()\n")
+    out = subprocess.run([sys.executable, "-c", pre + code], env=dict(os.environ, **(env or {})), capture_output=True, text=True,
+                         timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+# ---------------------------------------------------------------------------------------------------
+# a drop-in library leaves its caller's affinity as it found it
+# ---------------------------------------------------------------------------------------------------
+AFFINITY_CODE = """
+before = sorted(os.sched_getaffinity(0))
+D = pkg.datasets.synthetic_grid(48, np.float32)
+M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+seen = {}
+with pkg.Context(0) as ctx:
+    seen["create"] = sorted(os.sched_getaffinity(0))
+    r = ctx.point_to_point(D, M, max_iter=20, tol=1e-6)
+    seen["point_to_point"] = sorted(os.sched_getaffinity(0))
+    ctx.set_model(M); ctx.set_moving(D)
+    ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=20, tol=1e-6)
+    ctx.loop_run(3)
+    seen["loop_run"] = sorted(os.sched_getaffinity(0))
+    ctx.loop_enqueue(); ctx.loop_complete()
+    seen["complete"] = sorted(os.sched_getaffinity(0))
+seen["destroy"] = sorted(os.sched_getaffinity(0))
+print(json.dumps(dict(before=before, seen=seen, T=r.T.tolist(), it=r.iterations)))
+"""
+
+
+@pytest.mark.parametrize("pin", [None, "0", "1"])
+def test_callers_affinity_is_left_as_found(pin):
+    """icp_create narrowed the caller's mask and never restored it.  Now the narrowing is scoped to the entry
+    points that talk to the GPU in a loop (ICP_PIN=1, the default) or absent (ICP_PIN=0)."""
+    env = {} if pin is None else {"ICP_PIN": pin}
+    got = _child(AFFINITY_CODE, env)
+    for where, mask in got["seen"].items():
+        assert mask == got["before"], f"ICP_PIN={pin}: affinity changed after {where}"
+
+
+def test_pin_settings_do_not_change_results():
+    a = _child(AFFINITY_CODE, {"ICP_PIN": "0"})
+    b = _child(AFFINITY_CODE, {"ICP_PIN": "1"})
+    c = _child(AFFINITY_CODE.replace('for where', '#'), {"ICP_PIN": "2"})      # sticky narrowing (opt-in): still the same bits
+    assert a["T"] == b["T"] == c["T"] and a["it"] == b["it"] == c["it"]
+    cpus = os.cpu_count() or 1
+    if len(c["before"]) == cpus and any(len(m) < len(c["before"]) for m in c["seen"].values()):
+        assert set(c["seen"]["destroy"]) <= set(c["before"])                    # ICP_PIN=2 narrows and keeps it
+
+
+# ---------------------------------------------------------------------------------------------------
+# a host that comes back late: the waiting kernel is withdrawn and the registration resumes -- same bits
+# ---------------------------------------------------------------------------------------------------
+STALL_CODE = """
+import oracle_lib
+orc = oracle_lib.Oracle()
+P, Q = orc.hall_clouds(os.path.join(%r, 'tests', 'golden'))
+with pkg.Context(0) as ctx:
+    r = ctx.point_to_point(P, Q, max_iter=100, tol=1e-6)
+    moved = ctx.get_moving()
+print(json.dumps(dict(it=r.iterations, T=r.T.tolist(), err=r.err.tolist(), sec=r.seconds_total,
+                      idx=int(np.bitwise_xor.reduce(r.idx * np.arange(1, r.idx.size + 1, dtype=np.int64))),
+                      moved=float(np.abs(moved).sum()))))
+""" % ROOT
+
+
+@pytest.mark.parametrize("form", ["resident", "armed"])
+@pytest.mark.parametrize("stall", ["3:1.7", "5:4.6"])
+def test_late_host_withdraws_and_resumes(form, stall):
+    """ICP_DEBUG_STALL makes the host sleep before it publishes one pass's message: 1.7 s is past the host's lease (it
+    withdraws the kernel itself), 4.6 s is past the kernel's own wall-clock budget (every block has given up).  Either
+    way no block may act on a message another block missed: the run must end with exactly the bits of an undisturbed one."""
+    env = {"ICP_RESIDENT": "0"} if form == "armed" else {}
+    ref = _child(STALL_CODE, env)
+    got = _child(STALL_CODE, dict(env, ICP_DEBUG_STALL=stall))
+    assert got["sec"] > float(stall.split(":")[1]) - 0.2            # (the stall really happened)
+    for k in ("it", "T", "err", "idx", "moved"):
+        assert got[k] == ref[k], k
+
+
+# ---------------------------------------------------------------------------------------------------
+# executed-work counters (the roofline of the pruned search is about EXECUTED arithmetic)
+# ---------------------------------------------------------------------------------------------------
+def test_work_counters(ctx, pkg, orc, golden):
+    P, Q = orc.hall_clouds(golden)
+    ctx.set_model(Q)
+    ctx.set_moving(P)
+    plain = ctx.nn_match_resident()
+    idx_plain = ctx.get_indices()
+    ctx.set_work_counting(True)
+    try:
+        ctx.nn_match_resident()
+        w = ctx.get_work_counters()
+        assert np.array_equal(ctx.get_indices(), idx_plain)            # the instrumented instantiation is the same search
+        info = ctx.nn_launch_info()
+        blocks = info["blocks"]
+        assert w["block_passes"] == blocks and w["block_transforms"] == 0
+        assert w["find_boxes"] == blocks * (info["m_pad"] // 8) // info["splits"]   # every chunk box is tested once per block
+        assert w["hits_box"] >= w["hits_xy"] >= w["hits_full"] > 0
+        # a cold pass evaluates a few per cent of the pairs in full -- and never more than all of them
+        frac = w["hits_full"] * 128 * 8 / (P.shape[0] * Q.shape[0])
+        assert 1e-4 < frac < 0.2, frac
+        assert ctx.get_work_counters()["block_passes"] == 0            # reading resets
+    finally:
+        ctx.set_work_counting(False)
+    ctx.nn_match_resident()
+    assert np.array_equal(ctx.get_indices(), idx_plain)
+
+
+def test_per_launch_timing_modes(ctx, pkg, orc, golden):
+    P, Q = orc.hall_clouds(golden)
+    ctx.set_model(Q)
+    ctx.set_moving(P)
+    ctx.nn_match_resident()
+    seeded = ctx.nn_match_bench_launches(5, 2, 0)
+    cold = ctx.nn_match_bench_launches(5, 2, 1)
+    dense = ctx.nn_match_bench_launches(5, 2, 2)
+    assert seeded.shape == (5,) and (seeded > 0).all() and (cold > 0).all() and (dense > 0).all()
+    # the dense kernel executes all 2.7e8 pairs: at the fp32 peak that alone takes 13.7 us
+    assert dense.min() * 1e-3 > 13.7e-6
+    assert dense.min() > seeded.min()
+    assert ctx.nn_launch_info_ex(dense=True)["n_pad"] == 16384
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py under the driver's command lines
+# ---------------------------------------------------------------------------------------------------
+def _bench(args, env=None, timeout=420):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=dict(os.environ, **(env or {})),
+                         capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]                          # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_with_the_drivers_arguments():
+    """round 1's bench died with ZeroDivisionError on exactly this command (BENCH_r01.json)"""
+    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["unit"] == "iterations/s"
+    assert abs(d["value"] - 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert r["launches_timed"] >= 1 and r["avg_launch_us"] > 0
+    assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0 < r["dense_kernel"]["frac"] <= 0.5 + 1e-9                  # no FMA: half the FMA-counted roof at most
+    assert 0 < r["hbm"]["frac"] <= 1.0
+    assert r["matching_only"]["min_launch_us"] <= r["matching_only"]["avg_launch_us"]
+    assert r["executed"]["pairs_evaluated_in_full_fraction"] < 0.2
+    c = d["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] == 1 and c["kind"] == "port" and c["sample"]
+    assert d["final_rms_error"] < 1e-3
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent spawns the ranks (rehearsed with both on the one GPU)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ICP_BENCH_ONE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "120", "--warmup", "20"], env=env,
+                         capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_moving_points"] == 2 * 16384
+    assert "shared host memory" in d["config"]["collective"]
+    # RCCL refuses two ranks on one device: the leg must say so instead of hanging or killing the line
+    assert d["rccl"]["ranks"] == 2 and ("error" in d["rccl"] or d["rccl"]["value"] > 0)
+    assert 0 < d["roofline"]["frac"] <= 1.0
+
+
+def test_bench_rccl_leg_single_rank():
+    """the library-issued ncclAllReduce route, exercised with the one rank this box has"""
+    d = _bench(["--steps", "120", "--warmup", "20", "--no-cpu-baseline"], {"ICP_BENCH_FORCE_DIST": "1"})
+    assert d["rccl"]["ranks"] == 1 and d["rccl"]["value"] > 0 and d["rccl"]["us_per_iteration"] > 0

@@ -178,3 +178,29 @@ def test_library_embeds_gfx950_code_object(pkg):
     blob = open(pkg.capi.LIB_PATH, "rb").read()
     assert b"hipv4-amdgcn-amd-amdhsa--gfx950" in blob
     assert b"amdhsa--gfx906" not in blob
+
+
+def test_bench_executed_flop_arithmetic():
+    """bench.py's roofline counts EXECUTED flop from the kernel's work counters: the conversion, on known tallies"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    work = dict(find_boxes=2048, upper_boxes=0, hits_box=10, hits_xy=6, hits_full=4, sample_groups=2, block_passes=1, block_transforms=1)
+    total, parts = bench.executed_flop(work)
+    assert parts["find (group box vs chunk boxes)"] == 2048 * 12
+    assert parts["per-point box tests"] == 10 * 128 * 12
+    assert parts["xy halves"] == 6 * 128 * 8 * 5 and parts["z halves"] == 4 * 128 * 8 * 3
+    assert parts["cold-start samples"] == 2 * 128 * 8 * 8
+    assert parts["seed distances"] == 16 * 128 * 8 and parts["transforms"] == 16 * 128 * 18
+    assert total == sum(parts.values())
+    # a hit evaluated in full costs exactly the reference's 8 flop per pair, plus its box test
+    full = bench.executed_flop(dict(work, find_boxes=0, hits_box=1, hits_xy=1, hits_full=1, sample_groups=0, block_passes=0, block_transforms=0))[0]
+    assert full == 128 * 8 * 8 + 128 * 12
+
+
+def test_bench_refuses_a_rank_count_that_does_not_match_the_launcher():
+    import subprocess, sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
