@@ -271,6 +271,9 @@ __device__ __forceinline__ f2 pk_dist2(f2 qx, f2 qy, f2 qz, f2 px, f2 py, f2 pz)
 // drain the wave's global stores (s_waitcnt vmcnt(0)) -- ~1 us of idle time in the matching kernel's tail.
 __device__ __forceinline__ void lds_same_wave_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// a wave-uniform float, moved to a scalar register
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 // An index the compiler must treat as new: keeps it from hoisting the per-lane 64-bit addresses derived from a
 // loop-invariant index out of the resident kernel's pass loop (a dozen register pairs held for nothing -- it spilled).
 __device__ __forceinline__ int fresh(int i) { asm volatile("" : "+v"(i)); return i; }
@@ -473,6 +476,7 @@ struct NNFuse {
     long long* tlog;         // diagnostic (ICP_NN_PHASES): per-wave s_memrealtime stamps, 10 slots per wave, or NULL
     long long tlog_cap;      // slots available
     int tlog_pass;           // resident launch: stamp this pass only (-1: every pass, the last one survives)
+    int speculate;           // resident launch: prepare the next pass's hit list while the block waits for its message (see the end of the pass loop)
     unsigned long long* work; // diagnostic (icp_set_work_counting): NN_WORK_SLOTS device counters of the work the sparse kernel EXECUTES, or NULL
 };
 
@@ -1072,7 +1076,12 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * STG * 4;
     constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
     constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x SP_NW x 128
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MQ_OFF + 3 * MD_BYTES + (HIER ? SP_NW * 64 * 4 : 0)];  // (+ the level-3 hit list)
+    // flat search: the chunk boxes of every wave's first PRE find passes are cached in LDS (the model does not change during
+    // a resident launch; in registers they cost 16 VGPRs the kernel does not have): [wave][pass][half][lane] float4
+    constexpr int PRE = 2;
+    constexpr int BOXC_OFF = MQ_OFF + 3 * MD_BYTES, BOXC_BYTES = HIER ? 0 : SP_NW * PRE * 2 * 64 * 16;
+    constexpr int SPST_OFF = BOXC_OFF + BOXC_BYTES, SPST_BYTES = HIER ? 0 : SP_NW * 8 * 4;   // per wave: what its speculative list was built for
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SPST_OFF + SPST_BYTES + (HIER ? SP_NW * 64 * 4 : 0)];  // (+ the level-3 hit list)
     int* hits = reinterpret_cast<int*>(lds_raw);
     // merge scratch: one (distance, index, wave) key per moving point, folded with LDS atomic mins -- the 64-bit
     // integer order is the lexicographic order the tie rule needs (d >= 0; index < 2^28; the wave id rides in the
@@ -1099,7 +1108,6 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     ICP_PHASE(0)
     const int q0 = blockIdx.y * seg_len;
     const int c_lo = q0 / 8, c_hi = min(q0 + seg_len, m_pad) / 8;
-    constexpr int PRE = 2;
     // issued first, with everything else that does not depend on the points:
     // the seed gather does not depend on the points (the compiler cannot move these loads above the
     // stores to P_out itself), and when the seeds are the correspondences the fused transform came from -- the
@@ -1146,30 +1154,37 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     // host: no launch, no dispatch, no kernel boundary between two passes.
     // Wave 0 of every block waits for the message (see below), the other waves sleep at the barrier.  The poll budget
     // (a few seconds) is the exit every wave reaches if the host never answers.
-    // the chunk boxes of the wave's first two find passes: fetched once (a resident kernel keeps them in registers: the model
-    // does not change)
-    float4 pb[PRE][2];
-#pragma unroll
-    for (int r = 0; r < PRE; ++r) {
-        if constexpr (HIER) {
-            // (the upper levels follow the chunk boxes in the same array; the search starts at level 3: one pass per wave)
-            const int n2_all = ((m_pad >> 3) + 63) >> 6;
-            const int t_lo = c_lo >> 12, t_hi = ((((c_hi + 63) >> 6)) + 63) >> 6;
-            const int tidx = t_lo + w * 64 + lane;
-            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)m_pad + ((size_t)n2_all + (size_t)(tidx < t_hi ? tidx : t_lo)) * 8);
-            pb[r][0] = bp[0];
-            pb[r][1] = bp[1];
-        } else {
-            const int cidx = c_lo + (r * SP_NW + w) * 64 + lane;
-            const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cidx < c_hi ? cidx : 0) * 8);
-            pb[r][0] = bp[0];
-            pb[r][1] = bp[1];
-        }
+    // the chunk boxes of the wave's first find passes: fetched once, at kernel entry (with everything else that does not
+    // depend on the points or on the message)
+    float4 pb0 = float4{0.f, 0.f, 0.f, 0.f}, pb1 = pb0;   // hierarchical search: the wave's level-3 box, kept in registers
+    float4 (*boxc)[2][64] = reinterpret_cast<float4 (*)[2][64]>(lds_raw + BOXC_OFF) + w * PRE;   // flat search: [pass][half][lane]
+    if constexpr (HIER) {
+        // (the upper levels follow the chunk boxes in the same array; the search starts at level 3: one pass per wave)
+        const int n2_all = ((m_pad >> 3) + 63) >> 6;
+        const int t_lo = c_lo >> 12, t_hi = ((((c_hi + 63) >> 6)) + 63) >> 6;
+        const int tidx = t_lo + w * 64 + lane;
+        const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)m_pad + ((size_t)n2_all + (size_t)(tidx < t_hi ? tidx : t_lo)) * 8);
+        pb0 = bp[0];
+        pb1 = bp[1];
+    } else {
+        static_assert(PRE == 2, "two passes are fetched together");
+        const int ca = c_lo + w * 64 + lane, cb = ca + SP_NW * 64;
+        const float4* bpa = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(ca < c_hi ? ca : 0) * 8);
+        const float4* bpb = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cb < c_hi ? cb : 0) * 8);
+        const float4 a0 = bpa[0], a1 = bpa[1], b0 = bpb[0], b1 = bpb[1];
+        // (read back by this wave only: DS operations of a wave stay in order)
+        boxc[0][0][lane] = a0; boxc[0][1][lane] = a1;
+        boxc[1][0][lane] = b0; boxc[1][1][lane] = b1;
     }
+    // (work-counting instantiation only) what this wave executes -- wave-uniform tallies, flushed once per pass
+    unsigned int wk_find = 0, wk_upper = 0, wk_hit[3] = {0, 0, 0}, wk_samp = 0;
+    // Speculative hit list of a resident launch (prepared at the end of a pass, see there): the group box and the bound
+    // it was built for, and its length.  Wave-uniform, and the same in every wave of the block.
+    // (kept in LDS, a private slot per wave {lo.xyz, B, hi.xyz, -}: the kernel has no registers to spare across the wait)
+    bool spec_valid = false;
+    float* spst = reinterpret_cast<float*>(lds_raw + SPST_OFF) + w * 8;
     for (int pass = 0;; ++pass) {
     phase_pass_ = pass;
-    // (work-counting instantiation only) what this wave executes in this pass -- wave-uniform tallies, flushed once per pass
-    unsigned int wk_find = 0, wk_upper = 0, wk_hit[3] = {0, 0, 0}, wk_samp = 0;
     double err_row = 0.0;
     RT<float> rt = rt_arg;
     int cmd = fuse.apply ? ICP_CMD_TRANSFORM_MATCH : ICP_CMD_MATCH;
@@ -1180,7 +1195,9 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         mkey[lane] = ~0ull; mkey[lane + 64] = ~0ull;
     }
     if (threadIdx.x == 0) {
-        *hcount = 0;
+        // (flat search: from the second pass of a resident launch on, the counter is looked after at the end of the pass
+        // before -- it may hold the length of a speculative list)
+        if (HIER || pass == 0) *hcount = 0;
         if constexpr (HIER) { hcount[1] = 0; hcount[2] = 0; }
     }
     if (fuse.mailbox != nullptr) {
@@ -1381,12 +1398,13 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     wave_box(glo, ghi);
 
     const int round_chunks = SP_NW * 64 * round_passes;
+    float B0_pass = -1.f;   // (flat search) the largest starting bound of this pass
     // one find pass: lane l tests chunk c0 + l (box b0 = lo.xyz hi.x, b1 = hi.yz - -) and appends it to the hit list
-    auto find_pass = [&](int c0, const float4 b0, const float4 b1, float B) {
+    auto find_pass = [&](int c0, const float4 b0, const float4 b1, float B, const float (&gl)[3], const float (&gh)[3]) {
         const int cidx = c0 + lane;
-        const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - ghi[0], glo[0] - b0.w), 0.f);
-        const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - ghi[1], glo[1] - b1.x), 0.f);
-        const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - ghi[2], glo[2] - b1.y), 0.f);
+        const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - gh[0], gl[0] - b0.w), 0.f);
+        const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - gh[1], gl[1] - b1.x), 0.f);
+        const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - gh[2], gl[2] - b1.y), 0.f);
         const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;
         const bool pass = cidx < c_hi && L < B;  // every candidate winner lies strictly below its point's starting bound
         if constexpr (DIAG) wk_find += (unsigned int)max(0, min(64, c_hi - c0));
@@ -1403,8 +1421,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     // gather -- 8 lanes x 16 bytes per hit -- into its private LDS stage, so a batch of hits costs one trip to
     // memory instead of three or four each.
     // (exchanging minima between the batches of a cold pass was measured too: the barriers cost more than they save)
-    auto process_hits = [&](const int h1) {
-        for (int hb = 0; hb < h1; hb += SP_NW * 8) {
+    auto gather_batch = [&](const int hb, const int h1) {
             {
                 const int r = lane >> 3, part = lane & 7;
                 const int h = hb + r * SP_NW + w;
@@ -1424,6 +1441,8 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 }
             }
             lds_same_wave_order();
+    };
+    auto scan_batch = [&](const int hb, const int h1) {
             const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
             const int cnt = mine < 8 ? mine : 8;
             for (int rr = 0; rr < cnt; ++rr) {
@@ -1441,6 +1460,11 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 }
             }
             lds_same_wave_order();
+    };
+    auto process_hits = [&](const int h1) {
+        for (int hb = 0; hb < h1; hb += SP_NW * 8) {
+            gather_batch(hb, h1);
+            scan_batch(hb, h1);
         }
     };
     // exchange before the next round: every wave goes on from the block's best minimum so far, bumped by
@@ -1456,6 +1480,29 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             if (real[t] && v < 0x7f800000u && v < __float_as_uint(best[t])) { best[t] = __uint_as_float(v + 1u); bj[t] = -1; }
         }
     };
+    // one round of the find: every wave tests its share of the round's chunks against the group box (gl, gh) and the bound B
+    auto find_round = [&](int rb, float B, const float (&gl)[3], const float (&gh)[3]) {
+        int r = 0;
+        if (rb == c_lo) {  // the first round's first passes use the boxes fetched at kernel entry
+#pragma unroll
+            for (; r < PRE; ++r) {
+                const int c0 = rb + (r * SP_NW + w) * 64;
+                if constexpr (!HIER)
+                    if (r < round_passes && c0 < c_hi) find_pass(c0, boxc[r][0][lane], boxc[r][1][lane], B, gl, gh);
+            }
+        }
+        // (the boxes of two passes are requested together: one memory latency for both)
+        for (; r < round_passes; r += 2) {
+            const int c0 = rb + (r * SP_NW + w) * 64, c1 = c0 + SP_NW * 64;
+            if (c0 >= c_hi) break;
+            const bool two = r + 1 < round_passes && c1 < c_hi;
+            const float4* bp0 = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
+            const float4* bp1 = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(two && c1 + lane < c_hi ? c1 + lane : c_lo) * 8);
+            const float4 a0 = bp0[0], a1 = bp0[1], d0 = bp1[0], d1 = bp1[1];
+            find_pass(c0, a0, a1, B, gl, gh);
+            if (two) find_pass(c1, d0, d1, B, gl, gh);
+        }
+    };
     if constexpr (HIER) {
         // A hierarchy of boxes, 64 to 1: chunks (8 model points) < super boxes (512 points) < level-3 boxes (32 768
         // points).  Every level is tested like the chunks of the flat search -- one box per lane against the group
@@ -1468,7 +1515,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         constexpr int TCAP = SP_NW * 64;       // level-3 hit list = level-3 boxes per outermost round (33 M model points)
         static_assert(SCAP * 4 <= 3 * 2048 * 4 - HITS_BYTES, "the super-box hit list lies between the chunk hit list and the merge keys");
         int* shits = reinterpret_cast<int*>(lds_raw + HITS_BYTES);
-        int* thits = reinterpret_cast<int*>(lds_raw + MQ_OFF + 3 * MD_BYTES);
+        int* thits = reinterpret_cast<int*>(lds_raw + SPST_OFF + SPST_BYTES);
         int* scount = hcount + 1;
         int* tcount = hcount + 2;
         const int n2_all = ((m_pad >> 3) + 63) >> 6;
@@ -1504,7 +1551,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             {   // level 3: one pass per wave (the first round's boxes were fetched at kernel entry)
                 const float Bt = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
                 const int tidx = tb + w * 64 + lane;
-                float4 b0 = pb[0][0], b1 = pb[0][1];
+                float4 b0 = pb0, b1 = pb1;
                 if (tb != t_lo) {
                     const float4* bp = reinterpret_cast<const float4*>(tboxes + (size_t)(tidx < t_hi ? tidx : t_lo) * 8);
                     b0 = bp[0]; b1 = bp[1];
@@ -1538,7 +1585,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                     for (int k = sh0 + w; k < send; k += SP_NW) {
                         const int c0 = shits[k] << 6;
                         const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
-                        find_pass(c0, bp[0], bp[1], B);
+                        find_pass(c0, bp[0], bp[1], B, glo, ghi);
                     }
                     __syncthreads();
                     dg_lap(1);
@@ -1571,33 +1618,38 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             }
         }
     } else {
+    const float B0 = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));   // the largest starting bound of the block's points
+    B0_pass = B0;
+    bool searched = false;
+    if (spec_valid) {
+        // A hit list for this pass was prepared -- found AND fetched into the waves' stages -- while the block waited for
+        // the message, for a group box and a bound that were guessed (end of the pass loop).  It holds every chunk the
+        // find below would list if the guesses cover the real ones: the box test is monotonic in both, operation by
+        // operation (a wider group box gives smaller gaps, a larger bound passes more).  Extra chunks cost time, never
+        // the answer: every hit still goes through the exact per-point tests.
+        const float4 s0 = *reinterpret_cast<const float4*>(spst), s1 = *reinterpret_cast<const float4*>(spst + 4);   // (broadcast reads)
+        const bool covered = glo[0] >= s0.x && glo[1] >= s0.y && glo[2] >= s0.z &&
+                             ghi[0] <= s1.x && ghi[1] <= s1.y && ghi[2] <= s1.z && B0 <= s0.w;
+        if (covered) {
+            scan_batch(0, *hcount);   // (the list's length is still in the counter)
+            searched = true;
+        } else {
+            if (threadIdx.x == 0) *hcount = 0;   // the guess did not hold: forget the list and search as usual
+            __syncthreads();
+        }
+    }
+    if (!searched) {
     for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
         // B only shrinks while the block works: refreshed once per round
-        const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
+        const float B = rb == c_lo ? B0 : wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
         if (rb != c_lo) __syncthreads();  // the list is empty and its counter reset (first round: the barrier above)
-        int r = 0;
-        if (rb == c_lo) {  // the first round's first passes use the boxes fetched at kernel entry
-#pragma unroll
-            for (; r < PRE; ++r) {
-                const int c0 = rb + (r * SP_NW + w) * 64;
-                if (r < round_passes && c0 < c_hi) find_pass(c0, pb[r][0], pb[r][1], B);
-            }
-        }
-        // (the boxes of two passes are requested together: one memory latency for both)
-        for (; r < round_passes; r += 2) {
-            const int c0 = rb + (r * SP_NW + w) * 64, c1 = c0 + SP_NW * 64;
-            if (c0 >= c_hi) break;
-            const bool two = r + 1 < round_passes && c1 < c_hi;
-            const float4* bp0 = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
-            const float4* bp1 = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(two && c1 + lane < c_hi ? c1 + lane : c_lo) * 8);
-            const float4 a0 = bp0[0], a1 = bp0[1], d0 = bp1[0], d1 = bp1[1];
-            find_pass(c0, a0, a1, B);
-            if (two) find_pass(c1, d0, d1, B);
-        }
+        find_round(rb, B, glo, ghi);
         __syncthreads();
         process_hits(*hcount);
         if (rb + round_chunks < c_hi) exchange();
     }
+    }
+    spec_valid = false;
     }
     ICP_PHASE(3)
     if constexpr (DIAG) {
@@ -1612,6 +1664,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             if (w == 0) atomicAdd(&fuse.work[NN_WORK_BLOCK_PASSES], 1ull);
             if (w == 0 && apply) atomicAdd(&fuse.work[NN_WORK_BLOCK_TRANSFORMS], 1ull);
         }
+        wk_find = wk_upper = wk_samp = 0; wk_hit[0] = wk_hit[1] = wk_hit[2] = 0;
     }
 
     // in-block merge: every wave that lowered its bound folds its candidate into the point's key
@@ -1628,10 +1681,8 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     ICP_PHASE(5)
     // wave 0 finishes the row: it holds both of every lane's points in registers
     if (w != 0) {
-        if (!fuse.resident) return;
-        continue;  // resident: on to the next message (asleep at its barrier while wave 0 works)
-    }
-
+        if (!fuse.resident) return;   // (resident: on to the speculative search below, then the next message)
+    } else {
     float fb[2];
     int fj[2];
 #pragma unroll
@@ -1659,7 +1710,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const unsigned long long key = ((unsigned long long)__float_as_uint(fb[t]) << 32) | (unsigned int)fj[t];
-                __hip_atomic_fetch_min(&tail.keys[(size_t)blockIdx.x * 128 + lane + t * 64], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_min(&tail.keys[fresh((int)blockIdx.x * 128 + lane) + t * 64], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (fresh: no address held across the pass loop)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ICP_PHASE(6)
@@ -1670,7 +1721,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             if (ticket != gridDim.y - 1) return;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int i = ibase + t * 64;  // keys live per slot
+                const int i = fresh(ibase) + t * 64;  // keys live per slot
                 const unsigned long long key = __hip_atomic_load(&tail.keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 tail.keys[i] = ~0ull;  // ready for the next launch (nobody touches this row again in this one)
                 fj[t] = (int)(unsigned int)(key & 0xffffffffull);
@@ -1700,6 +1751,60 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         for (int t = 0; t < 2; ++t) {
             sok[t] = real[t];
             seedq[0][lane + t * 64] = sq[t][0]; seedq[1][lane + t * 64] = sq[t][1]; seedq[2][lane + t * 64] = sq[t][2];
+        }
+    }
+    }  // (wave 0)
+
+    // ---- resident launch: the wait for the next message is put to use -----------------------------------------------------
+    // The rows are on their way to the host, which will add them up, solve and answer: 3-4 us during which the block
+    // used to sleep, after which it searched the chunk boxes (find), fetched the hit chunks (one trip to memory) and only
+    // then got to the arithmetic.  Instead the block now GUESSES where the next transform will put its points -- the group
+    // box of this pass widened by twice the displacement this pass's transform caused (plus a thousandth of the box), and
+    // a bound that grows with it by the triangle inequality -- and runs the find and the fetch for that guess right away.
+    // When the message arrives the real group box and bound are compared with the guess (seven comparisons); if they are
+    // covered, the list is a superset of the real one (see where it is used) and the pass goes straight to the exact
+    // per-point tests on chunks that already sit in LDS.  If not -- or if the list outgrew one batch -- the pass searches
+    // as before; nothing but idle time was spent.
+    if constexpr (!HIER) {
+        if (threadIdx.x == 0) *hcount = 0;   // (this pass's list is consumed; ordered before its next use by the barriers below / the message barrier)
+        const bool single_round = c_hi - c_lo <= round_chunks;
+        if (fuse.speculate && single_round && apply && B0_pass >= 0.f && B0_pass < inf_<float>()) {
+            // displacement of the block's points under this pass's transform, per axis, bounded over their (new) group box:
+            // p_old = R^T (p_new - t)  =>  p_new - p_old = (I - R^T) p_new + R^T t
+            float dl[3], dn2 = 0.f, sp_lo[3], sp_hi[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float acc = 0.f, rt_t = 0.f;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float m = (a == b ? 1.f : 0.f) - rt.r[b * 3 + a];           // (I - R^T)_ab
+                    acc += __builtin_fabsf(m) * __builtin_fmaxf(__builtin_fabsf(glo[b]), __builtin_fabsf(ghi[b]));
+                    rt_t += rt.r[b * 3 + a] * rt.t[b];                                // (R^T t)_a
+                }
+                dl[a] = 2.f * (acc + __builtin_fabsf(rt_t)) + 1e-3f * (ghi[a] - glo[a]) + 1e-6f;
+                dn2 += dl[a] * dl[a];
+                sp_lo[a] = glo[a] - dl[a];
+                sp_hi[a] = ghi[a] + dl[a];
+            }
+            // every point's next starting bound is its distance to this pass's match after the move:
+            // sqrt(d_new) <= sqrt(d_old) + |displacement|, and d_old < this pass's largest starting bound
+            const float rB = __builtin_sqrtf(B0_pass) + __builtin_sqrtf(dn2);
+            const float sp_B = rB * rB * 1.0001f;
+            if (lane == 0) {
+                *reinterpret_cast<float4*>(spst) = float4{sp_lo[0], sp_lo[1], sp_lo[2], sp_B};
+                *reinterpret_cast<float4*>(spst + 4) = float4{sp_hi[0], sp_hi[1], sp_hi[2], 0.f};
+            }
+            __syncthreads();   // wave 0 is through with the row (its transpose buffer overlays the hit list); the counter is reset
+            find_round(c_lo, sp_B, sp_lo, sp_hi);
+            __syncthreads();
+            const int spec_n = *hcount;
+            if (spec_n <= SP_NW * 8) {
+                gather_batch(0, spec_n);
+                spec_valid = true;
+            } else {
+                __syncthreads();   // (everybody has read the count)
+                if (threadIdx.x == 0) *hcount = 0;
+            }
         }
     }
     }  // pass loop
@@ -2780,6 +2885,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             fuse.slot_state = (pl.sparse && pl.splits == 1 && !ft->resident) ? (float*)ft->slot_state : nullptr;
             fuse.slot_valid = (fuse.slot_state && ft->slot_valid) ? 1 : 0;
             fuse.resident = ft->resident ? 1 : 0;
+            static const int env_spec = env_int("ICP_NN_SPECULATE", 1);   // (A/B runs: 0 switches the speculative search of resident launches off)
+            fuse.speculate = (ft->resident && env_spec) ? 1 : 0;
             fuse.store_first = ft->store_first ? 1 : 0;
         } else {
             for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
