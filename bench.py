@@ -57,17 +57,18 @@ PTS_PER_HIT = 128          # one hit = one wave (64 lanes x 2 moving points) aga
 WAVES_PER_BLOCK = 16
 
 
-def executed_flop(work):
+def executed_flop(work, pts_per_hit=PTS_PER_HIT, waves_per_block=WAVES_PER_BLOCK):
     """fp32 flop the sparse kernel EXECUTED, from its work counters (the fp64 moment sums of the row tail -- ~45 flop per
-    point and pass -- are left out: another unit, <2 % of the total)"""
+    point and pass -- are left out: another unit, <2 % of the total).  pts_per_hit: the moving points one wave holds
+    (128 with rows of 128 points, 64 with rows of 64); waves_per_block: every wave re-derives the block's points"""
     parts = {
         "find (group box vs chunk boxes)": (work["find_boxes"] + work["upper_boxes"]) * FLOP_BOX,
-        "per-point box tests": work["hits_box"] * PTS_PER_HIT * FLOP_BOX,
-        "xy halves": work["hits_xy"] * PTS_PER_HIT * 8 * FLOP_XY,
-        "z halves": work["hits_full"] * PTS_PER_HIT * 8 * FLOP_Z,
-        "cold-start samples": work["sample_groups"] * PTS_PER_HIT * 8 * FLOP_PAIR,
-        "seed distances": work["block_passes"] * WAVES_PER_BLOCK * PTS_PER_HIT * FLOP_PAIR,
-        "transforms": work["block_transforms"] * WAVES_PER_BLOCK * PTS_PER_HIT * FLOP_RT,
+        "per-point box tests": work["hits_box"] * pts_per_hit * FLOP_BOX,
+        "xy halves": work["hits_xy"] * pts_per_hit * 8 * FLOP_XY,
+        "z halves": work["hits_full"] * pts_per_hit * 8 * FLOP_Z,
+        "cold-start samples": work["sample_groups"] * pts_per_hit * 8 * FLOP_PAIR,
+        "seed distances": work["block_passes"] * waves_per_block * pts_per_hit * FLOP_PAIR,
+        "transforms": work["block_transforms"] * waves_per_block * pts_per_hit * FLOP_RT,
     }
     return float(sum(parts.values())), {k: float(v) for k, v in parts.items()}
 
@@ -320,9 +321,11 @@ def run_hall(args, rank, local_rank, world):
         ctx.set_work_counting(False)
         blocks = info["blocks"]
         passes_counted = work["block_passes"] / max(1, blocks)
-        flop_reg, flop_parts = executed_flop(work)
+        row64 = info["threads"] == 512          # rows of 64 points: 8 waves per block, one point per lane
+        pts_hit, nwaves = (64, 8) if row64 else (128, 16)
+        flop_reg, flop_parts = executed_flop(work, pts_hit, nwaves)
         flop_launch = flop_reg * (ppl / max(1.0, passes_counted))      # scaled to the passes an average timed launch ran
-        pairs_full = work["hits_full"] * PTS_PER_HIT * 8
+        pairs_full = work["hits_full"] * pts_hit * 8
         # (3) the stand-alone matching kernel by the reference's method: min (and mean) of 10 launches after 2 warm-ups
         seeded = ctx.nn_match_bench_launches(10, 2, 0)
         dense = ctx.nn_match_bench_launches(10, 2, 2)
@@ -335,14 +338,15 @@ def run_hall(args, rank, local_rank, world):
         pmc = os.path.join(ROOT, "profiles", "r2", "pmc_hbm_traffic_sparse.json")
         if world == 1 and os.path.exists(pmc):
             rec = json.load(open(pmc))
-            k = next((v for kk, v in rec.items() if "nn_match_sparse" in kk), None)
+            k = next((v for kk, v in rec.items() if "nn_match_" in kk), None)
             if k:
                 traffic = k["hbm_bytes_corrected"]
                 traffic_src = ("profiles/r2/pmc_hbm_traffic_sparse.json (%s): ONE stand-alone seeded pass, FETCH_SIZE %.0f B raw (x2: gfx950 "
                                "correction) + WRITE_SIZE %.0f B; a resident launch keeps its chunk boxes in registers, so its later passes "
                                "read less" % (rec.get("_build", "build unknown"), k["fetch_bytes_raw"], k["write_bytes"]))
         out["roofline"] = {
-            "kernel": "nn_match_sparse<1>, resident: ONE launch per REGISTRATION, every block on the machine (%.2f matching passes per "
+            "kernel": ("nn_match_row64<1> (rows of 64 points, 8 waves per block)" if row64 else "nn_match_sparse<1> (rows of 128 points, 16 waves per block)") +
+                      ", resident: ONE launch per REGISTRATION, every block on the machine (%.2f matching passes per "
                       "timed launch); every pass = mailbox message from the host (command, R, t) -> [transform + error of the previous "
                       "pass] -> lane-parallel chunk-box search -> hit processing (packed fp32, exact arithmetic) -> LDS key merge -> "
                       "moment row to the host.  The duration INCLUDES the host round trips between the passes." % ppl,
@@ -369,7 +373,7 @@ def run_hall(args, rank, local_rank, world):
                                  "note": "the arithmetic the answer stands for (8 flop x N x M per pass) over the measured time: a speed-up "
                                          "figure, not a roofline fraction",
                                  "speedup_vs_dense_kernel_per_pass": t_dense / (t_launch / ppl)},
-            "matching_only": {"what": "stand-alone seeded launches of nn_match_sparse<0> (no transform, no moment rows), events around "
+            "matching_only": {"what": "stand-alone seeded launches of the same kernel without its fused front end and tail (no transform, no moment rows), events around "
                                       "every launch, 2 warm-ups: the reference's method (src/CUDA/Matching_opt.cu:213-226)",
                               "min_launch_us": 1e3 * float(seeded.min()), "avg_launch_us": 1e3 * float(seeded.mean()), "launches": 10},
             "dense_kernel": {"what": "nn_match_f32_v2<2,8,0,0>: the LDS-tiled packed kernel that EXECUTES every pair (no boxes, no early-out) on "

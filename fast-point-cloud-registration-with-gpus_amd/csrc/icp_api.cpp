@@ -158,6 +158,7 @@ struct LoopState {
     bool host_reduce = false;  // how the pending enqueue's partial rows are being reduced
     bool matched = false;      // a matching pass of THIS loop has filled idx[cur]
     bool rows_have_err = false; // slot 0 of the pending moment rows carries the error shares (fused tail)
+    bool rows_compact = false;  // the pending rows are compact (NN_CROW doubles; slot 0 = error share with the tag in its low mantissa bits)
     double wait_tag = 0.0;      // completion tag of the pending enqueue's rows
     // armed launch: the matching pass AFTER the pending one is already enqueued and waits for its (R, t)
     bool armed = false;
@@ -165,6 +166,7 @@ struct LoopState {
     double armed_tag = 0.0;
     int armed_slot = 0;
     int armed_prev_cur = 0;
+    bool armed_compact = false;
     std::chrono::steady_clock::time_point armed_at{};   // when the armed pass was launched (mailbox lease)
     icp::NNMailbox* live_mailbox = nullptr;             // a resident kernel is running and listens here
 };
@@ -216,6 +218,7 @@ struct icp_ctx {
     DevBuf mom_partials, err_partials, mom_own, nbr;
     DevBuf keys, tickets;              // fused tail of the matching kernel: (d, idx) keys per moving point, row tickets
     size_t rows_cap = 0;               // rows available in mom_partials / h_mom_partials
+    int rows_format = -1;              // format of the rows last written to h_mom_partials: 1 compact, 0 full, -1 none yet
     bool fused_tail = true;            // ICP_FUSED_TAIL=0 keeps matching and moments as two kernels
     bool use_boxes = true;             // ICP_NN_BOXES=0 disables the bounding-box level of the early-out
     bool mail_wide = true;             // ICP_MAILBOX_AVX=0: write the mailbox line word by word (payload, fence, tags) -- the path of a CPU without AVX
@@ -298,6 +301,7 @@ int ensure_work_buffers(icp_ctx* c)
     c->plan = icp::nn_plan(c->n, c->m, c->prec, c->num_cus);
     const icp::NNPlan& pl = c->plan;
     if (before.n_pad != pl.n_pad || before.m_pad != pl.m_pad) c->resident_refused = false;  // another geometry: ask again
+    if (before.n_pad != pl.n_pad || before.blocks_x != pl.blocks_x) c->rows_format = -1;     // (rows that were not in use keep old tags: wiped before the next launch)
     const size_t es = icp::elem_size(c->prec);
     const size_t S = pl.splits > 0 ? (size_t)pl.splits : 1;
     HIP_TRY(c->part_d.ensure(S * (size_t)pl.n_pad * es));
@@ -312,6 +316,7 @@ int ensure_work_buffers(icp_ctx* c)
         HIP_TRY(hipHostMalloc((void**)&c->h_mom_partials, rows * ICP_NMOM * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(c->h_mom_partials, 0, rows * ICP_NMOM * sizeof(double));
         c->rows_cap = rows;
+        c->rows_format = -1;
     }
     HIP_TRY(c->mom_partials.ensure(rows * ICP_NMOM * sizeof(double)));
     if (icp::nn_can_fuse_tail(pl)) {
@@ -836,8 +841,11 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
         icp::PrepBuffers pb{};
         if (int rc = prep_buffers(c, n, pb)) return rc;
         icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
-        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->P.p, n, n_pad, 128, 0, (int32_t*)c->prep_perm.p, small->totals, c->stream));
-        if (int rc = morton_decision(c, n, 128, 0, &c->moving_sorted, nullptr)) return rc;
+        // (judged on the groups the matching kernel will work on: rows of 64 points for a cloud that cannot fill the machine
+        // with rows of 128 -- icp_kernels.hip, nn_plan)
+        const int grp = (n_pad / 128 <= c->num_cus) ? 64 : 128;
+        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->P.p, n, n_pad, grp, 0, (int32_t*)c->prep_perm.p, small->totals, c->stream));
+        if (int rc = morton_decision(c, n, grp, 0, &c->moving_sorted, nullptr)) return rc;
         if (c->moving_sorted) {
             HIP_TRY(c->Pperm.ensure((size_t)n_pad * sizeof(int32_t)));
             HIP_TRY(icp::launch_slot_map((const int32_t*)c->prep_perm.p, n, n_pad, (int32_t*)c->Pperm.p, c->stream));
@@ -867,6 +875,38 @@ int icp_set_model_normals(icp_ctx* c, const void* nxyz, int m)
     if (int rc = upload_cloud(c, nxyz, m, icp::pad_model(m), c->prec, c->Nrm)) return rc;
     c->have_normals = true;
     return ICP_OK;
+}
+
+// rows the host itself adds up (single GPU, or ranks meeting in host memory) leave the sparse point-to-point kernels in
+// the compact two-cache-line form (icp_kernels.h, NNTailArgs)
+static bool use_compact_rows(const icp_ctx* c, const icp::NNPlan& pl, int metric, const double* rows)
+{
+    static const bool off = std::getenv("ICP_COMPACT_ROWS") && std::getenv("ICP_COMPACT_ROWS")[0] == '0';   // (A/B runs)
+    return !off && pl.sparse && metric == ICP_POINT_TO_POINT && rows == c->h_mom_partials;
+}
+
+// Completion tags are consecutive integers.  A compact row shows only the low NN_CROW_TAG_BITS bits of its tag, and a
+// wiped row shows zero: no tag that is ever waited for may have those bits all zero.  Returns the first of `count`
+// consecutive tags that are safe in that sense and reserves them.
+static uint64_t take_tags(icp_ctx* c, uint64_t count)
+{
+    constexpr uint64_t kMod = 1ull << icp::NN_CROW_TAG_BITS;
+    uint64_t first = c->tag_seq + 1;
+    if (first % kMod == 0 || first / kMod != (first + count - 1) / kMod) first = (first / kMod + 1) * kMod + 1;   // (count << kMod)
+    c->tag_seq = first + count - 1;
+    return first;
+}
+
+// The two row formats keep their completion tags in different places of the same pinned buffer: when the format changes
+// (another metric, a communicator attached or removed -- never inside a loop) the buffer is wiped, so that no sum left by
+// the other format can ever be mistaken for a tag.
+static void prepare_rows_format(icp_ctx* c, bool compact)
+{
+    const int want = compact ? 1 : 0;
+    if (c->rows_format == want || !c->h_mom_partials) { c->rows_format = want; return; }
+    std::memset(c->h_mom_partials, 0, c->rows_cap * ICP_NMOM * sizeof(double));
+    bar_fence();
+    c->rows_format = want;
 }
 
 static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
@@ -1118,6 +1158,7 @@ int icp_loop_enqueue(icp_ctx* c)
     L.err_blocks = 0;
     L.mom_blocks = 0;
     L.rows_have_err = false;
+    L.rows_compact = false;
     const bool host_reduce = c->host_reduce();
     double* mom_rows = host_reduce ? c->h_mom_partials : (double*)c->mom_partials.p;
     double* err_rows = (double*)c->err_partials.p;  // device: the moments kernel folds them into its rows
@@ -1156,8 +1197,11 @@ int icp_loop_enqueue(icp_ctx* c)
             ta.idx_out = (int32_t*)c->idx[c->cur].p;
             ta.Nrm_soa = c->Nrm.p;
             ta.rows = mom_rows;
-            ta.tag = (double)(++c->tag_seq);
+            ta.tag = (double)take_tags(c, 1);
+            ta.compact = use_compact_rows(c, pl, ta.metric, mom_rows) ? 1 : 0;
         }
+        L.rows_compact = tail && ta.compact != 0;
+        if (tail && host_reduce) prepare_rows_format(c, L.rows_compact);
         if (fused) {
             icp::NNFusedTransform ft{L.H.R, L.H.t, (const int32_t*)c->idx[L.applied_idx].p, c->P2.p, err_rows};
             HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, tail ? &ta : nullptr, c->stream));
@@ -1174,7 +1218,7 @@ int icp_loop_enqueue(icp_ctx* c)
         } else {
             HIP_TRY(icp::launch_moments(pl, L.H.prm.metric, c->P.p, c->Q.p, c->Nrm.p, c->part_d.p,
                                         (const int32_t*)c->part_idx.p, (int32_t*)c->idx[c->cur].p, mom_rows,
-                                        &L.mom_blocks, (double)(++c->tag_seq), err_rows, L.err_blocks, c->stream));
+                                        &L.mom_blocks, (double)take_tags(c, 1), err_rows, L.err_blocks, c->stream));
             if (host_reduce) L.err_blocks = 0;  // already inside the moment rows
         }
     }
@@ -1224,24 +1268,48 @@ int icp_loop_complete(icp_ctx* c, int* done)
         // kernel started.  Fixed block order => the same bits every run.
         // Rows are summed in block order AS their tags arrive, so the reduction overlaps the kernel's last blocks.
         double* mom = c->h_mom;
+        const bool compact = L.rows_compact;
+        const size_t stride = compact ? (size_t)icp::NN_CROW : (size_t)ICP_NMOM, tag_slot = compact ? 0 : ICP_NMOM - 1;
+        constexpr unsigned long long kTagMask = (1ull << icp::NN_CROW_TAG_BITS) - 1ull;
+        // the tag a row carries now: a double of its own (full rows), or the low mantissa bits of slot 0 (compact rows)
+        auto row_tag = [&](int b) -> double {
+            const volatile double* p = c->h_mom_partials + (size_t)b * stride + tag_slot;
+            if (!compact) return *p;
+            unsigned long long bits;
+            const double v = *p;
+            std::memcpy(&bits, &v, sizeof bits);
+            return (double)(bits & kTagMask);
+        };
+        auto tag_value = [&](double tag) { return compact ? (double)((unsigned long long)tag & kTagMask) : tag; };
         auto start_sum = [&]() {
             for (int k = 0; k < ICP_NMOM; ++k) mom[k] = 0.0;
             for (int b = 0; b < L.err_blocks; ++b) mom[ICP_MOM_ERR] += c->h_err_partials[b];
+            // (a compact row does not carry its point count: a row of the sparse kernels holds the real points of its slots)
+            if (compact) mom[ICP_MOM_CNT] = (double)c->n;
         };
         auto add_row = [&](int b) {
-            const double* row = c->h_mom_partials + (size_t)b * ICP_NMOM;
-            for (int k = 0; k < ICP_NMOM - 1; ++k) mom[k] += row[k];  // the last slot is the completion tag
+            const double* row = c->h_mom_partials + (size_t)b * stride;
+            if (compact) {   // {error share + tag, sum p, sum q, sum q p^T} -> slots ICP_MOM_SP .. ICP_MOM_SQP + 8, ICP_MOM_ERR
+                for (int k = 1; k < icp::NN_CROW; ++k) mom[ICP_MOM_SP - 1 + k] += row[k];
+                unsigned long long bits;
+                std::memcpy(&bits, &row[0], sizeof bits);
+                bits &= ~kTagMask;
+                double e;
+                std::memcpy(&e, &bits, sizeof e);
+                mom[ICP_MOM_ERR] += e;
+            } else {
+                for (int k = 0; k < ICP_NMOM - 1; ++k) mom[k] += row[k];  // the last slot is the completion tag
+            }
         };
         bool polled = false;
         if (L.mom_blocks > 0 && !L.timed_nn && c->poll && L.err_blocks == 0) {
-            const double want = L.wait_tag;
+            const double want = tag_value(L.wait_tag);
             const auto t0 = std::chrono::steady_clock::now();
             int b = 0;
             unsigned spins = 0;
             start_sum();
             while (b < L.mom_blocks) {
-                const volatile double* tagp = c->h_mom_partials + (size_t)b * ICP_NMOM + (ICP_NMOM - 1);
-                if (*tagp == want) {
+                if (row_tag(b) == want) {
                     std::atomic_thread_fence(std::memory_order_acquire);
                     if (c->trace_passes && b == 0) c->tr_first_row = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     add_row(b++);
@@ -1258,7 +1326,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
                 std::fprintf(stderr, "[icp trace]   poll gave up at row %d; rows still missing:", b);
                 int shown = 0;
                 for (int r = 0; r < L.mom_blocks && shown < 40; ++r)
-                    if (c->h_mom_partials[(size_t)r * ICP_NMOM + (ICP_NMOM - 1)] != want) { std::fprintf(stderr, " %d", r); ++shown; }
+                    if (row_tag(r) != want) { std::fprintf(stderr, " %d", r); ++shown; }
                 std::fprintf(stderr, "\n");
             }
         }
@@ -1269,13 +1337,13 @@ int icp_loop_complete(icp_ctx* c, int* done)
             HIP_TRY(hipStreamSynchronize(c->stream));
             tr1 = std::chrono::steady_clock::now();
             for (int b = 0; b < L.mom_blocks; ++b)
-                if (c->h_mom_partials[(size_t)b * ICP_NMOM + (ICP_NMOM - 1)] != L.wait_tag) {
+                if (row_tag(b) != tag_value(L.wait_tag)) {
                     L.pending = false;
                     char msg[240];
                     int have = 0;
-                    for (int r = 0; r < L.mom_blocks; ++r) have += c->h_mom_partials[(size_t)r * ICP_NMOM + (ICP_NMOM - 1)] == L.wait_tag ? 1 : 0;
+                    for (int r = 0; r < L.mom_blocks; ++r) have += row_tag(r) == tag_value(L.wait_tag) ? 1 : 0;
                     std::snprintf(msg, sizeof msg, "a matching pass ended without producing its rows: row %d of %d carries tag %.0f, expected %.0f; %d rows arrived (armed / resident launch timed out?)",
-                                  b, L.mom_blocks, c->h_mom_partials[(size_t)b * ICP_NMOM + (ICP_NMOM - 1)], L.wait_tag, have);
+                                  b, L.mom_blocks, row_tag(b), tag_value(L.wait_tag), have);
                     return fail(ICP_ERR_HIP, msg);
                 }
             start_sum();
@@ -1347,7 +1415,7 @@ int loop_arm(icp_ctx* c)
     const int prev_cur = c->cur;
     const int slot = (int)(c->mail_seq++ % kMailSlots);
     icp::NNMailbox* mb = c->h_mail + slot;
-    const double tag = (double)(++c->tag_seq);
+    const double tag = (double)take_tags(c, 1);
     post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, 0.0);   // cleared: nothing to act on yet
     icp::NNTailArgs ta{};
     ta.metric = L.H.prm.metric;
@@ -1358,6 +1426,9 @@ int loop_arm(icp_ctx* c)
     ta.Nrm_soa = c->Nrm.p;
     ta.rows = c->h_mom_partials;
     ta.tag = tag;
+    ta.compact = use_compact_rows(c, pl, ta.metric, ta.rows) ? 1 : 0;
+    L.armed_compact = ta.compact != 0;
+    prepare_rows_format(c, L.armed_compact);
     icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[prev_cur].p, c->P2.p, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, tag};
     // every armed pass leaves its points and matches in slot order; the next one starts from them (one level of
     // coalesced loads instead of slot -> point -> seed -> model point) if the pass before it was such a pass
@@ -1388,6 +1459,7 @@ void loop_release_armed(icp_ctx* c)
     L.mom_blocks = c->plan.blocks_x;
     L.err_blocks = 0;
     L.rows_have_err = true;
+    L.rows_compact = L.armed_compact;
     L.host_reduce = true;
     L.timed_nn = false;
     L.wait_tag = L.armed_tag;
@@ -1437,8 +1509,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
         if (v[0] == '2') { mailbox_selftest(c, 0, "loop"); mailbox_selftest(c, 1, "loop"); }
     icp::NNMailbox* mb = c->h_mail + (int)(c->mail_seq++ % kMailSlots);
     const int pass_cap = L.H.prm.max_iter + 2;
-    const double base = (double)(c->tag_seq + 1);
-    c->tag_seq += (uint64_t)pass_cap + 1;
+    const double base = (double)take_tags(c, (uint64_t)pass_cap + 1);
     post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, 0.0);   // cleared
     const int c0 = c->cur;
     const icp::NNCullInputs cull = make_cull(c, L.matched ? (const int32_t*)c->idx[c0].p : nullptr);
@@ -1452,6 +1523,8 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     ta.Nrm_soa = c->Nrm.p;
     ta.rows = c->h_mom_partials;
     ta.tag = 0.0;
+    ta.compact = use_compact_rows(c, rp, ta.metric, ta.rows) ? 1 : 0;
+    prepare_rows_format(c, ta.compact != 0);
     icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[c0].p, c->P.p /* in place */, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, base, true};
     // icp_set_profiling(n): every n-th resident kernel is bracketed by events (read after it has ended)
     const bool time_this = c->profile_stride > 0 && (c->resident_launch_count++ % (uint64_t)c->profile_stride) == 0;
@@ -1509,6 +1582,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
         L.mom_blocks = rp.blocks_x;
         L.err_blocks = 0;
         L.rows_have_err = true;
+        L.rows_compact = ta.compact != 0;
         L.host_reduce = true;
         L.timed_nn = false;
         L.wait_tag = base + (double)sent;

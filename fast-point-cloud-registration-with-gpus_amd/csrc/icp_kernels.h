@@ -30,6 +30,7 @@ struct NNPlan {
     int cull;           // the packed kernel may use the seeded-bound / xy early-out variant
     int sparse;         // the geometry is the sparse kernel's (16-wave blocks of 128 moving points; needs chunk boxes)
     int hier;           // sparse kernel: two-level search (boxes of 64 chunks first) -- large models
+    int row;            // sparse geometry: moving points per block row -- 128 (nn_match_sparse, 16 waves) or 64 (nn_match_row64, 8 waves)
 };
 int nn_block_threads(const NNPlan& pl);
 
@@ -121,7 +122,11 @@ enum {
     NN_WORK_SAMPLE_GROUPS = 5,    // cold start: groups of 8 samples scanned by a wave (128 x 8 x 8 flop)
     NN_WORK_BLOCK_PASSES = 6,     // (block, pass) pairs, for normalisation
     NN_WORK_BLOCK_TRANSFORMS = 7, // ... of which applied a transform first (16 waves x 128 points x 15 flop, redundantly)
-    NN_WORK_SLOTS = 8
+    NN_WORK_SPEC_LISTS = 8,       // resident launches: (block, pass) pairs that entered a pass with a speculative hit list
+    NN_WORK_SPEC_COVERED = 9,     // ... whose list covered the real group box and bound (the pass skipped find + fetch)
+    NN_WORK_SPEC_HITS = 10,       // hits on the speculative lists that were used
+    NN_WORK_LIST_HITS = 11,       // hits on the lists built by the ordinary find
+    NN_WORK_SLOTS = 12
 };
 // device-side preparation of the sparse kernel's views (icp_set_model / icp_set_moving): scratch owned by the caller
 struct PrepBuffers {
@@ -163,7 +168,12 @@ struct NNTailArgs {
     const void* Nrm_soa;        // normals (plane)
     double* rows;               // [blocks_x][ICP_NMOM], pinned host or device
     double tag;
+    // sparse kernels, point-to-point, rows read by the host: rows of NN_CROW doubles {error share + tag, sum p, sum q,
+    // sum q p^T} -- see NNTail in icp_kernels.hip
+    int compact = 0;
 };
+constexpr int NN_CROW = 16;            // doubles per compact row
+constexpr int NN_CROW_TAG_BITS = 16;   // low mantissa bits of slot 0 that carry the row's tag (mod 2^16)
 bool nn_can_fuse_tail(const NNPlan& pl);
 
 // matching: per (segment, point) partial minimum + index.  `ft` (optional) = fused transform,

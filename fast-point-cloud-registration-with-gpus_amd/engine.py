@@ -172,13 +172,14 @@ class Context:
         capi.check(self._lib.icp_nn_launch_info_ex(self._h, 1 if dense else 0, *[C.byref(x) for x in v]), "icp_nn_launch_info_ex")
         return dict(zip(("splits", "blocks", "threads", "n_pad", "m_pad"), (x.value for x in v)))
 
-    WORK_SLOTS = ("find_boxes", "upper_boxes", "hits_box", "hits_xy", "hits_full", "sample_groups", "block_passes", "block_transforms")
+    WORK_SLOTS = ("find_boxes", "upper_boxes", "hits_box", "hits_xy", "hits_full", "sample_groups", "block_passes", "block_transforms",
+                  "spec_lists", "spec_covered", "spec_hits", "list_hits")
 
     def set_work_counting(self, enable=True):
         capi.check(self._lib.icp_set_work_counting(self._h, 1 if enable else 0), "icp_set_work_counting")
 
     def get_work_counters(self, reset=True):
-        out = np.zeros(8, dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
         capi.check(self._lib.icp_get_work_counters(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if reset else 0),
                    "icp_get_work_counters")
         return dict(zip(self.WORK_SLOTS, (int(x) for x in out)))

@@ -145,7 +145,7 @@ int icp_nn_launch_info_ex(icp_ctx* ctx, int dense, int* splits, int* blocks, int
  *   4 ... evaluated in full (each hit: 64 lanes x 2 moving points x 8 model points)
  *   5 cold-start sample groups scanned (128 x 8 pairs each)   6 (block, pass) pairs   7 ... that applied a transform
  * Timing with counting on is not representative (atomics, extra registers): count in a separate run. */
-#define ICP_WORK_SLOTS 8
+#define ICP_WORK_SLOTS 12 /* 8..11: speculative lists entered / that covered the pass / their hits / hits of ordinarily built lists */
 int icp_set_work_counting(icp_ctx* ctx, int enable);
 int icp_get_work_counters(icp_ctx* ctx, uint64_t* out_slots, int reset);
 

@@ -405,6 +405,7 @@ def test_fused_and_two_kernel_forms_agree(pkg, orc, golden, tail):
 # ---------------------------------------------------------------------------------------------------
 LOOP_FORMS = {
     "resident": {},
+    "resident_no_speculation": {"ICP_NN_SPECULATE": "0"},   # (cached per process: effective only in a run that starts with it)
     "resident_host_mailbox": {"ICP_MAILBOX": "host"},
     "resident_plain_stores": {"ICP_MAILBOX_AVX": "0"},   # the mailbox line written word by word (a CPU without AVX)
     "armed": {"ICP_RESIDENT": "0"},
@@ -413,7 +414,7 @@ LOOP_FORMS = {
 
 
 def _run_form(pkg, monkeypatch, env, fn):
-    for k in ("ICP_MAILBOX", "ICP_MAILBOX_AVX", "ICP_RESIDENT", "ICP_ARMED"):
+    for k in ("ICP_MAILBOX", "ICP_MAILBOX_AVX", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_SPECULATE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)           # read by icp_create
@@ -421,11 +422,13 @@ def _run_form(pkg, monkeypatch, env, fn):
         return fn(c)
 
 
+@pytest.mark.parametrize("row", ["64", "128"])
 @pytest.mark.parametrize("metric", ["point_to_point", "point_to_plane"])
-def test_loop_forms_are_bit_identical(pkg, orc, golden, monkeypatch, metric):
+def test_loop_forms_are_bit_identical(pkg, orc, golden, monkeypatch, metric, row):
     """icp_loop_run keeps one resident kernel for the registration (mailbox in BAR-visible device memory, or in
     pinned host memory relayed by block 0), or arms the next pass ahead of its (R, t), or launches pass by pass:
     same rows, same host half -> the same bits, and the oracle's run."""
+    monkeypatch.setenv("ICP_NN_ROW", row)     # rows of 64 points (nn_match_row64, the default here) / of 128 (nn_match_sparse)
     P, Q = orc.hall_clouds(golden)
     if metric == "point_to_point":
         fn = lambda c: c.point_to_point(P, Q, max_iter=100, tol=1e-6)
@@ -570,13 +573,19 @@ def _fuzz_cloud(rng, n, kind, scale):
     return (scale * X).astype(np.float32)
 
 
-@pytest.mark.parametrize("sort,hier", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
-def test_matching_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier):
+# (sort, hier, row): Morton views forbidden / forced; flat search with 64-point rows (nn_match_row64) and with 128-point rows
+# (nn_match_sparse), and the box hierarchy (128-point rows only)
+FUZZ_VARIANTS = [("0", "0", "64"), ("1", "0", "64"), ("0", "0", "128"), ("1", "0", "128"), ("0", "1", "128"), ("1", "1", "128")]
+
+
+@pytest.mark.parametrize("sort,hier,row", FUZZ_VARIANTS)
+def test_matching_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier, row):
     """randomised clouds (uniform / clustered with duplicates / integer lattice / collinear, three scales, ragged sizes)
     through the sparse kernel with its Morton views forbidden and forced, flat and through the box hierarchy of the
     large models (forced onto models of one or two super boxes): indices bit-exact against the CPU oracle"""
     monkeypatch.setenv("ICP_SORT", sort)
     monkeypatch.setenv("ICP_NN_HIER", hier)
+    monkeypatch.setenv("ICP_NN_ROW", row)
     rng = np.random.default_rng(20260210 + int(sort))
     with pkg.Context(0) as c:
         for case in range(int(os.environ.get("ICP_FUZZ_CASES", "40"))):     # (a longer soak: ICP_FUZZ_CASES=1000)
@@ -588,12 +597,13 @@ def test_matching_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier):
             assert np.array_equal(got, want), (case, n, m, kp, km, scale, int(np.flatnonzero(got != want)[0]))
 
 
-@pytest.mark.parametrize("sort,hier", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
-def test_registration_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier):
+@pytest.mark.parametrize("sort,hier,row", FUZZ_VARIANTS)
+def test_registration_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier, row):
     """randomised registrations (seeded passes, resident kernel, clustered / lattice models with duplicates and ties),
     flat search and box hierarchy: error series, transform and final correspondences against the oracle's run"""
     monkeypatch.setenv("ICP_SORT", sort)
     monkeypatch.setenv("ICP_NN_HIER", hier)
+    monkeypatch.setenv("ICP_NN_ROW", row)
     rng = np.random.default_rng(7300 + int(sort))
     with pkg.Context(0) as c:
         for case in range(max(1, int(os.environ.get("ICP_FUZZ_CASES", "40")) // 5)):

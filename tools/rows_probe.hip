@@ -1,0 +1,98 @@
+// rows_probe.hip -- the communication floor of one resident pass: the host posts a 64-byte line (BAR-visible device
+// memory), N blocks poll it, each answers with one ROW of `slots` doubles + a tag into pinned coherent host memory
+// (system-scope stores, drained, then the tag -- the protocol of tail_close_row), the host adds the rows up in block
+// order as their tags appear.  No computation at all: what is measured is message flight + detection + row flight +
+// the host's ingest of N rows.  Variants: rows of 32 doubles with the tag in slot 31 (the full format), rows of 16
+// with the tag in slot 0 (the compact format), and 16 + a separate 8-byte error array.
+// build: hipcc --offload-arch=gfx950 -O2 -mavx -o bin/rows_probe tools/rows_probe.hip
+#include <hip/hip_runtime.h>
+#include <immintrin.h>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s -> %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ void answer(const unsigned int* mb, double* rows, double* errs, int stride, int tag_slot, int nslots, int use_err, int rounds)
+{
+    const int lane = threadIdx.x;
+    double* row = rows + (size_t)blockIdx.x * stride;
+    for (int i = 1; i <= rounds; ++i) {
+        unsigned int word = 0;
+        const long long give_up = (long long)wall_clock64() + 200000000ll;
+        for (unsigned int spins = 1;; ++spins) {
+            word = __hip_atomic_load(mb + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned int)__builtin_amdgcn_readlane((int)word, 7) == (unsigned int)i && (unsigned int)__builtin_amdgcn_readlane((int)word, 14) == (unsigned int)i) break;
+            if ((spins & 63u) == 0u && (long long)wall_clock64() > give_up) return;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (lane < nslots && lane != tag_slot) __hip_atomic_store(&row[lane], (double)(blockIdx.x + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (use_err && lane == 0) __hip_atomic_store(&errs[blockIdx.x], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&row[tag_slot], (double)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__attribute__((target("avx"))) static void post(unsigned int* mb, unsigned int tag)
+{
+    alignas(32) unsigned int line[16] = {0};
+    line[7] = tag; line[14] = tag;
+    _mm256_store_si256((__m256i*)mb, _mm256_load_si256((const __m256i*)line));
+    _mm256_store_si256((__m256i*)(mb + 8), _mm256_load_si256((const __m256i*)(line + 8)));
+    _mm_sfence();
+}
+
+static int run(unsigned int* mb, int blocks, int stride, int tag_slot, int nslots, int use_err, const char* name)
+{
+    const int rounds = 3000;
+    double *rows = nullptr, *errs = nullptr;
+    CK(hipHostMalloc((void**)&rows, (size_t)blocks * stride * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    CK(hipHostMalloc((void**)&errs, (size_t)blocks * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(rows, 0, (size_t)blocks * stride * sizeof(double));
+    std::memset(errs, 0, (size_t)blocks * sizeof(double));
+    std::memset(mb, 0, 64); _mm_sfence();
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipLaunchKernelGGL(answer, dim3(blocks), dim3(64), 0, st, mb, rows, errs, stride, tag_slot, nslots, use_err, rounds);
+    CK(hipGetLastError());
+    std::vector<double> rt, first, ingest;
+    double sink = 0;
+    for (int i = 1; i <= rounds; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        post(mb, (unsigned int)i);
+        double mom[32] = {0};
+        double t_first = 0;
+        for (int b = 0; b < blocks; ++b) {
+            const volatile double* tg = rows + (size_t)b * stride + tag_slot;
+            while (*tg != (double)i)
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) { std::printf("%s: timeout round %d row %d\n", name, i, b); return 1; }
+            if (b == 0) t_first = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double* row = rows + (size_t)b * stride;
+            for (int k = 0; k < nslots; ++k) if (k != tag_slot) mom[k] += row[k];
+            if (use_err) mom[31] += errs[b];
+        }
+        const double t1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        sink += mom[1] + mom[31];
+        if (i > rounds / 3) { rt.push_back(1e6 * t1); first.push_back(1e6 * t_first); }
+    }
+    CK(hipStreamSynchronize(st));
+    std::sort(rt.begin(), rt.end()); std::sort(first.begin(), first.end());
+    std::printf("%-46s blocks %4d: row 0 after %5.2f us, all rows added after %5.2f us (medians; p90 %5.2f)  [%g]\n", name, blocks, first[first.size() / 2],
+                rt[rt.size() / 2], rt[rt.size() * 9 / 10], sink > 0 ? 0.0 : 1.0);
+    CK(hipStreamDestroy(st)); CK(hipHostFree(rows)); CK(hipHostFree(errs));
+    return 0;
+}
+
+int main()
+{
+    unsigned int* mb = nullptr;
+    CK(hipExtMallocWithFlags((void**)&mb, 256, hipDeviceMallocFinegrained));
+    for (int blocks : {1, 32, 128, 256, 512}) {
+        run(mb, blocks, 32, 31, 19, 0, "rows of 32 doubles, 19 used, tag in slot 31");
+        run(mb, blocks, 16, 0, 16, 0, "rows of 16 doubles, tag in slot 0");
+        run(mb, blocks, 16, 0, 16, 1, "rows of 16 doubles + error array");
+        run(mb, blocks, 8, 0, 8, 0, "rows of 8 doubles, tag in slot 0");
+    }
+    return 0;
+}
