@@ -960,7 +960,9 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
 // px.y = point lane + 64) with their final correspondences j[]: stores idx, gathers q (and the normal),
 // accumulates in fp64, reduces through LDS in lane order and writes the row + completion tag.
 // (qio: the coordinates of the correspondences -- gathered here when `gather`, else supplied by the caller)
-template <int TAIL, bool phase_diag_, int NWP = SP_NW>
+// (ONE: only the lane's first point exists -- rows of 64 points; its contributions go straight to the transpose buffer
+// instead of through 18 register pairs)
+template <int TAIL, bool phase_diag_, int NWP = SP_NW, bool ONE = false>
 __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f2 pz, const int (&j)[2], int lane, const int (&pi)[2],
                                                int m_pad, const NNFuse& fuse, const NNTail& tail, double err_row,
                                                unsigned char* lds_raw, float (&qio)[2][3], bool gather, int phase_pass_ = 0)
@@ -971,7 +973,28 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
     // up in lane order
     double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
     const float* Qg = fuse.Q_gather;
-    if constexpr (TAIL == 1) {
+    if constexpr (TAIL == 1 && ONE) {
+        const int i = fresh(pi[0]);
+        const bool live = i < fuse.n;
+        double ppx = 0.0, ppy = 0.0, ppz = 0.0, qx = 0.0, qy = 0.0, qz = 0.0;
+        if (live) {
+            const int jj = j[0];
+            tail.idx_out[i] = jj;
+            ppx = (double)px.x; ppy = (double)py.x; ppz = (double)pz.x;
+            if (gather) { qio[0][0] = Qg[jj]; qio[0][1] = Qg[(size_t)m_pad + jj]; qio[0][2] = Qg[2 * (size_t)m_pad + jj]; }
+            qx = (double)qio[0][0]; qy = (double)qio[0][1]; qz = (double)qio[0][2];
+        }
+        // (0.0 + v: the value the two-point routine's accumulator holds after its one addition)
+        tr[0][lane] = 0.0 + (live ? 1.0 : 0.0);
+        tr[1][lane] = 0.0 + ppx; tr[2][lane] = 0.0 + ppy; tr[3][lane] = 0.0 + ppz;
+        tr[4][lane] = 0.0 + qx; tr[5][lane] = 0.0 + qy; tr[6][lane] = 0.0 + qz;
+        tr[7][lane] = 0.0 + qx * ppx; tr[8][lane] = 0.0 + qx * ppy; tr[9][lane] = 0.0 + qx * ppz;
+        tr[10][lane] = 0.0 + qy * ppx; tr[11][lane] = 0.0 + qy * ppy; tr[12][lane] = 0.0 + qy * ppz;
+        tr[13][lane] = 0.0 + qz * ppx; tr[14][lane] = 0.0 + qz * ppy; tr[15][lane] = 0.0 + qz * ppz;
+        tr[16][lane] = 0.0 + (ppx * ppx + ppy * ppy + ppz * ppz);
+        tr[17][lane] = 0.0 + (qx * qx + qy * qy + qz * qz);
+        ICP_PHASE(7)
+    } else if constexpr (TAIL == 1) {
         double acc[NACC];
 #pragma unroll
         for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
@@ -1941,6 +1964,10 @@ __device__ __forceinline__ void scan8_min1(const float4 qx0, const float4 qx1, c
     }
 }
 
+// (Two blocks fit a CU: 512 rows = 32 768 points can stay on the machine for a whole registration.  Tried: a third
+// instantiation squeezed to 80 VGPRs, three blocks per CU, so that Bunny.csv's 576 rows stay resident -- 47.3 us per
+// iteration against 45.7 us with rows of 128 and one armed launch per pass: that cloud's passes are decided by a few
+// hit-heavy blocks, which 8 waves work through more slowly than 16.  Not kept.)
 template <int TAIL, bool DIAG, bool PERM>
 __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64(const float* __restrict__ P, int n_pad, const float* __restrict__ Q,
                                                                  int m_pad, int round_passes, float* __restrict__ part_d,
@@ -2162,7 +2189,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64(const float* __
             if (lane == 0) base = atomicAdd(hcount, (int)__builtin_popcountll(mask));
             base = __builtin_amdgcn_readfirstlane(base);
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            if (pass_) hits[base + rank] = cidx;
+            if (pass_ && base + rank < SP_HCAP) hits[base + rank] = cidx;   // (a round never lists more; a speculative list that would is dropped)
         }
     };
     // one round of the find: every wave tests its share of the round's chunks (the boxes of two passes are requested
@@ -2300,6 +2327,11 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64(const float* __
             if (w == 0 && apply) atomicAdd(&fuse.work[NN_WORK_BLOCK_TRANSFORMS], 1ull);
         }
         wk_find = wk_samp = 0; wk_hit[0] = wk_hit[1] = wk_hit[2] = 0;
+        // (phase log) wave 1 leaves where the block runs: XCC_ID << 32 | HW_ID -- tools/cu_usage.py counts the CUs in use
+        if (fuse.tlog != nullptr && lane == 0 && w == 1 && (fuse.tlog_pass < 0 || fuse.tlog_pass == phase_pass_)) {
+            const long long slot_ = ((long long)blockIdx.x * phase_nw_ + w) * 10 + 8;
+            if (slot_ < fuse.tlog_cap) fuse.tlog[slot_] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+        }
     }
 
     // in-block merge: every wave that lowered its bound folds its candidate into the point's key (the 64-bit integer order
@@ -2337,8 +2369,8 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64(const float* __
             // the row's moments by the two-points-per-lane routine with its second point switched off (an index beyond n)
             const int j2[2] = {fj, 0}, pi2[2] = {pi, 0x7fffffff};
             float qio[2][3] = {{sq[0], sq[1], sq[2]}, {0.f, 0.f, 0.f}};
-            tail_close_row<TAIL, DIAG, NW>(f2{x, 0.f}, f2{y, 0.f}, f2{z, 0.f}, j2, lane, pi2, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, qio,
-                                           false, pass);
+            tail_close_row<TAIL, DIAG, NW, true>(f2{x, 0.f}, f2{y, 0.f}, f2{z, 0.f}, j2, lane, pi2, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, qio,
+                                                 false, pass);
             ICP_PHASE(9)
             if (!fuse.resident) return;
             // the matches of this pass seed the next one and are what its error is measured against
@@ -2350,7 +2382,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64(const float* __
     // ---- resident launch: the wait for the next message is put to use (see nn_match_sparse) -----------------------------
     if (threadIdx.x == 0) *hcount = 0;   // (this pass's list is consumed; ordered before its next use by the barriers below / the message barrier)
     const float B0 = wave_minmax<true>(best0);   // the largest starting bound of the block's points
-    if (fuse.speculate && c_hi - c_lo <= round_chunks && apply && B0 >= 0.f && B0 < inf_<float>()) {
+    if (fuse.speculate && apply && B0 >= 0.f && B0 < inf_<float>()) {
         if (searched) wave_box(glo, ghi);   // (a pass served by the speculative list has not derived its group box yet)
         // guess: the next transform moves the points no further than twice what this one did (per axis, bounded over the
         // group box: p_new - p_old = (I - R^T) p_new + R^T t), plus a thousandth of the box
@@ -2377,7 +2409,8 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64(const float* __
             *reinterpret_cast<float4*>(spst + 4) = float4{sp_hi[0], sp_hi[1], sp_hi[2], 0.f};
         }
         __syncthreads();   // wave 0 is through with the row (its transpose buffer overlays the hit list); the counter is reset
-        find_round(c_lo, sp_B, sp_lo, sp_hi);
+        // (one list over ALL rounds of the model: the bound does not change between them, and a list that does not fit one batch is dropped anyway)
+        for (int rb = c_lo; rb < c_hi; rb += round_chunks) find_round(rb, sp_B, sp_lo, sp_hi);
         __syncthreads();
         const int spec_n = *hcount;
         if (spec_n <= NW * 8) {
@@ -3354,7 +3387,8 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense)
                 const int env_hier0 = env_int("ICP_NN_HIER", -1);
                 const bool hier0 = env_hier0 >= 0 ? env_hier0 != 0 : pl.m_pad >= (1 << 17);
                 const int env_row = env_int("ICP_NN_ROW", 0);   // (not cached: the tests switch it between contexts)
-                const bool row64 = !hier0 && (env_row == 64 || (env_row != 128 && pl.n_pad / 128 <= num_cus));
+                // (two 8-wave blocks fit a CU: 512 rows of 64 = 32 768 points can stay on the machine for a whole registration)
+                const bool row64 = !hier0 && (env_row == 64 || (env_row != 128 && pl.n_pad / 64 <= 2 * num_cus));
                 if (row64) {
                     pl.row = 64;
                     pl.blocks_x = pl.n_pad / 64;

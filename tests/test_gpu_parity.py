@@ -469,14 +469,28 @@ def test_resident_kernel_resumes_and_fixed_iterations(pkg, orc, golden, monkeypa
 
 
 def test_moving_cloud_too_large_for_a_resident_kernel(ctx, pkg, orc):
-    """more than one block per CU cannot be resident together: the cooperative launch is refused once and the loop
-    runs pass by pass (armed) -- same answer"""
-    D = pkg.datasets.synthetic_grid(192, np.float32)              # 36 864 moving points = 288 blocks of 128
+    """36 864 moving points are 576 rows of 64 -- more than two blocks per CU hold -- so the plan falls back to rows of 128
+    (288 blocks: more than one per CU cannot be resident together either): the resident launch is refused once and the
+    loop runs pass by pass (armed) -- same answer"""
+    D = pkg.datasets.synthetic_grid(192, np.float32)
     M = pkg.datasets.make_model_gpu(D[:4096], *pkg.datasets.P2P_GPU)
     res = ctx.point_to_point(D, M, max_iter=4, tol=1e-6)
     want = orc.icp_p2p_f32x(D, M, 4, 1e-6)
     assert res.iterations == want["iterations"] and np.array_equal(res.idx, want["idx"])
     assert rel(res.T, want["T"]) < TOL_T
+    assert ctx.nn_launch_info()["threads"] == 1024
+
+
+@pytest.mark.parametrize("width", [176, 181])
+def test_largest_clouds_that_stay_resident(ctx, pkg, orc, width):
+    """30 976 and 32 761 moving points: 484 and 512 rows of 64, two blocks on (almost) every CU for the whole registration"""
+    D = pkg.datasets.synthetic_grid(width, np.float32)
+    M = pkg.datasets.make_model_gpu(D[:4096], *pkg.datasets.P2P_GPU)
+    res = ctx.point_to_point(D, M, max_iter=4, tol=1e-6)
+    want = orc.icp_p2p_f32x(D, M, 4, 1e-6)
+    assert res.iterations == want["iterations"] and np.array_equal(res.idx, want["idx"])
+    assert rel(res.T, want["T"]) < TOL_T
+    assert ctx.nn_launch_info()["threads"] == 512
 
 
 def test_two_ranks_one_node_local_communicator(pkg, orc, golden):
