@@ -174,6 +174,9 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+STUCK = []   # helper threads that never came back (a communicator attempt that hangs)
+
+
 def guarded(fn, seconds):
     """run fn() on a helper thread; (True, result) or (False, reason) when it raised or did not return in time -- the
     stuck thread is abandoned (the process leaves through os._exit)"""
@@ -188,6 +191,7 @@ def guarded(fn, seconds):
     t.start()
     t.join(seconds)
     if t.is_alive():
+        STUCK.append(t)
         return False, f"no answer within {seconds} s"
     if "err" in box:
         return False, box["err"]
@@ -522,7 +526,8 @@ def main():
     ranks.close()
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)    # (a communicator attempt that never returned may have left a helper thread behind)
+    if STUCK:
+        os._exit(0)    # a communicator attempt never returned: its helper thread would keep the interpreter from ending
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(O+"/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"].split("(")[0]
-        if "nn_match_sparse" in k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "nn_match_" in k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(O+"/summary.txt","w") as out:
     for k,v in acc.items():
         print(k, file=out)
