@@ -55,8 +55,8 @@ typedef struct icp_ctx icp_ctx; /* opaque: owns device buffers, stream, pinned s
 #define ICP_MOM_SP 2   /* sum p (3) */
 #define ICP_MOM_SQ 5   /* sum q[idx] (3) */
 #define ICP_MOM_SQP 8  /* sum q_a * p_b, a-major (9) */
-#define ICP_MOM_SPP 17 /* sum |p|^2 */
-#define ICP_MOM_SQQ 18 /* sum |q[idx]|^2 */
+#define ICP_MOM_SPP 17 /* sum |p|^2   (informational: nothing on the path reads these two; the single-GPU point-to-point */
+#define ICP_MOM_SQQ 18 /* sum |q[idx]|^2  fast path, whose rows the host adds itself, leaves them 0)                         */
 #define ICP_MOM_C 2    /* point-to-plane: upper triangle of C, row-major (21) */
 #define ICP_MOM_B 23   /* point-to-plane: b (6) */
 
@@ -86,9 +86,11 @@ const char* icp_strerror(int code);
 const char* icp_last_error(void);
 /* number of usable HIP devices, or a negative error code */
 int icp_device_count(void);
-/* The calling thread's CPU affinity is narrowed to the CPUs local to the device's NUMA node (sysfs local_cpulist): the loop
- * is a host-thread <-> GPU conversation and every message from the other socket costs ~0.5 us more.  ICP_PIN=0 leaves the
- * affinity alone. */
+/* The loop is a host-thread <-> GPU conversation and every message from the other socket costs ~0.5 us more, so the entry
+ * points that hold that conversation (icp_create while it allocates its pinned buffers, icp_loop_run, icp_loop_complete,
+ * icp_point_to_*) narrow the calling thread's CPU affinity to the device's NUMA node (sysfs local_cpulist) if the thread
+ * currently runs elsewhere -- and put the caller's mask back before they return.  ICP_PIN=0 never touches the affinity;
+ * ICP_PIN=2 narrows once in icp_create and keeps it (a thread dedicated to the context). */
 int icp_create(int device, icp_ctx** out);
 void icp_destroy(icp_ctx* ctx);
 /* run all work of this context on an externally owned hipStream_t (e.g. torch's current stream);
@@ -96,7 +98,8 @@ void icp_destroy(icp_ctx* ctx);
 int icp_set_stream(icp_ctx* ctx, void* hip_stream);
 /* hipEvent timing of the matching kernel inside the loop: 0 = off, n > 0 = time every n-th launch
  * (two event records + a stream synchronisation on the timed launches only; with a resident registration
- * kernel the launch is the whole registration) */
+ * kernel the launch is the whole registration).  The call restarts the stride and the accumulators: the first
+ * launch after it is a timed one. */
 int icp_set_profiling(icp_ctx* ctx, int every_nth);
 
 /* ---- matching seam: replaces  Matching<<<>>>(n, P, Q, q_points, idx)
