@@ -814,6 +814,16 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         HIP_TRY(icp::launch_model_samples(view, m_pad, (float*)c->Qsamp.p, c->stream));
         c->have_scan_copy = true;
     }
+    if (precision == ICP_F64 && m > 0) {
+        // fp64 on the sparse structure: chunk boxes and cold-start samples of the model itself, in double (nothing is
+        // voided and no Morton view is built: the CPU path's clouds are grids and scans, which have locality)
+        const int m_pad = icp::pad_model(m);
+        HIP_TRY(c->Qbox.ensure(icp::model_boxes_f64_bytes(m_pad)));
+        HIP_TRY(c->Qsamp.ensure(icp::model_samples_f64_bytes(m_pad)));
+        HIP_TRY(icp::launch_model_tables_f64(c->Q.p, m_pad, c->Qbox.p, c->Qsamp.p, c->stream));
+        c->model_sorted = false;
+        c->voided = 0;
+    }
     c->have_model = true;
     return ICP_OK;
 }
@@ -911,6 +921,8 @@ static void prepare_rows_format(icp_ctx* c, bool compact)
 
 static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
 {
+    if (c->prec == ICP_F64)   // (fp64: the model is its own scan copy)
+        return icp::NNCullInputs{c->Q.p, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
@@ -1399,7 +1411,7 @@ bool can_arm(icp_ctx* c)
 {
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    return c->arm && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
+    return c->arm && c->prec == ICP_F32 && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
            icp::nn_can_fuse_transform(pl) && c->have_scan_copy && c->use_boxes && L.active && L.pending && !L.armed &&
            L.matched && !L.H.done && !L.H.have_rt &&
            !L.timed_nn &&  // a timed pass is completed with a stream synchronisation: nothing may wait behind it
@@ -1494,7 +1506,7 @@ bool can_reside(icp_ctx* c)
 {
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    return c->resident && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
+    return c->resident && c->prec == ICP_F32 && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
            icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done;
 }
 

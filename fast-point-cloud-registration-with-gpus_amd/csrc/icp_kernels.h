@@ -25,7 +25,7 @@ struct NNPlan {
     int blocks_x;       // n_pad / (NN_BLOCK * T)
     int splits;         // S: model segments scanned by different blocks (grid.y)
     int seg_len;        // model points per segment (multiple of NN_CHUNK)
-    int version;        // 1: generic kernel (fp64, A/B), 2: packed fp32 kernel
+    int version;        // 1: generic kernel (dense fp64, A/B), 2: packed fp32 kernels, 3: fp64 on the sparse structure (rows of 64)
     int chunk;          // index-tracking chunk of the launched kernel
     int cull;           // the packed kernel may use the seeded-bound / xy early-out variant
     int sparse;         // the geometry is the sparse kernel's (16-wave blocks of 128 moving points; needs chunk boxes)
@@ -146,6 +146,10 @@ hipError_t launch_morton_order(const PrepBuffers& b, const float* X_soa, int n, 
 hipError_t launch_gather_sorted(const float* Qs_soa, int m, int m_pad, const int32_t* perm, float* out_soa, int32_t* perm_pad, hipStream_t st);
 hipError_t launch_slot_map(const int32_t* perm, int n, int n_pad, int32_t* out, hipStream_t st);
 size_t model_samples_bytes(int m_pad);
+// fp64 form of the sparse search: chunk boxes {lo.xyz, hi.xyz, -, -} and one sample per chunk, in double, of the model itself
+size_t model_boxes_f64_bytes(int m_pad);
+size_t model_samples_f64_bytes(int m_pad);
+hipError_t launch_model_tables_f64(const void* Q_soa, int m_pad, void* boxes, void* samples, hipStream_t st);
 hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, hipStream_t st);
 // diagnostic: per-wave phase stamps (s_memrealtime, 100 MHz) of the packed matching kernel, 10 slots per wave indexed
 // ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 10 + phase; NULL switches it off (the default)

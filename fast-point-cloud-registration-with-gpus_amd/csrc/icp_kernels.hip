@@ -956,6 +956,9 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
     }
 }
 
+template <int TAIL, bool phase_diag_, int NWP>
+__device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, const NNFuse& fuse, const NNTail& tail, double err_row, int phase_pass_);
+
 // moment row of one row of 128 moving points, by ONE wave holding them two per lane (px.x = point lane,
 // px.y = point lane + 64) with their final correspondences j[]: stores idx, gathers q (and the normal),
 // accumulates in fp64, reduces through LDS in lane order and writes the row + completion tag.
@@ -1056,6 +1059,15 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
         }
         ICP_PHASE(7)
     }
+    tail_reduce_store<TAIL, phase_diag_, NWP>(tr, lane, fuse, tail, err_row, phase_pass_);
+}
+
+// second half of a row tail: the transpose buffer is summed slot by slot in a fixed order and the row goes out
+template <int TAIL, bool phase_diag_, int NWP>
+__device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, const NNFuse& fuse, const NNTail& tail, double err_row, int phase_pass_)
+{
+    constexpr int w = 0, phase_nw_ = NWP;  // (phase log) the closing wave of a sparse-kernel block
+    constexpr int NACC = TAIL == 2 ? 28 : 18;
     lds_same_wave_order();
     double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
     // Slot k is the sum of its 64 lane entries in a FIXED order: PARTS lanes per slot add a contiguous share each
@@ -2423,6 +2435,281 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64(const float* __
     }
     }  // pass loop
 }
+
+// ------------------------------------------------------------------------------------------------
+// matching, fp64, sparse, 64-point rows -- the CPU path's precision (src/ICP_CPU.c:220-234) on the structure of
+// nn_match_row64: chunk boxes (in double), seeded ulp-bumped bounds, lane-parallel find, unordered hit list with the
+// explicit (distance, index) tie rule, one point per lane.  There is no packed fp64 arithmetic, so a hit chunk is eight
+// scalar evaluations of (dx*dx + dy*dy) + dz*dz per lane, every operation rounded on its own.  One launch per pass
+// (no mailbox: a message line holds twelve floats, not twelve doubles): [transform + error of the previous pass] ->
+// matching -> moment row, where round 1 needed three launches per pass around a dense thread-per-point scan.
+// A 64-bit distance and an index do not fit one LDS key: every wave leaves its candidate (distance, index,
+// coordinates) in LDS and wave 0 takes the lexicographic minimum over the eight of them.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = __builtin_fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = __builtin_fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double bump_ulp(double d)   // next double above d (d >= 0, finite)
+{
+    return __longlong_as_double(__double_as_longlong(d) + 1ll);
+}
+
+// the transpose buffer of a row tail, filled from ONE point per lane given in double (see tail_close_row)
+template <int TAIL>
+__device__ __forceinline__ void tail_fill_one(double (*tr)[65], int lane, bool live, double ppx, double ppy, double ppz, double qx, double qy,
+                                              double qz, double nx, double ny, double nz)
+{
+    if constexpr (TAIL == 1) {
+        tr[0][lane] = 0.0 + (live ? 1.0 : 0.0);
+        tr[1][lane] = 0.0 + ppx; tr[2][lane] = 0.0 + ppy; tr[3][lane] = 0.0 + ppz;
+        tr[4][lane] = 0.0 + qx; tr[5][lane] = 0.0 + qy; tr[6][lane] = 0.0 + qz;
+        tr[7][lane] = 0.0 + qx * ppx; tr[8][lane] = 0.0 + qx * ppy; tr[9][lane] = 0.0 + qx * ppz;
+        tr[10][lane] = 0.0 + qy * ppx; tr[11][lane] = 0.0 + qy * ppy; tr[12][lane] = 0.0 + qy * ppz;
+        tr[13][lane] = 0.0 + qz * ppx; tr[14][lane] = 0.0 + qz * ppy; tr[15][lane] = 0.0 + qz * ppz;
+        tr[16][lane] = 0.0 + (ppx * ppx + ppy * ppy + ppz * ppz);
+        tr[17][lane] = 0.0 + (qx * qx + qy * qy + qz * qz);
+    } else {
+        double cn[6] = {0, 0, 0, 0, 0, 0}, bb = 0.0;
+        if (live) {
+            cn[0] = ppy * nz - ppz * ny;
+            cn[1] = ppz * nx - ppx * nz;
+            cn[2] = ppx * ny - ppy * nx;
+            cn[3] = nx; cn[4] = ny; cn[5] = nz;
+            bb = (ppx - qx) * nx + (ppy - qy) * ny + (ppz - qz) * nz;
+        }
+        tr[0][lane] = 0.0 + (live ? 1.0 : 0.0);
+        int o = 1;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c2 = a; c2 < 6; ++c2) tr[o++][lane] = 0.0 + cn[a] * cn[c2];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) tr[22 + a][lane] = 0.0 + -(cn[a] * bb);
+    }
+}
+
+template <int TAIL>
+__global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const double* __restrict__ P, int n_pad, const double* __restrict__ Q,
+                                                                     int m_pad, int round_passes, double* __restrict__ part_d,
+                                                                     int32_t* __restrict__ part_idx, RT<double> rt, NNFuse fuse, NNTail tail)
+{
+    constexpr int NW = R64_NW;
+    constexpr int STG = 32;              // doubles per staged hit: box 8, x 8, y 8, z 8
+    constexpr int SMAX = 1024;           // cold start: samples staged per round
+    constexpr int HITS_BYTES = SP_HCAP * 4, SAMPLE_BYTES = 3 * SMAX * 8;
+    constexpr int TR_BYTES = TAIL ? ((TAIL == 2 ? 28 : 18) * 65 + 64) * 8 : 0;
+    static_assert(TR_BYTES <= HITS_BYTES && HITS_BYTES <= SAMPLE_BYTES, "transpose buffer and staged samples overlay the hit list");
+    constexpr int SMIN_OFF = SAMPLE_BYTES, HCNT_OFF = SMIN_OFF + 64 * 8, STAGE_OFF = HCNT_OFF + 16, STAGE_BYTES = NW * 8 * STG * 8;
+    constexpr int CD_OFF = STAGE_OFF + STAGE_BYTES, CJ_OFF = CD_OFF + NW * 64 * 8, CQ_OFF = CJ_OFF + NW * 64 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[CQ_OFF + 3 * NW * 64 * 8];
+    int* hits = reinterpret_cast<int*>(lds_raw);
+    unsigned long long* smin = reinterpret_cast<unsigned long long*>(lds_raw + SMIN_OFF);
+    int* hcount = reinterpret_cast<int*>(lds_raw + HCNT_OFF);
+    double (*cand_d)[64] = reinterpret_cast<double (*)[64]>(lds_raw + CD_OFF);
+    int (*cand_j)[64] = reinterpret_cast<int (*)[64]>(lds_raw + CJ_OFF);
+    double (*cand_q)[NW][64] = reinterpret_cast<double (*)[NW][64]>(lds_raw + CQ_OFF);
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pi = blockIdx.x * 64 + lane;
+    double* stage = reinterpret_cast<double*>(lds_raw + STAGE_OFF) + w * (8 * STG);
+    const double* boxes = reinterpret_cast<const double*>(fuse.boxes);
+    const double* Qg = reinterpret_cast<const double*>(fuse.Q_gather);
+    const int c_lo = 0, c_hi = m_pad / 8;
+    const bool real = pi < fuse.n;
+    constexpr double kInf = __builtin_huge_val();
+    constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
+
+    // the seed: last pass's match, or (cold start) the model point at the same RELATIVE index -- any valid index is a valid bound
+    int js = !real ? -1 : fuse.seed_idx ? fuse.seed_idx[pi] : (int)(((long long)pi * fuse.m) / fuse.n);
+    const bool sok = (unsigned)js < (unsigned)fuse.m;
+    js = sok ? js : 0;
+    double sq[3] = {Qg[js], Qg[(size_t)m_pad + js], Qg[2 * (size_t)m_pad + js]};
+    double x = P[pi], y = P[(size_t)n_pad + pi], z = P[2 * (size_t)n_pad + pi];
+    if (w == 0) smin[lane] = kInfBits;
+    if (threadIdx.x == 0) *hcount = 0;
+    __syncthreads();
+
+    double err_row = 0.0;
+    if (fuse.apply) {
+        // every wave re-derives the moved point (same instructions => same bits); wave 0 stores it and accounts the error
+        // of the pass that produced (R, t): the statements of src/ICP_CPU.c:251-266
+        apply_rt<double>(rt, x, y, z, x, y, z);
+        if (w == 0) {
+            double* Po = reinterpret_cast<double*>(fuse.P_out);
+            Po[pi] = x; Po[(size_t)n_pad + pi] = y; Po[2 * (size_t)n_pad + pi] = z;
+            double err = 0.0;
+            if (real) {
+                double qx = sq[0], qy = sq[1], qz = sq[2];
+                if (!(fuse.seed_idx != nullptr && fuse.idx_prev == fuse.seed_idx && sok)) {
+                    const int j = fuse.idx_prev[pi];
+                    qx = Qg[j]; qy = Qg[(size_t)m_pad + j]; qz = Qg[2 * (size_t)m_pad + j];
+                }
+                const double ex = qx - x, ey = qy - y, ez = qz - z;
+                err = ex * ex + ey * ey + ez * ez;
+            }
+            err_row = wave_sum(err);
+            if constexpr (TAIL == 0) { if (lane == 0) fuse.err_rows[blockIdx.x] = err_row; }
+        }
+    }
+    double best = kInf;
+    double bq[3] = {0.0, 0.0, 0.0};
+    int bj = -1;   // index of the running minimum; -1: this wave has not lowered the bound it started from
+    {
+        const double d = dist2<double>(x, y, z, sq[0], sq[1], sq[2]);
+        best = (sok && d < kInf) ? bump_ulp(d) : kInf;   // the true minimum is <= d < bound: the seed changes the work, never the answer
+        best = real ? best : -1.0;                       // padding lanes never ask for a chunk
+    }
+    if (fuse.seed_idx == nullptr && fuse.samples != nullptr) {
+        // cold start: the points are measured against a thinned-out model (one point per chunk, up to SMAX of them spread
+        // evenly) and every wave starts from the block-wide minimum bumped by an ulp
+        const double* samples = reinterpret_cast<const double*>(fuse.samples);
+        const int ns8 = ((m_pad / 8) + 7) / 8, ns_pad = ns8 * 8;
+        double* sl = reinterpret_cast<double*>(lds_raw);       // [3][SMAX]
+        const int gcap = min(max(fuse.sample_groups, 1), SMAX / 8);
+        const int gs = (ns8 + gcap - 1) / gcap, ng = (ns8 + gs - 1) / gs;
+        for (int v = threadIdx.x; v < ng * 12; v += NW * 64) {
+            const int gp = v / 12, r = v % 12, a = r >> 2, hh = r & 3;
+            *reinterpret_cast<double2*>(sl + a * SMAX + gp * 8 + hh * 2) =
+                *reinterpret_cast<const double2*>(samples + (size_t)a * ns_pad + (size_t)gp * gs * 8 + hh * 2);
+        }
+        __syncthreads();
+        double sb = kInf;
+        for (int gp = w; gp < ng; gp += NW)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sb = __builtin_fmin(sb, dist2<double>(x, y, z, sl[gp * 8 + k], sl[SMAX + gp * 8 + k], sl[2 * SMAX + gp * 8 + k]));
+        if (real && sb < kInf) atomicMin(&smin[lane], (unsigned long long)__double_as_longlong(sb));
+        __syncthreads();  // (also: the staging area is free again)
+        const unsigned long long v = smin[lane];
+        if (real && v < kInfBits && __longlong_as_double((long long)(v + 1ull)) < best) best = __longlong_as_double((long long)(v + 1ull));
+        __syncthreads();  // everybody has read the minima before they are used again
+        if (w == 0) smin[lane] = kInfBits;
+    }
+    // bounding box of the block's 64 points (every wave derives the same one)
+    const double glo[3] = {wave_min_f64(x), wave_min_f64(y), wave_min_f64(z)};
+    const double ghi[3] = {wave_max_f64(x), wave_max_f64(y), wave_max_f64(z)};
+    const int round_chunks = NW * 64 * round_passes;
+    for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
+        const double B = wave_max_f64(best);   // only shrinks while the block works: refreshed once per round
+        if (rb != c_lo) __syncthreads();
+        // find: lane l tests chunk c0 + l -- box {lo.xyz, hi.xyz, -, -} against the group box
+        for (int r = 0; r < round_passes; ++r) {
+            const int c0 = rb + (r * NW + w) * 64;
+            if (c0 >= c_hi) break;
+            const int cidx = c0 + lane;
+            const double* bp = boxes + (size_t)(cidx < c_hi ? cidx : c_lo) * 8;
+            const double2 b01 = *reinterpret_cast<const double2*>(bp), b23 = *reinterpret_cast<const double2*>(bp + 2),
+                          b45 = *reinterpret_cast<const double2*>(bp + 4);
+            const double gx = __builtin_fmax(__builtin_fmax(b01.x - ghi[0], glo[0] - b23.y), 0.0);
+            const double gy = __builtin_fmax(__builtin_fmax(b01.y - ghi[1], glo[1] - b45.x), 0.0);
+            const double gz = __builtin_fmax(__builtin_fmax(b23.x - ghi[2], glo[2] - b45.y), 0.0);
+            const double L = ((gx * gx + gy * gy) + gz * gz) * 0.99999999;   // rounding is monotonic; the shave is belt and braces
+            const bool pass_ = cidx < c_hi && L < B;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass_);
+            if (mask != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(hcount, (int)__builtin_popcountll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (pass_ && base + rank < SP_HCAP) hits[base + rank] = cidx;
+            }
+        }
+        __syncthreads();
+        const int h1 = *hcount;
+        for (int hb = 0; hb < h1; hb += NW * 8) {
+            // hits are dealt round-robin; a wave fetches box + coordinates of up to 8 of its hits (16 lanes x 16 bytes per hit)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int r = half * 4 + (lane >> 4), part = lane & 15;
+                const int h = hb + r * NW + w;
+                if (h < h1) {
+                    const int chl = hits[h];
+                    const double* src = part < 4 ? boxes + (size_t)chl * 8 + part * 2
+                                                 : Q + (size_t)((part - 4) >> 2) * m_pad + (size_t)chl * 8 + ((part - 4) & 3) * 2;
+                    *reinterpret_cast<double2*>(stage + r * STG + part * 2) = *reinterpret_cast<const double2*>(src);
+                }
+            }
+            lds_same_wave_order();
+            const int mine = (h1 - hb - w + NW - 1) / NW;
+            const int cnt = mine < 8 ? mine : 8;
+            for (int rr = 0; rr < cnt; ++rr) {
+                const double* sb = stage + rr * STG;
+                {   // the chunk's box against the lane's point (ties pass: the hits are unordered)
+                    const double gx = __builtin_fmax(__builtin_fmax(sb[0] - x, x - sb[3]), 0.0);
+                    const double gy = __builtin_fmax(__builtin_fmax(sb[1] - y, y - sb[4]), 0.0);
+                    const double gz = __builtin_fmax(__builtin_fmax(sb[2] - z, z - sb[5]), 0.0);
+                    const double L = ((gx * gx + gy * gy) + gz * gz) * 0.99999999;
+                    if (__builtin_amdgcn_ballot_w64(L <= best) == 0ull) continue;
+                }
+                const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * NW + w]);
+                double d[8];
+                double c0 = kInf;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    d[k] = dist2<double>(x, y, z, sb[8 + k], sb[16 + k], sb[24 + k]);
+                    c0 = __builtin_fmin(c0, d[k]);
+                }
+                // identity order: chunks are disjoint index ranges, "lower model index" is "lower chunk, then lower k"
+                const bool take = (c0 < best) | ((c0 == best) & (ch < (bj >> 3)));   // bj = -1: nothing to tie with
+                if (__builtin_amdgcn_ballot_w64(take) != 0ull) {
+                    int k0 = 7;
+#pragma unroll
+                    for (int k = 6; k >= 0; --k) k0 = (d[k] == c0) ? k : k0;
+                    if (take) { best = c0; bj = ch * 8 + k0; bq[0] = sb[8 + k0]; bq[1] = sb[16 + k0]; bq[2] = sb[24 + k0]; }
+                }
+            }
+            lds_same_wave_order();
+        }
+        if (rb + round_chunks < c_hi) {
+            // exchange before the next round: every wave goes on from the block's best minimum so far, bumped by an ulp
+            if (real && best >= 0.0 && best < kInf) atomicMin(&smin[lane], (unsigned long long)__double_as_longlong(best));
+            __syncthreads();
+            if (threadIdx.x == 0) *hcount = 0;
+            const unsigned long long v = smin[lane];
+            if (real && v < kInfBits && v < (unsigned long long)__double_as_longlong(best)) { best = __longlong_as_double((long long)(v + 1ull)); bj = -1; }
+        }
+    }
+    // every wave leaves its candidate; wave 0 takes the lexicographic (distance, index) minimum
+    cand_d[w][lane] = bj >= 0 ? best : kInf;
+    cand_j[w][lane] = bj >= 0 ? bj : 0x7fffffff;
+    cand_q[0][w][lane] = bq[0]; cand_q[1][w][lane] = bq[1]; cand_q[2][w][lane] = bq[2];
+    __syncthreads();
+    if (w != 0) return;
+    double fb = cand_d[0][lane];
+    int fj = cand_j[0][lane], bw = 0;
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+        const double dd = cand_d[ww][lane];
+        const int jj = cand_j[ww][lane];
+        const bool lower = (dd < fb) | ((dd == fb) & (jj < fj));
+        fb = lower ? dd : fb; fj = lower ? jj : fj; bw = lower ? ww : bw;
+    }
+    if constexpr (TAIL == 0) {
+        part_d[pi] = fb;
+        part_idx[pi] = fj;
+    } else {
+        fj = ((unsigned)fj < (unsigned)fuse.m) ? fj : fuse.m - 1;  // unreachable clamp (padding lanes)
+        const double qx = cand_q[0][bw][lane], qy = cand_q[1][bw][lane], qz = cand_q[2][bw][lane];
+        if (real) tail.idx_out[pi] = fj;
+        double nx = 0.0, ny = 0.0, nz = 0.0;
+        if constexpr (TAIL == 2) {
+            const double* Nr = reinterpret_cast<const double*>(tail.Nrm);
+            if (real) { nx = Nr[fj]; ny = Nr[(size_t)m_pad + fj]; nz = Nr[2 * (size_t)m_pad + fj]; }
+        }
+        double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
+        tail_fill_one<TAIL>(tr, lane, real, real ? x : 0.0, real ? y : 0.0, real ? z : 0.0, real ? qx : 0.0, real ? qy : 0.0, real ? qz : 0.0, nx, ny, nz);
+        tail_reduce_store<TAIL, false, NW>(tr, lane, fuse, tail, fuse.apply ? err_row : 0.0, 0);
+    }
+}
 #undef ICP_PHASE
 
 // diagnostic (ICP_SELFTEST=1): does a running kernel see a store the host makes AFTER the kernel has started?
@@ -2727,6 +3014,54 @@ __global__ void model_samples_kernel(const float* __restrict__ Qs, int m_pad, in
     samples[(size_t)ns_pad + c] = v[1];
     samples[2 * (size_t)ns_pad + c] = v[2];
 }
+
+// the same two tables in double, for the fp64 form of the search (the model itself is the scan copy: nothing is voided)
+__global__ void model_boxes_f64_kernel(const double* __restrict__ Qs, int m_pad, double* __restrict__ boxes)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * 8 >= m_pad) return;
+    double lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = inf_<double>(); hi[a] = -inf_<double>(); }
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v = Qs[(size_t)a * m_pad + j];
+            if (v < inf_<double>() && v > -inf_<double>()) { lo[a] = __builtin_fmin(lo[a], v); hi[a] = __builtin_fmax(hi[a], v); }
+        }
+    }
+    double* o = boxes + (size_t)c * 8;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.0; o[7] = 0.0;
+}
+
+__global__ void model_samples_f64_kernel(const double* __restrict__ Qs, int m_pad, int ns_pad, double* __restrict__ samples)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ns_pad) return;
+    double v[3] = {inf_<double>(), inf_<double>(), inf_<double>()};
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+        const double x = Qs[j];
+        if (x < inf_<double>() && x > -inf_<double>()) { v[0] = x; v[1] = Qs[(size_t)m_pad + j]; v[2] = Qs[2 * (size_t)m_pad + j]; break; }
+    }
+    samples[c] = v[0];
+    samples[(size_t)ns_pad + c] = v[1];
+    samples[2 * (size_t)ns_pad + c] = v[2];
+}
+
+hipError_t launch_model_tables_f64(const void* Q_soa, int m_pad, void* boxes, void* samples, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const int chunks = (m_pad + 7) / 8, ns_pad = (chunks + 7) / 8 * 8;
+    hipLaunchKernelGGL(model_boxes_f64_kernel, dim3((chunks + 255) / 256), dim3(256), 0, st, (const double*)Q_soa, m_pad, (double*)boxes);
+    hipLaunchKernelGGL(model_samples_f64_kernel, dim3((ns_pad + 255) / 256), dim3(256), 0, st, (const double*)Q_soa, m_pad, ns_pad, (double*)samples);
+    return hipGetLastError();
+}
+size_t model_boxes_f64_bytes(int m_pad) { return (size_t)((m_pad + 7) / 8) * 8 * sizeof(double); }
+size_t model_samples_f64_bytes(int m_pad) { return 3 * (size_t)(((m_pad / 8) + 7) / 8 * 8) * sizeof(double); }
 
 size_t model_samples_bytes(int m_pad) { return 3 * (size_t)(((m_pad / 8) + 7) / 8 * 8) * sizeof(float); }
 
@@ -3437,6 +3772,25 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense)
         pl.seg_len = seg;
         return pl;
     }
+    if (precision == ICP_F64 && !force_dense && n > 0 && m > 0) {
+        // fp64 on the sparse structure (nn_match_row64_f64: rows of 64 points, one launch per pass): up to two blocks per CU
+        // and a model that is searched flat; ICP_F64_SPARSE=0 keeps the dense thread-per-point kernel
+        static const int env_sparse = env_int("ICP_NN_SPARSE", 1);
+        static const int env_boxes = env_int("ICP_NN_BOXES", 1);
+        const int env_f64 = env_int("ICP_F64_SPARSE", 1);   // (not cached: the tests switch it between contexts)
+        if (env_sparse && env_boxes && env_f64 && pl.n_pad / 64 <= 2 * num_cus && pl.m_pad < (1 << 17)) {
+            pl.version = 3;
+            pl.sparse = 1;
+            pl.cull = 1;
+            pl.chunk = 8;
+            pl.row = 64;
+            pl.pts_per_thread = 1;
+            pl.blocks_x = pl.n_pad / 64;
+            pl.splits = 1;
+            pl.seg_len = round_up(pl.m_pad, 8);
+            return pl;
+        }
+    }
     int T = precision == ICP_F64 ? NNCfg<double>::T : NNCfg<float>::T;
     if (env_T == 1 || env_T == 2 || env_T == 4 || env_T == 8) T = env_T;
     if (precision == ICP_F64 && T > 4) T = 4;
@@ -3478,7 +3832,10 @@ static hipError_t launch_nn_t(const NNPlan& pl, const void* P, const void* Q, vo
     return hipGetLastError();
 }
 
-bool nn_can_fuse_tail(const NNPlan& pl) { return pl.version == 2 && pl.pts_per_thread == 2 && pl.chunk == 8 && pl.n > 0 && pl.m > 0; }
+bool nn_can_fuse_tail(const NNPlan& pl)
+{
+    return ((pl.version == 2 && pl.pts_per_thread == 2 && pl.chunk == 8) || pl.version == 3) && pl.n > 0 && pl.m > 0;
+}
 
 int nn_block_threads(const NNPlan& pl) { return pl.sparse ? (pl.row == 64 ? R64_NW * 64 : SP_NW * 64) : NN_BLOCK; }
 
@@ -3691,13 +4048,61 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     return hipGetLastError();
 }
 
-bool nn_can_fuse_transform(const NNPlan& pl) { return pl.version == 2 && pl.n > 0 && pl.m > 0; }
+bool nn_can_fuse_transform(const NNPlan& pl) { return (pl.version == 2 || pl.version == 3) && pl.n > 0 && pl.m > 0; }
+
+// fp64, rows of 64 points: one launch per pass, no mailbox (NNFusedTransform::mailbox must be NULL)
+static hipError_t launch_row64_f64(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
+                                   const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st)
+{
+    if (!(opt && opt->Q_scan && opt->boxes)) return hipErrorInvalidValue;
+    if (ft && ft->mailbox) return hipErrorInvalidValue;
+    RT<double> rt{};
+    NNFuse fuse{};
+    fuse.n = pl.n;
+    fuse.m = pl.m;
+    fuse.Q_gather = (const float*)Q;                 // (typed by the kernel: doubles)
+    fuse.seed_idx = opt->seed_idx;
+    fuse.boxes = (const float*)opt->boxes;
+    static const int env_samples = env_int("ICP_NN_SAMPLES", 1);
+    fuse.samples = env_samples ? (const float*)opt->samples : nullptr;
+    static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 256);
+    fuse.sample_groups = env_sgroups;
+    if (ft) {
+        for (int k = 0; k < 9; ++k) rt.r[k] = ft->R9[k];
+        for (int k = 0; k < 3; ++k) rt.t[k] = ft->t3[k];
+        fuse.apply = 1;
+        fuse.idx_prev = ft->idx_prev;
+        fuse.P_out = (float*)ft->P_out;
+        fuse.err_rows = ft->err_rows;
+    }
+    NNTail tail{};
+    if (ta) {
+        tail.idx_out = ta->idx_out;
+        tail.idx_out_odd = ta->idx_out;
+        tail.Nrm = (const float*)ta->Nrm_soa;
+        tail.rows = ta->rows;
+        tail.tag = ta->tag;
+        tail.tag_lo = (unsigned int)(unsigned long long)ta->tag;
+        tail.compact = (ta->compact && ta->metric == ICP_POINT_TO_POINT) ? 1 : 0;
+    }
+    int passes = (fuse.seed_idx || fuse.samples) ? R64_MAX_PASSES : 1;
+    const dim3 grid(pl.blocks_x), block(R64_NW * 64);
+    const double* Pp = (const double*)P;
+    const double* Qs = (const double*)opt->Q_scan;
+#define ICP_R64F_LAUNCH(TL) hipLaunchKernelGGL((nn_match_row64_f64<TL>), grid, block, 0, st, Pp, pl.n_pad, Qs, pl.m_pad, passes, (double*)part_d, part_idx, rt, fuse, tail)
+    if (!ta) ICP_R64F_LAUNCH(0);
+    else if (ta->metric == ICP_POINT_TO_PLANE) ICP_R64F_LAUNCH(2);
+    else ICP_R64F_LAUNCH(1);
+#undef ICP_R64F_LAUNCH
+    return hipGetLastError();
+}
 
 hipError_t launch_nn(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,
                      const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st)
 {
     if (pl.n <= 0 || pl.m <= 0) return hipSuccess;
     if (pl.version == 2) return launch_nn_v2(pl, P, Q, part_d, part_idx, ft, opt, ta, st);
+    if (pl.version == 3) return launch_row64_f64(pl, P, Q, part_d, part_idx, ft, opt, ta, st);
     if (ft || ta) return hipErrorInvalidValue;  // only the packed fp32 kernel carries the fused front end
     return pl.precision == ICP_F64 ? launch_nn_t<double>(pl, P, Q, part_d, part_idx, st)
                                    : launch_nn_t<float>(pl, P, Q, part_d, part_idx, st);

@@ -258,6 +258,32 @@ def test_icp_hall_against_the_fp64_cpu_path(ctx, pkg, orc, golden):
     assert np.array_equal(r32.idx, want["idx"])                   # the final correspondences agree point for point
 
 
+@pytest.mark.parametrize("sparse", ["1", "0"])
+def test_fp64_forms_sparse_and_dense(pkg, orc, golden, monkeypatch, sparse):
+    """ICP_F64 runs on the sparse structure (nn_match_row64_f64: chunk boxes in double, one launch per pass) where the cloud
+    fits, or (ICP_F64_SPARSE=0, larger clouds) on the dense thread-per-point kernel: indices bit-exact against the fp64
+    oracle either way -- ragged sizes, lattice ties, duplicated points, the CPU program's own configuration"""
+    monkeypatch.setenv("ICP_F64_SPARSE", sparse)
+    rng = np.random.default_rng(99)
+    with pkg.Context(0) as c:
+        for n, m in [(1, 1), (3, 17), (1000, 255), (1025, 257), (2049, 4097), (777, 16), (5000, 3000)]:
+            P = rng.standard_normal((n, 3)); Q = rng.standard_normal((m, 3))
+            assert np.array_equal(c.Matching(P, Q), orc.nn(P, Q)), (n, m)
+        g = np.stack(np.meshgrid(np.arange(12.0), np.arange(12.0), np.arange(5.0), indexing="ij"), -1).reshape(-1, 3)
+        Q = np.concatenate([g, g[::3], g[5:40]]); P = np.concatenate([g[::2] + 0.5, g[1::5]])
+        assert np.array_equal(c.Matching(P, Q), orc.nn(P, Q))               # 8-way ties, exact duplicates at higher indices
+        Ph, Qh = orc.hall_clouds(golden)
+        Ph, Qh = Ph.astype(np.float64), Qh.astype(np.float64)
+        assert np.array_equal(c.Matching(Ph, Qh), orc.nn(Ph, Qh))            # 4361 coincident model points
+        D, M = orc.synth_icp_cpu(32)
+        res = c.point_to_point(D, M, max_iter=200, tol=1e-5)
+        want = orc.icp_p2p(D, M, 200, 1e-5)
+        assert res.iterations == want["iterations"] == 56 and np.array_equal(res.idx, want["idx"])
+        assert rel(res.T, want["T"]) < 1e-9 and np.abs(res.err - want["err"]).max() < 1e-9
+        info = c.nn_launch_info()
+        assert info["threads"] == (512 if sparse == "1" else 256)
+
+
 def test_icp_bunny(ctx, pkg, orc, golden):
     B = np.fromfile(os.path.join(golden, "bunny_res_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
     M = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
