@@ -112,7 +112,43 @@ static inline void post_message(icp::NNMailbox* mb, const double* R9, const doub
     bar_fence();
 }
 
+// the message of a registration in double (NNMailbox64): four 32-byte parts {3 doubles, cmd, tag}, one vector store each
+static inline void post_message64(icp::NNMailbox* mb32, const double* R9, const double* t3, int cmd, double seq, bool wide_stores = true)
+{
+    alignas(32) uint32_t line[32];
+    std::memset(line, 0, sizeof line);
+    const uint32_t tag = seq == 0.0 ? 0u : icp::mailbox_tag(seq);
+    for (int h = 0; h < 4; ++h) {
+        if (R9 && t3)
+            for (int k = 0; k < 3; ++k) {
+                const int i = 3 * h + k;
+                const double v = i < 9 ? R9[i] : t3[i - 9];
+                std::memcpy(&line[h * 8 + 2 * k], &v, sizeof v);
+            }
+        line[h * 8 + icp::ICP_MB64_CMD] = (uint32_t)cmd;
+        line[h * 8 + 7] = tag;
+    }
+    uint32_t* dstw = reinterpret_cast<uint32_t*>(mb32);
+#if defined(__x86_64__)
+    static const bool have_avx = __builtin_cpu_supports("avx");
+    if (have_avx && wide_stores) {
+        store_line_avx(dstw, line);
+        store_line_avx(dstw + 16, line + 16);
+        bar_fence();
+        return;
+    }
+#endif
+    volatile uint32_t* dst = dstw;
+    for (int k = 0; k < 32; ++k)
+        if ((k & 7) != 7) dst[k] = line[k];
+    bar_fence();
+    for (int h = 0; h < 4; ++h) dst[h * 8 + 7] = tag;
+    bar_fence();
+}
+
 static constexpr int kMailSlots = 4;  // armed launches: ring of mailboxes (one is live at a time)
+static constexpr size_t kMailSlotBytes = sizeof(icp::NNMailbox64);   // a slot holds a float message (one line) or a double one (two)
+static inline icp::NNMailbox* mail_slot(icp::NNMailbox* base, int slot) { return reinterpret_cast<icp::NNMailbox*>(reinterpret_cast<char*>(base) + (size_t)slot * kMailSlotBytes); }
 // Time budgets of a kernel that waits for the host, ordered so that a late host and a waiting kernel can never disagree:
 //   * a waiting block gives up (and reads that as EXIT) only after ICP_MAILBOX_BUDGET_S of WALL-CLOCK time (icp_kernels.h);
 //   * the host posts a message only while at most kMailLeaseS have passed since it last knew the kernel to be waiting (the
@@ -466,7 +502,7 @@ int icp_device_count(void)
 
 static void mailbox_selftest(icp_ctx* c, int slot, const char* when)
 {
-    icp::NNMailbox* mb = c->h_mail + slot;
+    icp::NNMailbox* mb = mail_slot(c->h_mail, slot);
     volatile double* ack = c->h_mom;
     *ack = 0.0;
     post_message(mb, nullptr, nullptr, icp::ICP_CMD_MATCH, 1.0);
@@ -555,17 +591,17 @@ int icp_create(int device, icp_ctx** out)
         const char* mv = std::getenv("ICP_MAILBOX");
         int large_bar = 0;
         if (!(mv && mv[0] == 'h') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
-            hipExtMallocWithFlags((void**)&c->h_mail, kMailSlots * sizeof(icp::NNMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
+            hipExtMallocWithFlags((void**)&c->h_mail, kMailSlots * kMailSlotBytes, hipDeviceMallocFinegrained) == hipSuccess) {
             c->mail_in_bar = true;
         } else {
             (void)hipGetLastError();
-            e = hipHostMalloc((void**)&c->h_mail, kMailSlots * sizeof(icp::NNMailbox), hipHostMallocMapped | hipHostMallocCoherent);
+            e = hipHostMalloc((void**)&c->h_mail, kMailSlots * kMailSlotBytes, hipHostMallocMapped | hipHostMallocCoherent);
         }
-        if (e == hipSuccess) { std::memset(c->h_mail, 0, kMailSlots * sizeof(icp::NNMailbox)); bar_fence(); }
+        if (e == hipSuccess) { std::memset(c->h_mail, 0, kMailSlots * kMailSlotBytes); bar_fence(); }
     }
     if (e == hipSuccess) {
-        if (hipExtMallocWithFlags((void**)&c->relay, sizeof(icp::NNMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
-            e = hipMemset(c->relay, 0, sizeof(icp::NNMailbox));
+        if (hipExtMallocWithFlags((void**)&c->relay, kMailSlotBytes, hipDeviceMallocFinegrained) == hipSuccess) {
+            e = hipMemset(c->relay, 0, kMailSlotBytes);
         } else {
             (void)hipGetLastError();
             c->relay = nullptr;  // no armed / resident launches on this device: every pass is launched after its solve
@@ -815,14 +851,23 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         c->have_scan_copy = true;
     }
     if (precision == ICP_F64 && m > 0) {
-        // fp64 on the sparse structure: chunk boxes and cold-start samples of the model itself, in double (nothing is
-        // voided and no Morton view is built: the CPU path's clouds are grids and scans, which have locality)
+        // fp64 on the sparse structure: the scan copy (exact duplicates of a lower-index point and the padding voided to
+        // +inf -- the hall scan's 4361 coincident points would otherwise put 545 chunks on every origin point's hit list),
+        // its chunk boxes and the cold-start samples, all in double.  No Morton view is built: the CPU path's clouds are
+        // grids and scans, which have locality.
         const int m_pad = icp::pad_model(m);
+        icp::PrepBuffers pb{};
+        if (int rc = prep_buffers(c, m, pb)) return rc;
+        icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
+        HIP_TRY(c->Qs.ensure(3 * (size_t)m_pad * sizeof(double)));
+        HIP_TRY(icp::launch_duplicates_and_scan_copy_f64(pb, (const double*)c->Q.p, m, m_pad, (unsigned char*)c->prep_voided.p, &small->voided,
+                                                         (double*)c->Qs.p, c->stream));
         HIP_TRY(c->Qbox.ensure(icp::model_boxes_f64_bytes(m_pad)));
         HIP_TRY(c->Qsamp.ensure(icp::model_samples_f64_bytes(m_pad)));
-        HIP_TRY(icp::launch_model_tables_f64(c->Q.p, m_pad, c->Qbox.p, c->Qsamp.p, c->stream));
+        HIP_TRY(icp::launch_model_tables_f64(c->Qs.p, m_pad, c->Qbox.p, c->Qsamp.p, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         c->model_sorted = false;
-        c->voided = 0;
+        c->have_scan_copy = true;
     }
     c->have_model = true;
     return ICP_OK;
@@ -892,7 +937,9 @@ int icp_set_model_normals(icp_ctx* c, const void* nxyz, int m)
 static bool use_compact_rows(const icp_ctx* c, const icp::NNPlan& pl, int metric, const double* rows)
 {
     static const bool off = std::getenv("ICP_COMPACT_ROWS") && std::getenv("ICP_COMPACT_ROWS")[0] == '0';   // (A/B runs)
-    return !off && pl.sparse && metric == ICP_POINT_TO_POINT && rows == c->h_mom_partials;
+    // (fp32 only: the compact row spends the last 16 mantissa bits of the error share on its tag -- 2^-36 of a sum of squares
+    // of floats is nothing, but the fp64 path is held to 1e-12 against src/ICP_CPU.c's arithmetic)
+    return !off && c->prec == ICP_F32 && pl.sparse && metric == ICP_POINT_TO_POINT && rows == c->h_mom_partials;
 }
 
 // Completion tags are consecutive integers.  A compact row shows only the low NN_CROW_TAG_BITS bits of its tag, and a
@@ -921,8 +968,8 @@ static void prepare_rows_format(icp_ctx* c, bool compact)
 
 static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
 {
-    if (c->prec == ICP_F64)   // (fp64: the model is its own scan copy)
-        return icp::NNCullInputs{c->Q.p, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
+    if (c->prec == ICP_F64)   // (fp64: no sorted views)
+        return icp::NNCullInputs{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
@@ -1345,7 +1392,10 @@ int icp_loop_complete(icp_ctx* c, int* done)
         tr1 = std::chrono::steady_clock::now();
         if (!polled) {
             // a resident kernel would go on waiting for its next message: withdraw it (under the tag it will wait for)
-            if (L.live_mailbox) post_message(L.live_mailbox, nullptr, nullptr, icp::ICP_CMD_EXIT, L.wait_tag + 1.0, c->mail_wide);
+            if (L.live_mailbox) {
+                if (c->prec == ICP_F64) post_message64(L.live_mailbox, nullptr, nullptr, icp::ICP_CMD_EXIT, L.wait_tag + 1.0, c->mail_wide);
+                else post_message(L.live_mailbox, nullptr, nullptr, icp::ICP_CMD_EXIT, L.wait_tag + 1.0, c->mail_wide);
+            }
             HIP_TRY(hipStreamSynchronize(c->stream));
             tr1 = std::chrono::steady_clock::now();
             for (int b = 0; b < L.mom_blocks; ++b)
@@ -1426,7 +1476,7 @@ int loop_arm(icp_ctx* c)
     const icp::NNCullInputs cull = make_cull(c, (const int32_t*)c->idx[c->cur].p);
     const int prev_cur = c->cur;
     const int slot = (int)(c->mail_seq++ % kMailSlots);
-    icp::NNMailbox* mb = c->h_mail + slot;
+    icp::NNMailbox* mb = mail_slot(c->h_mail, slot);
     const double tag = (double)take_tags(c, 1);
     post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, 0.0);   // cleared: nothing to act on yet
     icp::NNTailArgs ta{};
@@ -1464,7 +1514,7 @@ int loop_arm(icp_ctx* c)
 void loop_release_armed(icp_ctx* c)
 {
     LoopState& L = c->loop;
-    icp::NNMailbox* mb = c->h_mail + L.armed_slot;
+    icp::NNMailbox* mb = mail_slot(c->h_mail, L.armed_slot);
     post_message(mb, L.H.R, L.H.t, icp::ICP_CMD_TRANSFORM_MATCH, L.armed_tag, c->mail_wide);
     L.applied_idx = L.armed_prev_cur;
     L.H.note_applied();
@@ -1485,7 +1535,7 @@ void loop_withdraw_armed(icp_ctx* c)
 {
     LoopState& L = c->loop;
     if (!L.armed) return;
-    icp::NNMailbox* mb = c->h_mail + L.armed_slot;
+    icp::NNMailbox* mb = mail_slot(c->h_mail, L.armed_slot);
     post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, L.armed_tag, c->mail_wide);
     std::swap(c->P, c->P2);
     c->cur = L.armed_prev_cur;
@@ -1506,7 +1556,7 @@ bool can_reside(icp_ctx* c)
 {
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    return c->resident && c->prec == ICP_F32 && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
+    return c->resident && (c->prec == ICP_F32 || pl.version == 3) && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
            icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done;
 }
 
@@ -1519,10 +1569,15 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     rp.seg_len = icp::round_up(rp.m_pad, 8);
     if (const char* v = std::getenv("ICP_SELFTEST"))
         if (v[0] == '2') { mailbox_selftest(c, 0, "loop"); mailbox_selftest(c, 1, "loop"); }
-    icp::NNMailbox* mb = c->h_mail + (int)(c->mail_seq++ % kMailSlots);
+    icp::NNMailbox* mb = mail_slot(c->h_mail, (int)(c->mail_seq++ % kMailSlots));
     const int pass_cap = L.H.prm.max_iter + 2;
     const double base = (double)take_tags(c, (uint64_t)pass_cap + 1);
-    post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, 0.0);   // cleared
+    const bool f64 = c->prec == ICP_F64;
+    auto post = [&](const double* R9, const double* t3, int cmd, double seq) {
+        if (f64) post_message64(mb, R9, t3, cmd, seq, c->mail_wide);
+        else post_message(mb, R9, t3, cmd, seq, c->mail_wide);
+    };
+    post(nullptr, nullptr, icp::ICP_CMD_EXIT, 0.0);   // cleared
     const int c0 = c->cur;
     const icp::NNCullInputs cull = make_cull(c, L.matched ? (const int32_t*)c->idx[c0].p : nullptr);
     icp::NNTailArgs ta{};
@@ -1555,7 +1610,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     *fell_back = false;
     if (time_this) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     if (c->trace_passes) std::fprintf(stderr, "[icp trace] resident launch: mailbox %p relay %p base %.0f\n", (void*)mb, (void*)c->relay, base);
-    auto send = [&](int cmd, double seq) { post_message(mb, L.H.R, L.H.t, cmd, seq, c->mail_wide); };   // (R, t: ignored by a plain MATCH)
+    auto send = [&](int cmd, double seq) { post(L.H.R, L.H.t, cmd, seq); };   // (R, t: ignored by a plain MATCH)
     int k = *k_io, d = *d_io, sent = 0, matched = 0, rc = ICP_OK;
     bool alive = true;
     c->rows_done_at = std::chrono::steady_clock::now();   // (the launch: the kernel waits from now on at the earliest)

@@ -68,6 +68,14 @@ enum { ICP_MB_TAG0 = 7, ICP_MB_CMD = 13, ICP_MB_TAG1 = 14 };
 ICP_HOST_DEVICE inline uint32_t mailbox_tag(double seq) { return (uint32_t)(unsigned long long)seq | 0x80000000u; }
 ICP_HOST_DEVICE inline int mailbox_rt_word(int k) { return k < 7 ? k : k + 1; }   // the word rt[k] travels in
 enum { ICP_CMD_EXIT = 0, ICP_CMD_MATCH = 1, ICP_CMD_TRANSFORM_MATCH = 2, ICP_CMD_TRANSFORM_ONLY = 3 };
+// The same for a registration in double: twelve doubles do not fit one cache line, so the message is TWO lines in four
+// 32-byte parts, part h = {rt[3h], rt[3h+1], rt[3h+2] (6 words), cmd, tag}; each part is written by one 32-byte store and
+// the reader accepts the message only when all four tags are the awaited one.  A mailbox slot is 128 bytes for both
+// precisions (the float message uses its first line).
+struct alignas(128) NNMailbox64 {
+    uint32_t w[32];
+};
+enum { ICP_MB64_CMD = 6 };   // (within each part; tags: word 7 of each part)
 // How long a block waits for a message before it gives up (which reads as EXIT), in WALL-CLOCK seconds of the device's
 // constant 100 MHz counter -- the same budget whatever memory the poll goes to.  Blocks that listen to block 0's relay
 // wait twice as long: block 0 decides, and publishes its verdict (message or EXIT) through the relay.  The host side of
@@ -140,6 +148,8 @@ struct PrepBuffers {
 size_t prep_sort_temp_bytes(int count);
 hipError_t launch_duplicates_and_scan_copy(const PrepBuffers& b, const float* X_soa, int n, int n_pad, unsigned char* voided, int* count_dev,
                                            float* scan_out_soa, hipStream_t st);
+hipError_t launch_duplicates_and_scan_copy_f64(const PrepBuffers& b, const double* X_soa, int n, int n_pad, unsigned char* voided, int* count_dev,
+                                               double* scan_out_soa, hipStream_t st);
 // totals_dev: 4 doubles -- summed extents of the groups in the given / the Morton order, for `group` and (if > 0) `group2`
 hipError_t launch_morton_order(const PrepBuffers& b, const float* X_soa, int n, int n_pad, int group, int group2, int32_t* perm_out,
                                double* totals_dev, hipStream_t st);

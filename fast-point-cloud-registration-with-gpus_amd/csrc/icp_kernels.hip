@@ -2497,12 +2497,13 @@ __device__ __forceinline__ void tail_fill_one(double (*tr)[65], int lane, bool l
     }
 }
 
-template <int TAIL>
-__global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const double* __restrict__ P, int n_pad, const double* __restrict__ Q,
+// NW: waves per block -- 16 while that still gives every block its own CU (a far-apart pair is hundreds of hits per
+// block: the more waves share them the better), else 8 (two blocks per CU)
+template <int TAIL, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(const double* __restrict__ P, int n_pad, const double* __restrict__ Q,
                                                                      int m_pad, int round_passes, double* __restrict__ part_d,
-                                                                     int32_t* __restrict__ part_idx, RT<double> rt, NNFuse fuse, NNTail tail)
+                                                                     int32_t* __restrict__ part_idx, RT<double> rt_arg, NNFuse fuse, NNTail tail)
 {
-    constexpr int NW = R64_NW;
     constexpr int STG = 32;              // doubles per staged hit: box 8, x 8, y 8, z 8
     constexpr int SMAX = 1024;           // cold start: samples staged per round
     constexpr int HITS_BYTES = SP_HCAP * 4, SAMPLE_BYTES = 3 * SMAX * 8;
@@ -2510,13 +2511,16 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const doubl
     static_assert(TR_BYTES <= HITS_BYTES && HITS_BYTES <= SAMPLE_BYTES, "transpose buffer and staged samples overlay the hit list");
     constexpr int SMIN_OFF = SAMPLE_BYTES, HCNT_OFF = SMIN_OFF + 64 * 8, STAGE_OFF = HCNT_OFF + 16, STAGE_BYTES = NW * 8 * STG * 8;
     constexpr int CD_OFF = STAGE_OFF + STAGE_BYTES, CJ_OFF = CD_OFF + NW * 64 * 8, CQ_OFF = CJ_OFF + NW * 64 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[CQ_OFF + 3 * NW * 64 * 8];
+    constexpr int MSG_OFF = CQ_OFF + 3 * NW * 64 * 8, SEED_OFF = MSG_OFF + 128;   // resident launch: the message (32 words), last pass's matches
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SEED_OFF + 3 * 64 * 8];
     int* hits = reinterpret_cast<int*>(lds_raw);
     unsigned long long* smin = reinterpret_cast<unsigned long long*>(lds_raw + SMIN_OFF);
     int* hcount = reinterpret_cast<int*>(lds_raw + HCNT_OFF);
     double (*cand_d)[64] = reinterpret_cast<double (*)[64]>(lds_raw + CD_OFF);
     int (*cand_j)[64] = reinterpret_cast<int (*)[64]>(lds_raw + CJ_OFF);
     double (*cand_q)[NW][64] = reinterpret_cast<double (*)[NW][64]>(lds_raw + CQ_OFF);
+    uint32_t* msg = reinterpret_cast<uint32_t*>(lds_raw + MSG_OFF);
+    double (*seedq)[64] = reinterpret_cast<double (*)[64]>(lds_raw + SEED_OFF);
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2531,16 +2535,67 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const doubl
 
     // the seed: last pass's match, or (cold start) the model point at the same RELATIVE index -- any valid index is a valid bound
     int js = !real ? -1 : fuse.seed_idx ? fuse.seed_idx[pi] : (int)(((long long)pi * fuse.m) / fuse.n);
-    const bool sok = (unsigned)js < (unsigned)fuse.m;
+    bool sok = (unsigned)js < (unsigned)fuse.m;
     js = sok ? js : 0;
     double sq[3] = {Qg[js], Qg[(size_t)m_pad + js], Qg[2 * (size_t)m_pad + js]};
     double x = P[pi], y = P[(size_t)n_pad + pi], z = P[2 * (size_t)n_pad + pi];
+    // ---- the pass loop: one turn for an ordinary launch, one per ICP pass for a resident one (fuse.mailbox: a message of
+    // TWO cache lines -- twelve doubles do not fit one -- in four 32-byte parts {3 doubles, cmd, tag}: NNMailbox64) ----
+    for (int pass = 0;; ++pass) {
+    RT<double> rt = rt_arg;
+    int cmd = fuse.apply ? ICP_CMD_TRANSFORM_MATCH : ICP_CMD_MATCH;
+    double row_tag = tail.tag;
+    unsigned int row_tag_lo = tail.tag_lo;
+    const bool have_seeds = pass > 0 || fuse.seed_idx != nullptr;
     if (w == 0) smin[lane] = kInfBits;
     if (threadIdx.x == 0) *hcount = 0;
-    __syncthreads();
+    if (fuse.mailbox != nullptr) {
+        if (w == 0) {
+            // one load fetches both lines (lane l reads word l & 31); the message is there when all four parts carry the
+            // awaited tag.  Block 0 relays a host-memory mailbox through device memory; the wait is bounded in wall-clock time
+            const bool first = blockIdx.x == 0 || fuse.relay == nullptr;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(first ? (const void*)fuse.mailbox : (const void*)fuse.relay) + (lane & 31);
+            const uint32_t want32 = (fuse.want_lo + (uint32_t)pass) | 0x80000000u;
+            uint32_t word = 0u;
+            bool ok = false;
+            const long long give_up = (long long)wall_clock64() + (first ? ICP_MAILBOX_BUDGET_TICKS : 2 * ICP_MAILBOX_BUDGET_TICKS);
+            for (unsigned int spins = 1;; ++spins) {
+                word = first ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                             : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (uint32_t)__builtin_amdgcn_readlane((int)word, 7) == want32 && (uint32_t)__builtin_amdgcn_readlane((int)word, 15) == want32 &&
+                     (uint32_t)__builtin_amdgcn_readlane((int)word, 23) == want32 && (uint32_t)__builtin_amdgcn_readlane((int)word, 31) == want32;
+                if (ok) break;
+                if ((spins & 63u) == 0u && (long long)wall_clock64() > give_up) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            // (a time-out reads as a withdrawal)
+            if (!ok) word = (lane & 7) == ICP_MB64_CMD ? (uint32_t)ICP_CMD_EXIT : (lane & 7) == 7 ? want32 : 0u;
+            if (first && fuse.relay != nullptr && lane < 32)
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(fuse.relay) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < 32) msg[lane] = word;
+        }
+        __syncthreads();
+        cmd = (int)msg[ICP_MB64_CMD];
+        if (cmd == ICP_CMD_EXIT) return;  // withdrawn (the loop stopped) or timed out: nothing more is touched
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {   // double k sits in part k / 3, words 2 (k % 3) and 2 (k % 3) + 1
+            const int wd = (k / 3) * 8 + (k % 3) * 2;
+            const double v = __hiloint2double((int)msg[wd + 1], (int)msg[wd]);
+            if (k < 9) rt.r[k] = v; else rt.t[k - 9] = v;
+        }
+        row_tag = fuse.want + (double)pass;
+        row_tag_lo = fuse.want_lo + (unsigned int)pass;
+        if (pass > 0) {   // the seeds of a resident pass are the matches of the one before
+            sok = real;
+            sq[0] = seedq[0][lane]; sq[1] = seedq[1][lane]; sq[2] = seedq[2][lane];
+        }
+    } else {
+        __syncthreads();
+    }
+    const bool apply = cmd != ICP_CMD_MATCH;
 
     double err_row = 0.0;
-    if (fuse.apply) {
+    if (apply) {
         // every wave re-derives the moved point (same instructions => same bits); wave 0 stores it and accounts the error
         // of the pass that produced (R, t): the statements of src/ICP_CPU.c:251-266
         apply_rt<double>(rt, x, y, z, x, y, z);
@@ -2550,7 +2605,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const doubl
             double err = 0.0;
             if (real) {
                 double qx = sq[0], qy = sq[1], qz = sq[2];
-                if (!(fuse.seed_idx != nullptr && fuse.idx_prev == fuse.seed_idx && sok)) {
+                if (!((pass > 0 || (fuse.seed_idx != nullptr && fuse.idx_prev == fuse.seed_idx)) && sok)) {
                     const int j = fuse.idx_prev[pi];
                     qx = Qg[j]; qy = Qg[(size_t)m_pad + j]; qz = Qg[2 * (size_t)m_pad + j];
                 }
@@ -2561,6 +2616,29 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const doubl
             if constexpr (TAIL == 0) { if (lane == 0) fuse.err_rows[blockIdx.x] = err_row; }
         }
     }
+    if (!apply && pass == 0 && fuse.store_first && w == 0) {   // resident launch reading a pristine copy
+        double* Po = reinterpret_cast<double*>(fuse.P_out);
+        Po[pi] = x; Po[(size_t)n_pad + pi] = y; Po[2 * (size_t)n_pad + pi] = z;
+    }
+    if (cmd == ICP_CMD_TRANSFORM_ONLY) {
+        // the loop's last pass: nothing is matched any more, the row carries the error alone
+        if constexpr (TAIL != 0) {
+            if (w == 0) {
+                if (TAIL == 1 && tail.compact != 0) {
+                    double* row = tail.rows + (size_t)blockIdx.x * NN_CROW;
+                    if (lane >= 1 && lane < NN_CROW) __hip_atomic_store(&row[lane], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&row[0], crow_pack(err_row, row_tag_lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
+                    if (lane < ICP_NMOM - 1) row[lane] = lane == ICP_MOM_ERR ? err_row : 0.0;
+                    __threadfence_system();
+                    if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], row_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+        return;
+    }
     double best = kInf;
     double bq[3] = {0.0, 0.0, 0.0};
     int bj = -1;   // index of the running minimum; -1: this wave has not lowered the bound it started from
@@ -2569,7 +2647,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const doubl
         best = (sok && d < kInf) ? bump_ulp(d) : kInf;   // the true minimum is <= d < bound: the seed changes the work, never the answer
         best = real ? best : -1.0;                       // padding lanes never ask for a chunk
     }
-    if (fuse.seed_idx == nullptr && fuse.samples != nullptr) {
+    if (!have_seeds && fuse.samples != nullptr) {
         // cold start: the points are measured against a thinned-out model (one point per chunk, up to SMAX of them spread
         // evenly) and every wave starts from the block-wide minimum bumped by an ulp
         const double* samples = reinterpret_cast<const double*>(fuse.samples);
@@ -2625,20 +2703,26 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const doubl
         }
         __syncthreads();
         const int h1 = *hcount;
-        for (int hb = 0; hb < h1; hb += NW * 8) {
-            // hits are dealt round-robin; a wave fetches box + coordinates of up to 8 of its hits (16 lanes x 16 bytes per hit)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int r = half * 4 + (lane >> 4), part = lane & 15;
-                const int h = hb + r * NW + w;
-                if (h < h1) {
-                    const int chl = hits[h];
-                    const double* src = part < 4 ? boxes + (size_t)chl * 8 + part * 2
-                                                 : Q + (size_t)((part - 4) >> 2) * m_pad + (size_t)chl * 8 + ((part - 4) & 3) * 2;
-                    *reinterpret_cast<double2*>(stage + r * STG + part * 2) = *reinterpret_cast<const double2*>(src);
-                }
+        // hits are dealt round-robin; a wave fetches box + coordinates of up to 8 of its hits per batch (16 lanes x 16 bytes
+        // per hit).  The fetch of the NEXT batch is in flight while the current one is scanned: a far-apart pair
+        // (src/ICP_CPU.c's own: 870 of 1250 chunks survive the group test) is a dozen batches per wave, and their memory
+        // round trips in a row were more than half of the pass.
+        double2 nxt0 = double2{0.0, 0.0}, nxt1 = nxt0;   // (named, not an array: the compiler moved an array of two to LDS)
+        const int part = lane & 15, r0 = lane >> 4, r1 = 4 + (lane >> 4);
+        auto fetch_one = [&](int h, double2& dst) {
+            if (h < h1) {
+                const int chl = hits[h];
+                const double* src = part < 4 ? boxes + (size_t)chl * 8 + part * 2
+                                             : Q + (size_t)((part - 4) >> 2) * m_pad + (size_t)chl * 8 + ((part - 4) & 3) * 2;
+                dst = *reinterpret_cast<const double2*>(src);
             }
+        };
+        if (h1 > 0) { fetch_one(r0 * NW + w, nxt0); fetch_one(r1 * NW + w, nxt1); }
+        for (int hb = 0; hb < h1; hb += NW * 8) {
+            if (hb + r0 * NW + w < h1) *reinterpret_cast<double2*>(stage + r0 * STG + part * 2) = nxt0;
+            if (hb + r1 * NW + w < h1) *reinterpret_cast<double2*>(stage + r1 * STG + part * 2) = nxt1;
             lds_same_wave_order();
+            if (hb + NW * 8 < h1) { fetch_one(hb + NW * 8 + r0 * NW + w, nxt0); fetch_one(hb + NW * 8 + r1 * NW + w, nxt1); }
             const int mine = (h1 - hb - w + NW - 1) / NW;
             const int cnt = mine < 8 ? mine : 8;
             for (int rr = 0; rr < cnt; ++rr) {
@@ -2683,7 +2767,10 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const doubl
     cand_j[w][lane] = bj >= 0 ? bj : 0x7fffffff;
     cand_q[0][w][lane] = bq[0]; cand_q[1][w][lane] = bq[1]; cand_q[2][w][lane] = bq[2];
     __syncthreads();
-    if (w != 0) return;
+    if (w != 0) {
+        if (!fuse.resident) return;
+        continue;   // resident: on to the next message (asleep at its barrier while wave 0 closes the row)
+    }
     double fb = cand_d[0][lane];
     int fj = cand_j[0][lane], bw = 0;
 #pragma unroll
@@ -2696,10 +2783,11 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const doubl
     if constexpr (TAIL == 0) {
         part_d[pi] = fb;
         part_idx[pi] = fj;
+        return;
     } else {
         fj = ((unsigned)fj < (unsigned)fuse.m) ? fj : fuse.m - 1;  // unreachable clamp (padding lanes)
         const double qx = cand_q[0][bw][lane], qy = cand_q[1][bw][lane], qz = cand_q[2][bw][lane];
-        if (real) tail.idx_out[pi] = fj;
+        if (real) ((pass & 1) ? tail.idx_out_odd : tail.idx_out)[pi] = fj;
         double nx = 0.0, ny = 0.0, nz = 0.0;
         if constexpr (TAIL == 2) {
             const double* Nr = reinterpret_cast<const double*>(tail.Nrm);
@@ -2707,8 +2795,15 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64_f64(const doubl
         }
         double (*tr)[65] = reinterpret_cast<double (*)[65]>(lds_raw);
         tail_fill_one<TAIL>(tr, lane, real, real ? x : 0.0, real ? y : 0.0, real ? z : 0.0, real ? qx : 0.0, real ? qy : 0.0, real ? qz : 0.0, nx, ny, nz);
-        tail_reduce_store<TAIL, false, NW>(tr, lane, fuse, tail, fuse.apply ? err_row : 0.0, 0);
+        NNTail tl = tail;
+        tl.tag = row_tag;
+        tl.tag_lo = row_tag_lo;
+        tail_reduce_store<TAIL, false, NW>(tr, lane, fuse, tl, apply ? err_row : 0.0, 0);
+        if (!fuse.resident) return;
+        // the matches of this pass seed the next one and are what its error is measured against
+        seedq[0][lane] = qx; seedq[1][lane] = qy; seedq[2][lane] = qz;
     }
+    }  // pass loop
 }
 #undef ICP_PHASE
 
@@ -2784,6 +2879,48 @@ __global__ void prep_scan_copy_kernel(const float* __restrict__ X, int n, int n_
     const bool keep = j < n && !voided[j];
 #pragma unroll
     for (int a = 0; a < 3; ++a) out[(size_t)a * n_pad + j] = keep ? X[(size_t)a * n_pad + j] : inf_<float>();
+}
+
+// ---- the same for a cloud in double: a 64-bit key is two stable 32-bit passes (low word, then high word) --------------
+__device__ __forceinline__ unsigned long long canon_bits64(double v) { return (unsigned long long)__double_as_longlong(v == 0.0 ? 0.0 : v); }
+
+__global__ void prep_axis_keys_f64_kernel(const double* __restrict__ X, int n, int n_pad, int axis, int high, const int32_t* __restrict__ order,
+                                          unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = order ? order[s] : s;
+    const unsigned long long b = canon_bits64(X[(size_t)axis * n_pad + i]);
+    keys[s] = high ? (unsigned int)(b >> 32) : (unsigned int)b;
+    if (!order) vals[s] = s;
+}
+
+__global__ void prep_mark_duplicates_f64_kernel(const double* __restrict__ X, int n, int n_pad, const int32_t* __restrict__ lex,
+                                                unsigned char* __restrict__ voided, int* __restrict__ count)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    bool v = false;
+    if (s > 0) {
+        const int a = lex[s - 1], b = lex[s];
+        const double bx = X[b], by = X[(size_t)n_pad + b], bz = X[2 * (size_t)n_pad + b];
+        const bool same = canon_bits64(X[a]) == canon_bits64(bx) && canon_bits64(X[(size_t)n_pad + a]) == canon_bits64(by) &&
+                          canon_bits64(X[2 * (size_t)n_pad + a]) == canon_bits64(bz);
+        const bool nan = bx != bx || by != by || bz != bz;
+        v = same && !nan;
+    }
+    voided[lex[s]] = v ? 1 : 0;
+    if (v) atomicAdd(count, 1);
+}
+
+__global__ void prep_scan_copy_f64_kernel(const double* __restrict__ X, int n, int n_pad, const unsigned char* __restrict__ voided,
+                                          double* __restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    const bool keep = j < n && !voided[j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out[(size_t)a * n_pad + j] = keep ? X[(size_t)a * n_pad + j] : inf_<double>();
 }
 
 // bounding cube of the finite points: box[0..2] = lo, box[3] = largest extent (one block, fixed order)
@@ -2931,6 +3068,27 @@ hipError_t launch_duplicates_and_scan_copy(const PrepBuffers& b, const float* X,
     }
     hipLaunchKernelGGL(prep_mark_duplicates_kernel, grd, blk, 0, st, X, n, n_pad, b.vals[cur], voided, count_dev);
     hipLaunchKernelGGL(prep_scan_copy_kernel, dim3((n_pad + 255) / 256), blk, 0, st, X, n, n_pad, voided, scan_out);
+    return hipGetLastError();
+}
+
+// the same for a cloud in double (six stable 32-bit passes: z low, z high, y low, ...)
+hipError_t launch_duplicates_and_scan_copy_f64(const PrepBuffers& b, const double* X, int n, int n_pad, unsigned char* voided, int* count_dev,
+                                               double* scan_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const dim3 blk(256), grd((n + 255) / 256);
+    int cur = 0;
+    bool first = true;
+    for (int axis = 2; axis >= 0; --axis)
+        for (int high = 0; high < 2; ++high) {
+            hipLaunchKernelGGL(prep_axis_keys_f64_kernel, grd, blk, 0, st, X, n, n_pad, axis, high, first ? (const int32_t*)nullptr : b.vals[cur],
+                               b.keys[cur], b.vals[cur]);
+            if (hipError_t e = sort_pairs(b, n, cur, 32, st)) return e;
+            cur ^= 1;
+            first = false;
+        }
+    hipLaunchKernelGGL(prep_mark_duplicates_f64_kernel, grd, blk, 0, st, X, n, n_pad, b.vals[cur], voided, count_dev);
+    hipLaunchKernelGGL(prep_scan_copy_f64_kernel, dim3((n_pad + 255) / 256), blk, 0, st, X, n, n_pad, voided, scan_out);
     return hipGetLastError();
 }
 
@@ -4055,7 +4213,7 @@ static hipError_t launch_row64_f64(const NNPlan& pl, const void* P, const void* 
                                    const NNFusedTransform* ft, const NNCullInputs* opt, const NNTailArgs* ta, hipStream_t st)
 {
     if (!(opt && opt->Q_scan && opt->boxes)) return hipErrorInvalidValue;
-    if (ft && ft->mailbox) return hipErrorInvalidValue;
+    if (ft && ft->mailbox && !ft->resident) return hipErrorInvalidValue;   // (no armed launches in double)
     RT<double> rt{};
     NNFuse fuse{};
     fuse.n = pl.n;
@@ -4068,8 +4226,17 @@ static hipError_t launch_row64_f64(const NNPlan& pl, const void* P, const void* 
     static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 256);
     fuse.sample_groups = env_sgroups;
     if (ft) {
-        for (int k = 0; k < 9; ++k) rt.r[k] = ft->R9[k];
-        for (int k = 0; k < 3; ++k) rt.t[k] = ft->t3[k];
+        if (ft->mailbox) {   // resident launch: (R, t) arrive as messages (NNMailbox64)
+            fuse.mailbox = ft->mailbox;
+            fuse.relay = ft->relay;
+            fuse.want = ft->want;
+            fuse.want_lo = (unsigned int)(unsigned long long)ft->want;
+            fuse.resident = 1;
+            fuse.store_first = ft->store_first ? 1 : 0;
+        } else {
+            for (int k = 0; k < 9; ++k) rt.r[k] = ft->R9[k];
+            for (int k = 0; k < 3; ++k) rt.t[k] = ft->t3[k];
+        }
         fuse.apply = 1;
         fuse.idx_prev = ft->idx_prev;
         fuse.P_out = (float*)ft->P_out;
@@ -4078,23 +4245,36 @@ static hipError_t launch_row64_f64(const NNPlan& pl, const void* P, const void* 
     NNTail tail{};
     if (ta) {
         tail.idx_out = ta->idx_out;
-        tail.idx_out_odd = ta->idx_out;
+        tail.idx_out_odd = ta->idx_out_odd ? ta->idx_out_odd : ta->idx_out;
         tail.Nrm = (const float*)ta->Nrm_soa;
         tail.rows = ta->rows;
         tail.tag = ta->tag;
         tail.tag_lo = (unsigned int)(unsigned long long)ta->tag;
         tail.compact = (ta->compact && ta->metric == ICP_POINT_TO_POINT) ? 1 : 0;
     }
-    int passes = (fuse.seed_idx || fuse.samples) ? R64_MAX_PASSES : 1;
-    const dim3 grid(pl.blocks_x), block(R64_NW * 64);
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int nw = pl.blocks_x <= cus ? 16 : 8;
+    const int passes = (fuse.seed_idx || fuse.samples) ? SP_HCAP / (nw * 64) : 1;
+    const dim3 grid(pl.blocks_x), block(nw * 64);
     const double* Pp = (const double*)P;
     const double* Qs = (const double*)opt->Q_scan;
-#define ICP_R64F_LAUNCH(TL) hipLaunchKernelGGL((nn_match_row64_f64<TL>), grid, block, 0, st, Pp, pl.n_pad, Qs, pl.m_pad, passes, (double*)part_d, part_idx, rt, fuse, tail)
-    if (!ta) ICP_R64F_LAUNCH(0);
-    else if (ta->metric == ICP_POINT_TO_PLANE) ICP_R64F_LAUNCH(2);
-    else ICP_R64F_LAUNCH(1);
-#undef ICP_R64F_LAUNCH
-    return hipGetLastError();
+    const int tl = !ta ? 0 : (ta->metric == ICP_POINT_TO_PLANE ? 2 : 1);
+    static const void* const fns[3][2] = {{(const void*)nn_match_row64_f64<0, 8>, (const void*)nn_match_row64_f64<0, 16>},
+                                          {(const void*)nn_match_row64_f64<1, 8>, (const void*)nn_match_row64_f64<1, 16>},
+                                          {(const void*)nn_match_row64_f64<2, 8>, (const void*)nn_match_row64_f64<2, 16>}};
+    const void* fn = fns[tl][nw == 16 ? 1 : 0];
+    if (fuse.resident) {
+        // every block must be on the machine at once: blocks <= CUs x resident blocks per CU (the occupancy query)
+        if (!ta) return hipErrorInvalidValue;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nw * 64, 0) != hipSuccess) return hipErrorCooperativeLaunchTooLarge;
+        if ((long long)pl.blocks_x > (long long)per_cu * cus) return hipErrorCooperativeLaunchTooLarge;
+    }
+    int n_pad = pl.n_pad, m_pad = pl.m_pad, passes_ = passes;
+    double* pd = (double*)part_d;
+    void* args[] = {&Pp, &n_pad, &Qs, &m_pad, &passes_, &pd, &part_idx, &rt, &fuse, &tail};
+    return hipLaunchKernel(fn, grid, block, args, 0, st);
 }
 
 hipError_t launch_nn(const NNPlan& pl, const void* P, const void* Q, void* part_d, int32_t* part_idx,

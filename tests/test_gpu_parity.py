@@ -284,6 +284,35 @@ def test_fp64_forms_sparse_and_dense(pkg, orc, golden, monkeypatch, sparse):
         assert info["threads"] == (512 if sparse == "1" else 256)
 
 
+def test_fp64_loop_forms_are_bit_identical(pkg, orc, golden, monkeypatch):
+    """ICP_F64: one resident kernel per registration (its (R, t) arrive as two-cache-line messages of twelve doubles), the
+    step-wise loop (one launch per pass), each with its mailbox in BAR memory or in host memory, and the dense kernel's
+    three-launch form: the same bits -- and the fp64 oracle's run"""
+    D, M = orc.synth_icp_cpu(48)
+    Ph, Qh = orc.hall_clouds(golden)
+    Ph, Qh = Ph.astype(np.float64), Qh.astype(np.float64)
+    forms = {"resident": {}, "resident_host_mailbox": {"ICP_MAILBOX": "host"}, "resident_plain_stores": {"ICP_MAILBOX_AVX": "0"},
+             "stepwise": {"ICP_RESIDENT": "0"}}
+    def run(c):
+        a = c.point_to_point(D, M, max_iter=200, tol=1e-5)
+        b = c.point_to_point(Ph, Qh, max_iter=200, tol=1e-5)
+        return a, b
+    res = {name: _run_form(pkg, monkeypatch, env, run) for name, env in forms.items()}
+    ref = res["stepwise"]
+    for name, r in res.items():
+        for x, y in zip(r, ref):
+            assert x.iterations == y.iterations, name
+            assert np.array_equal(x.T, y.T) and np.array_equal(x.err, y.err) and np.array_equal(x.idx, y.idx) and np.array_equal(x.moved, y.moved), name
+    monkeypatch.setenv("ICP_F64_SPARSE", "0")
+    dense = _run_form(pkg, monkeypatch, {}, run)
+    monkeypatch.delenv("ICP_F64_SPARSE")
+    for x, y, (A, B) in zip(dense, ref, ((D, M), (Ph, Qh))):
+        want = orc.icp_p2p(A, B, 200, 1e-5)
+        for r in (x, y):
+            assert r.iterations == want["iterations"] and np.array_equal(r.idx, want["idx"])
+            assert rel(r.T, want["T"]) < 1e-9 and np.abs(r.err - want["err"]).max() < 1e-9
+
+
 def test_icp_bunny(ctx, pkg, orc, golden):
     B = np.fromfile(os.path.join(golden, "bunny_res_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
     M = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
