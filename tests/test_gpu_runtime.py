@@ -189,6 +189,22 @@ def test_bench_starts_its_own_ranks():
     assert 0 < d["roofline"]["frac"] <= 1.0
 
 
+def test_bench_under_torch_distributed_run():
+    """the driver's launch line for N > 1 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`),
+    rehearsed with both ranks on the one GPU"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ICP_BENCH_ONE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29637", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "120", "--warmup", "20"],
+                         env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["rccl"]["ranks"] == 2
+
+
 def test_bench_rccl_leg_single_rank():
     """the library-issued ncclAllReduce route, exercised with the one rank this box has"""
     d = _bench(["--steps", "120", "--warmup", "20", "--no-cpu-baseline"], {"ICP_BENCH_FORCE_DIST": "1"})
