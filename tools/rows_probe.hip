@@ -44,6 +44,7 @@ __attribute__((target("avx"))) static void post(unsigned int* mb, unsigned int t
     _mm_sfence();
 }
 
+static int g_mode = 0;   // 0: poll the rows in block order; 1: the same with the next rows prefetched; 2: sweep over all missing tags, then add
 static int run(unsigned int* mb, int blocks, int stride, int tag_slot, int nslots, int use_err, const char* name)
 {
     const int rounds = 3000;
@@ -63,8 +64,30 @@ static int run(unsigned int* mb, int blocks, int stride, int tag_slot, int nslot
         post(mb, (unsigned int)i);
         double mom[32] = {0};
         double t_first = 0;
+        if (g_mode == 2) {
+            // sweep: touch every missing tag in turn until all are there (the loads of different rows overlap), then add in order
+            static unsigned char seen[1024];
+            std::memset(seen, 0, sizeof seen);
+            int left = blocks;
+            while (left > 0) {
+                for (int b = 0; b < blocks; ++b) {
+                    if (seen[b]) continue;
+                    const volatile double* tg = rows + (size_t)b * stride + tag_slot;
+                    if (*tg == (double)i) { seen[b] = 1; --left; _mm_prefetch((const char*)(rows + (size_t)b * stride) + 64, _MM_HINT_T0); }
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) { std::printf("%s: timeout round %d\n", name, i); return 1; }
+            }
+            t_first = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            for (int b = 0; b < blocks; ++b) {
+                const double* row = rows + (size_t)b * stride;
+                for (int k = 0; k < nslots; ++k) if (k != tag_slot) mom[k] += row[k];
+            }
+        } else
         for (int b = 0; b < blocks; ++b) {
             const volatile double* tg = rows + (size_t)b * stride + tag_slot;
+            if (g_mode == 1)
+                for (int a = 1; a <= 4; ++a)
+                    if (b + a < blocks) _mm_prefetch((const char*)(rows + (size_t)(b + a) * stride + tag_slot), _MM_HINT_T0);
             while (*tg != (double)i)
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) { std::printf("%s: timeout round %d row %d\n", name, i, b); return 1; }
             if (b == 0) t_first = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -88,6 +111,12 @@ int main()
 {
     unsigned int* mb = nullptr;
     CK(hipExtMallocWithFlags((void**)&mb, 256, hipDeviceMallocFinegrained));
+    for (g_mode = 1; g_mode <= 2; ++g_mode)
+        for (int blocks : {128, 256}) {
+            run(mb, blocks, 16, 0, 16, 0, g_mode == 1 ? "rows of 16, next 4 tag lines prefetched" : "rows of 16, sweep over missing tags then add");
+            run(mb, blocks, 32, 31, 19, 0, g_mode == 1 ? "rows of 32, next 4 tag lines prefetched" : "rows of 32, sweep over missing tags then add");
+        }
+    g_mode = 0;
     for (int blocks : {1, 32, 128, 256, 512}) {
         run(mb, blocks, 32, 31, 19, 0, "rows of 32 doubles, 19 used, tag in slot 31");
         run(mb, blocks, 16, 0, 16, 0, "rows of 16 doubles, tag in slot 0");
