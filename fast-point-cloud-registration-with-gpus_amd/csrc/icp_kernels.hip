@@ -4076,8 +4076,11 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         const void* Qsp = opt->Q_scan_sorted ? opt->Q_scan_sorted : opt->Q_scan;
         static const int env_samples = env_int("ICP_NN_SAMPLES", 1);
         fuse.samples = env_samples ? (const float*)opt->samples : nullptr;
-        static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 256);   // the cold start's full round (its probe round is 8 groups)
-        fuse.sample_groups = env_sgroups;
+        // the cold start's full round (its probe round is 8 groups): 64 groups = 512 samples on a small model -- measured
+        // (round 2, rows of 64): as good as 2048 on the 128 x 128 grid, Bunny_res and a random cloud, and 4 us less of a cold
+        // pass on the hall scan, where a few blocks take the full round without gaining from it; 2048 on large models
+        static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 0);
+        fuse.sample_groups = env_sgroups > 0 ? env_sgroups : (pl.m_pad <= 32768 ? 64 : 256);
         static const int env_passes = env_int("ICP_NN_PASSES", 0);
         // seeded: few hits, long rounds; cold: short rounds so that the exchanged minima start pruning early
         const int max_passes = pl.row == 64 ? R64_MAX_PASSES : SP_MAX_PASSES;

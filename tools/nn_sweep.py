@@ -25,6 +25,13 @@ if name == "hall":
 elif name == "bunny":
     P = np.fromfile(os.path.join(g, "bunny_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
     Q = pkg.datasets.make_model_gpu(P, *pkg.datasets.BUNNY)
+elif name == "bunny_res":
+    P = np.fromfile(os.path.join(g, "bunny_res_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
+    Q = pkg.datasets.make_model_gpu(P, *pkg.datasets.BUNNY)
+elif name == "random":
+    rng = np.random.default_rng(5)
+    Q = rng.uniform(-1, 1, (16384, 3)).astype(np.float32)
+    P = (Q[rng.permutation(16384)] + 0.01 * rng.standard_normal((16384, 3))).astype(np.float32)
 elif name == "grid128":
     P = pkg.datasets.synthetic_grid(128, np.float32)
     Q = pkg.datasets.make_model_gpu(P, *pkg.datasets.P2P_GPU)
