@@ -265,10 +265,12 @@ def run_hall(args, rank, local_rank, world):
         raise SystemExit(f"[bench] the hall registration did not converge: {passes_full} passes, rms error {st['err'][-1]}")
 
     run_steps(W)
-    # HIP events around the loop's kernel inside the timed region: with a resident kernel a launch is a whole
-    # registration, so every 7th is timed when the region holds many of them, every one when it holds few
+    # HIP events around the loop's kernel inside the timed region: with a resident kernel a launch is a whole registration,
+    # so every 7th is timed when the region holds many of them (1-2 % of overhead).  A region of a few registrations is
+    # not bracketed at all -- the two event records and the wait for the kernel's end would be a tenth of what is being
+    # measured; the roofline leg then comes from the fixed block of 20 registrations run right after it
     regs_expected = max(1, K // max(1, passes_full))
-    stride = 7 if regs_expected >= 70 else 1
+    stride = 7 if regs_expected >= 70 else 0
     dt, stats, sec1, cnt1, passes1 = timed(K, stride)
     out = None
     if rank == 0:

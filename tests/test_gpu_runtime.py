@@ -161,7 +161,7 @@ def test_bench_with_the_drivers_arguments():
     assert abs(d["value"] - 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
-    assert r["launches_timed"] >= 1 and r["avg_launch_us"] > 0
+    assert r["launches_timed"] >= 1 and r["avg_launch_us"] > 0 and r["timed_in"]
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert 0 < r["dense_kernel"]["frac"] <= 0.5 + 1e-9                  # no FMA: half the FMA-counted roof at most
     assert 0 < r["hbm"]["frac"] <= 1.0
