@@ -493,6 +493,7 @@ struct NNFuse {
     long long tlog_cap;      // slots available
     int tlog_pass;           // resident launch: stamp this pass only (-1: every pass, the last one survives)
     int speculate;           // resident launch: prepare the next pass's hit list while the block waits for its message (see the end of the pass loop)
+    float spec_gain, spec_floor; // ... the guess: next displacement <= spec_gain x this one + spec_floor x the group box's extent
     unsigned long long* work; // diagnostic (icp_set_work_counting): NN_WORK_SLOTS device counters of the work the sparse kernel EXECUTES, or NULL
 };
 
@@ -1853,7 +1854,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                     acc += __builtin_fabsf(m) * __builtin_fmaxf(__builtin_fabsf(glo[b]), __builtin_fabsf(ghi[b]));
                     rt_t += rt.r[b * 3 + a] * rt.t[b];                                // (R^T t)_a
                 }
-                dl[a] = 2.f * (acc + __builtin_fabsf(rt_t)) + 1e-3f * (ghi[a] - glo[a]) + 1e-6f;
+                dl[a] = fuse.spec_gain * (acc + __builtin_fabsf(rt_t)) + fuse.spec_floor * (ghi[a] - glo[a]) + 1e-6f;
                 dn2 += dl[a] * dl[a];
                 sp_lo[a] = glo[a] - dl[a];
                 sp_hi[a] = ghi[a] + dl[a];
@@ -2408,7 +2409,7 @@ __global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64(const float* __
                 acc += __builtin_fabsf(mm) * __builtin_fmaxf(__builtin_fabsf(glo[b]), __builtin_fabsf(ghi[b]));
                 rt_t += rt.r[b * 3 + a] * rt.t[b];                               // (R^T t)_a
             }
-            const float dl = 2.f * (acc + __builtin_fabsf(rt_t)) + 1e-3f * (ghi[a] - glo[a]) + 1e-6f;
+            const float dl = fuse.spec_gain * (acc + __builtin_fabsf(rt_t)) + fuse.spec_floor * (ghi[a] - glo[a]) + 1e-6f;
             dn2 += dl * dl;
             sp_lo[a] = glo[a] - dl;
             sp_hi[a] = ghi[a] + dl;
@@ -4034,6 +4035,12 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             fuse.resident = ft->resident ? 1 : 0;
             const int env_spec = env_int("ICP_NN_SPECULATE", 1);   // (A/B runs and tests: 0 switches the speculative search of resident launches off)
             fuse.speculate = (ft->resident && env_spec) ? 1 : 0;
+            {
+                const char* g = getenv("ICP_SPEC_GAIN");
+                const char* f = getenv("ICP_SPEC_FLOOR");
+                fuse.spec_gain = g && *g ? (float)atof(g) : 2.0f;
+                fuse.spec_floor = f && *f ? (float)atof(f) : 1e-3f;
+            }
             fuse.store_first = ft->store_first ? 1 : 0;
         } else {
             for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];

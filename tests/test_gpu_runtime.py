@@ -205,6 +205,20 @@ def test_bench_under_torch_distributed_run():
     assert d["rccl"]["ranks"] == 2
 
 
+def test_bench_two_gpus_rccl_leg():
+    """on a box with two or more GPUs: two ranks on two devices, the RCCL leg must report a rate for both ranks"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's scaling run exercises this path)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ICP_BENCH_ONE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["rccl"]["ranks"] == 2 and d["rccl"].get("value", 0) > 0, d["rccl"]
+
+
 def test_bench_rccl_leg_single_rank():
     """the library-issued ncclAllReduce route, exercised with the one rank this box has"""
     d = _bench(["--steps", "120", "--warmup", "20", "--no-cpu-baseline"], {"ICP_BENCH_FORCE_DIST": "1"})
