@@ -1903,7 +1903,6 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
 // armed and resident launches, the speculative search during the wait.  One segment only (gridDim.y == 1).
 // ------------------------------------------------------------------------------------------------
 constexpr int R64_NW = 8;                                   // waves per block
-constexpr int R64_MAX_PASSES = SP_HCAP / (R64_NW * 64);     // find passes per round: the hit list holds a round's chunks
 
 // one hit chunk (LDS stage {box 8, x 8, y 8, z 8 (, model index 8)}) against the lane's ONE point, two model points per
 // packed operation; same tie rule as scan_hit.  The per-point box test is done by the caller for all of a wave's hits at
@@ -1981,12 +1980,14 @@ __device__ __forceinline__ void scan8_min1(const float4 qx0, const float4 qx1, c
 // instantiation squeezed to 80 VGPRs, three blocks per CU, so that Bunny.csv's 576 rows stay resident -- 47.3 us per
 // iteration against 45.7 us with rows of 128 and one armed launch per pass: that cloud's passes are decided by a few
 // hit-heavy blocks, which 8 waves work through more slowly than 16.  Not kept.)
-template <int TAIL, bool DIAG, bool PERM>
-__global__ __launch_bounds__(R64_NW * 64, 2) void nn_match_row64(const float* __restrict__ P, int n_pad, const float* __restrict__ Q,
+// NW: waves per block.  8 is the shipped geometry (two blocks fit a CU).  16 (ICP_NN_WAVES=16, only while every block can have
+// a CU of its own) halves the hits per wave once more, but such a block fills its CU: nothing else that must be resident --
+// another context's registration, another rank rehearsed on the same device -- fits beside it.
+template <int TAIL, bool DIAG, bool PERM, int NW = R64_NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64(const float* __restrict__ P, int n_pad, const float* __restrict__ Q,
                                                                  int m_pad, int round_passes, float* __restrict__ part_d,
                                                                  int32_t* __restrict__ part_idx, RT<float> rt_arg, NNFuse fuse, NNTail tail)
 {
-    constexpr int NW = R64_NW;
     constexpr int STG = PERM ? 40 : 32;  // floats per staged hit: box 8, x 8, y 8, z 8 (, model indices 8)
     constexpr int SMAX = 2048;           // cold start: samples staged per round
     constexpr int HITS_BYTES = SP_HCAP * 4, SAMPLE_BYTES = 3 * SMAX * 4;
@@ -4090,7 +4091,11 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         fuse.sample_groups = env_sgroups > 0 ? env_sgroups : (pl.m_pad <= 32768 ? 64 : 256);
         static const int env_passes = env_int("ICP_NN_PASSES", 0);
         // seeded: few hits, long rounds; cold: short rounds so that the exchanged minima start pruning early
-        const int max_passes = pl.row == 64 ? R64_MAX_PASSES : SP_MAX_PASSES;
+        static const int env_waves = env_int("ICP_NN_WAVES", 0);
+        int cus64 = 0, dev64 = 0;
+        if (pl.row == 64 && (hipGetDevice(&dev64) != hipSuccess || hipDeviceGetAttribute(&cus64, hipDeviceAttributeMultiprocessorCount, dev64) != hipSuccess)) cus64 = 256;
+        const int nw64 = (pl.row == 64 && env_waves == 16 && pl.blocks_x <= cus64) ? 16 : R64_NW;
+        const int max_passes = pl.row == 64 ? SP_HCAP / (nw64 * 64) : SP_MAX_PASSES;
         int passes = env_passes > 0 ? env_passes : ((fuse.seed_idx || fuse.samples) ? max_passes : 1);
         if (passes > max_passes) passes = max_passes;
         if (pl.row == 64) {
@@ -4098,11 +4103,12 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             if (pl.splits != 1 || pl.hier) return hipErrorInvalidValue;
             const bool diag = fuse.tlog != nullptr || fuse.work != nullptr, perm = fuse.q_perm != nullptr;
             const int tl = !ta ? 0 : (ta->metric == ICP_POINT_TO_PLANE ? 2 : 1);
-#define ICP_R64_FN(TL) {{(const void*)nn_match_row64<TL, false, false>, (const void*)nn_match_row64<TL, false, true>},   \
-                        {(const void*)nn_match_row64<TL, true, false>, (const void*)nn_match_row64<TL, true, true>}}
-            static const void* const fns[3][2][2] = {ICP_R64_FN(0), ICP_R64_FN(1), ICP_R64_FN(2)};
+#define ICP_R64_FN(TL, W) {{(const void*)nn_match_row64<TL, false, false, W>, (const void*)nn_match_row64<TL, false, true, W>},   \
+                           {(const void*)nn_match_row64<TL, true, false, W>, (const void*)nn_match_row64<TL, true, true, W>}}
+            static const void* const fns[2][3][2][2] = {{ICP_R64_FN(0, 8), ICP_R64_FN(1, 8), ICP_R64_FN(2, 8)},
+                                                        {ICP_R64_FN(0, 16), ICP_R64_FN(1, 16), ICP_R64_FN(2, 16)}};
 #undef ICP_R64_FN
-            const void* fn = fns[tl][diag ? 1 : 0][perm ? 1 : 0];
+            const void* fn = fns[nw64 == 16 ? 1 : 0][tl][diag ? 1 : 0][perm ? 1 : 0];
             const float* Pp = (const float*)P;
             const float* Qp = (const float*)Qsp;
             int n_pad = pl.n_pad, m_pad = pl.m_pad;
@@ -4112,7 +4118,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             if (fuse.resident) {
                 if (!ta) return hipErrorInvalidValue;
                 // every block must be on the machine at once (see below): blocks <= CUs x resident blocks per CU
-                const int variant = 100 + (tl * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0);
+                const int variant = 100 + (((nw64 == 16 ? 3 : 0) + tl) * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0);
                 long long cap = 0;
                 {
                     static std::mutex mu;
@@ -4123,7 +4129,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
                     long long& slot = capacity[std::make_pair(dev, variant)];
                     if (slot <= 0) {
                         int per_cu = 0, cus = 0;
-                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, R64_NW * 64, 0) != hipSuccess ||
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nw64 * 64, 0) != hipSuccess ||
                             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
                             return hipErrorCooperativeLaunchTooLarge;
                         slot = (long long)per_cu * cus;
@@ -4132,7 +4138,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
                 }
                 if ((long long)g64.x > cap) return hipErrorCooperativeLaunchTooLarge;
             }
-            return hipLaunchKernel(fn, g64, dim3(R64_NW * 64), args, 0, st);
+            return hipLaunchKernel(fn, g64, dim3(nw64 * 64), args, 0, st);
         }
         if (fuse.resident) {
             if (!ta || pl.splits != 1) return hipErrorInvalidValue;
