@@ -237,6 +237,9 @@ struct icp_ctx {
     DevBuf Qperm; // ... and its permutation: sorted position -> model index
     DevBuf Pperm; // slot -> moving point (Morton order of the initial positions), when the cloud's own order has no locality
     DevBuf slot_state; // armed launches: moving points + matched model points in slot order (6 x n_pad floats)
+    DevBuf share_counts;                        // shared rows (NNPlan::share_blocks): 5 x blocks_x hit counters (3 in rotation from launch to launch, 2 for first passes)
+    mutable unsigned long long share_seq = 0;   // ... the launches so far (advanced by the launcher)
+    mutable unsigned long long share_cold_seq = 0;   // ... and those that were the first pass of a registration
     bool model_sorted = false, moving_sorted = false;
     // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
     DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
@@ -292,7 +295,7 @@ struct icp_ctx {
     std::chrono::steady_clock::time_point rows_done_at{};   // when the host last saw a pass's rows complete (mailbox lease)
     bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
     bool arm = true;                   // ICP_ARMED=0: icp_loop_run never enqueues a pass ahead of its (R, t)
-    bool resident = true;              // ICP_RESIDENT=0: icp_loop_run never keeps one kernel for a whole registration
+    int resident = 1;                  // ICP_RESIDENT=0: icp_loop_run never keeps one kernel for a whole registration; 2: also where shared rows are preferred
     bool resident_refused = false;     // the resident kernel does not fit the machine with this plan: do not try again
     // ring of mailboxes for armed / resident launches, in pinned mapped host memory, and the device-memory relay.
     // (Fine-grained device memory written through the PCIe BAR is ~0.5 us faster per message and needs no relay --
@@ -364,6 +367,15 @@ int ensure_work_buffers(icp_ctx* c)
         if (tb > c->tickets.cap) {
             HIP_TRY(c->tickets.ensure(tb));
             HIP_TRY(hipMemsetAsync(c->tickets.p, 0, c->tickets.cap, c->stream));
+        }
+    }
+    if (pl.share_blocks > 0) {
+        const size_t sb = 5 * (size_t)pl.blocks_x * sizeof(unsigned int);
+        if (sb > c->share_counts.cap || before.blocks_x != pl.blocks_x || before.share_blocks != pl.share_blocks) {
+            HIP_TRY(c->share_counts.ensure(sb));
+            HIP_TRY(hipMemsetAsync(c->share_counts.p, 0, c->share_counts.cap, c->stream));   // "nothing known": every row is one block
+            c->share_seq = 0;
+            c->share_cold_seq = 0;
         }
     }
     // one error row per matching block row (fused transform) or per transform block
@@ -621,7 +633,7 @@ int icp_create(int device, icp_ctx** out)
     }
     if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
     if (const char* v = std::getenv("ICP_ARMED")) c->arm = !(v[0] == '0');
-    if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1);
     if (const char* v = std::getenv("ICP_TRACE")) { c->trace = v[0] == '1' || v[0] == '2'; c->trace_passes = v[0] == '2'; }
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
@@ -660,7 +672,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->work, &c->slot_state, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->work, &c->slot_state, &c->share_counts, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -974,6 +986,7 @@ static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
     if (c->count_work) o.work = (unsigned long long*)c->work.p;
+    if (c->plan.share_blocks > 0 && c->share_counts.p != nullptr) { o.share_counts = (unsigned int*)c->share_counts.p; o.share_seq = &c->share_seq; o.share_cold_seq = &c->share_cold_seq; }
     return o;
 }
 
@@ -1585,7 +1598,10 @@ bool can_reside(icp_ctx* c)
 {
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    return c->resident && (c->prec == ICP_F32 || pl.version == 3) && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
+    // (a plan with shared rows -- 33-65 k moving points -- runs one armed launch per pass: its 8-wave blocks would all fit the
+    // machine, but a resident kernel cannot move blocks to the heavy rows from pass to pass; measured on Bunny.csv: 55 us per
+    // iteration resident, 32 us armed with shared rows.  ICP_RESIDENT=2 keeps such a plan resident.)
+    return c->resident && (c->resident > 1 || pl.share_blocks == 0) && (c->prec == ICP_F32 || pl.version == 3) && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
            icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done;
 }
 

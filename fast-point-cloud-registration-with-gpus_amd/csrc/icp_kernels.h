@@ -31,6 +31,8 @@ struct NNPlan {
     int sparse;         // the geometry is the sparse kernel's (16-wave blocks of 128 moving points; needs chunk boxes)
     int hier;           // sparse kernel: two-level search (boxes of 64 chunks first) -- large models
     int row;            // sparse geometry: moving points per block row -- 128 (nn_match_sparse, 16 waves) or 64 (nn_match_row64, 8 waves)
+    int nw;             // rows of 128: waves per block -- 16, or 8 (two blocks per CU: clouds whose rows outnumber the CUs; launches with a fused tail)
+    int share_blocks;   // rows of 128, 8 waves, one launch per pass: blocks of a launch (> blocks_x: the spare ones go to the heavy rows), or 0
 };
 int nn_block_threads(const NNPlan& pl);
 
@@ -118,6 +120,12 @@ struct NNCullInputs {
     // diagnostic (sparse kernel): NN_WORK_SLOTS device counters of the work the kernel executes -- the launch then uses
     // the instrumented instantiation.  NULL (the default): the production kernel, nothing is counted.
     unsigned long long* work = nullptr;
+    // shared rows (NNPlan::share_blocks): 5 x blocks_x device counters, zero before the first launch (three in rotation from
+    // launch to launch, two alternating between the first passes of registrations), and the context's counters of both kinds
+    // of launches (host; the launcher advances them).  NULL: every row is one block.
+    unsigned int* share_counts = nullptr;
+    unsigned long long* share_seq = nullptr;
+    unsigned long long* share_cold_seq = nullptr;
 };
 // What the sparse kernel EXECUTED (it returns the brute-force answer without evaluating most pairs): wave-level tallies.
 // One "hit" = one 8-point model chunk processed by one wave = 64 lanes x 2 moving points against that chunk.

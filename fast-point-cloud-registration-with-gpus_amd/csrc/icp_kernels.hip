@@ -435,6 +435,7 @@ struct NNTail {
     // drained, exactly as the separate tag word was.
     int compact;
     unsigned int tag_lo;       // low 32 bits of `tag` as an integer (a double -> integer conversion on the device expands to f64 fma code)
+    int row;                   // the row this block closes, or -1: blockIdx.x (shared rows: a block's row is not its index)
 };
 __device__ __forceinline__ double crow_pack(double err, unsigned int tag_lo)
 {
@@ -495,6 +496,15 @@ struct NNFuse {
     int speculate;           // resident launch: prepare the next pass's hit list while the block waits for its message (see the end of the pass loop)
     float spec_gain, spec_floor; // ... the guess: next displacement <= spec_gain x this one + spec_floor x the group box's extent
     unsigned long long* work; // diagnostic (icp_set_work_counting): NN_WORK_SLOTS device counters of the work the sparse kernel EXECUTES, or NULL
+    // shared rows (nn_match_sparse, one launch per pass, more blocks than rows): hits per row of the PREVIOUS launch decide how
+    // many blocks work on each row of this one -- see the kernel; NULL: one block per row (per model segment)
+    const unsigned int* share_prev;
+    unsigned int* share_cur;   // ... this launch's hits per row (added up by its blocks; zero when it starts)
+    unsigned int* share_next;  // ... zeroed by this launch for the next one
+    unsigned int* share_cur2;  // ... a second copy of this launch's counts (the first pass of a registration: kept for the next registration's first pass) or NULL
+    unsigned int* share_zero2; // ... a second array to zero (the one the next first pass will add to) or NULL
+    int share_rows;            // rows of the launch (<= threads of a block)
+    int share_min;             // a part is never made smaller than this many hits (of the previous launch)
 };
 
 // phase stamp of the diagnostic log: one scalar branch when the log is off
@@ -824,6 +834,11 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
 constexpr int SP_NW = 16;                       // waves per block
 constexpr int SP_HCAP = 4096;                   // hit-list entries = chunks per round (SP_NW * 64 * passes <= this)
 constexpr int SP_MAX_PASSES = SP_HCAP / (SP_NW * 64);
+// flat search (models below 2^19 points = 65 536 chunks): the list holds 16-bit chunk numbers, twice as many in the same
+// 16 KB -- a model of up to 65 536 points is one round of the find (Bunny.csv: 5040 chunks, two rounds with 4096 entries)
+constexpr int SP_HCAP_FLAT = 2 * SP_HCAP;
+template <bool HIER> struct SpHit { using type = unsigned short; };
+template <> struct SpHit<true> { using type = int; };
 
 // one hit chunk against the lane's packed pair; (best, bj) follow the lexicographic (distance, MODEL index) rule:
 // the chunk takes a point's minimum if its own minimum is smaller, or equal with a lower model index.
@@ -1070,7 +1085,8 @@ __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, co
     constexpr int w = 0, phase_nw_ = NWP;  // (phase log) the closing wave of a sparse-kernel block
     constexpr int NACC = TAIL == 2 ? 28 : 18;
     lds_same_wave_order();
-    double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
+    const unsigned int rowi = tail.row >= 0 ? (unsigned int)tail.row : blockIdx.x;
+    double* row = tail.rows + (size_t)rowi * ICP_NMOM;
     // Slot k is the sum of its 64 lane entries in a FIXED order: PARTS lanes per slot add a contiguous share each
     // (loaded first, added after: the LDS latencies overlap), the shares are then added in part order.
     constexpr int PARTS = 64 / NACC, PER = (64 + PARTS - 1) / PARTS;
@@ -1096,7 +1112,7 @@ __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, co
     // read the row as soon as it sees the tag.  (No L2 write-back here -- it would flush the whole cache for the
     // sake of 19 doubles; the other outputs of the pass are for later kernels and become visible at kernel end.)
     const bool compact = TAIL == 1 && tail.compact != 0;
-    if (compact) row = tail.rows + (size_t)blockIdx.x * NN_CROW;
+    if (compact) row = tail.rows + (size_t)rowi * NN_CROW;
     if (lane < NACC) {
         double sum = tp[lane];
 #pragma unroll
@@ -1118,51 +1134,151 @@ __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, co
 // HIER: two-level search (large models): boxes of 64 chunks are tested first, lane-parallel like the chunks, and only
 // the chunks of the surviving ones after them -- compiled apart for the same reason (the extra level costs a small
 // model more than it saves)
-template <int TAIL, bool DIAG, bool PERM, bool HIER = false>
-__global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __restrict__ P, int n_pad,
+template <int TAIL, bool DIAG, bool PERM, bool HIER = false, int NWS = SP_NW>
+__global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(const float* __restrict__ P, int n_pad,
                                                               const float* __restrict__ Q, int m_pad, int seg_len,
                                                               int round_passes, float* __restrict__ part_d,
                                                               int32_t* __restrict__ part_idx, RT<float> rt_arg, NNFuse fuse,
                                                               NNTail tail)
 {
     constexpr int STG = PERM ? 40 : 32;  // floats per staged hit: box 8, x 8, y 8, z 8 (, model indices 8)
-    constexpr int HITS_BYTES = SP_HCAP * 4, MD_BYTES = SP_NW * 128 * 4;
+    // The head of the block's LDS is an overlay: the hit list, under it the cold start's sample stage (3 x SMAX floats, used
+    // before there is a list) and the tail's transpose buffer (after it), and behind both the 128 merge keys.  16 waves:
+    // 2048 samples, 32 KB in all.  8 waves (two blocks share a CU's 160 KB): 1024 samples, so that the keys follow the
+    // hit list directly -- 17 KB.
+    constexpr int SMAX = NWS == 8 ? 1024 : 2048;
+    constexpr int HITS_BYTES = SP_HCAP * 4, MQ_BYTES = NWS * 128 * 4;
+    constexpr int MKEY_OFF = 3 * SMAX * 4 > HITS_BYTES ? 3 * SMAX * 4 : HITS_BYTES;
+    constexpr int OVL_BYTES = NWS == 8 ? MKEY_OFF + 128 * 8 : HITS_BYTES + 2 * SP_NW * 128 * 4;
     constexpr int TR_BYTES = TAIL ? ((TAIL == 2 ? 28 : 18) * 65 + 64) * 8 : 0;
     static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
-    constexpr int STAGE_OFF = HITS_BYTES + 2 * MD_BYTES + 128 * 4 + 16, STAGE_BYTES = SP_NW * 8 * STG * 4;
+    constexpr int STAGE_OFF = OVL_BYTES + 128 * 4 + 16, STAGE_BYTES = NWS * 8 * STG * 4;
     constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
-    constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x SP_NW x 128
+    constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x NWS x 128
     // flat search: the chunk boxes of every wave's first PRE find passes are cached in LDS (the model does not change during
     // a resident launch; in registers they cost 16 VGPRs the kernel does not have): [wave][pass][half][lane] float4
     constexpr int PRE = 2;
-    constexpr int BOXC_OFF = MQ_OFF + 3 * MD_BYTES, BOXC_BYTES = HIER ? 0 : SP_NW * PRE * 2 * 64 * 16;
-    constexpr int SPST_OFF = BOXC_OFF + BOXC_BYTES, SPST_BYTES = HIER ? 0 : SP_NW * 8 * 4;   // per wave: what its speculative list was built for
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SPST_OFF + SPST_BYTES + (HIER ? SP_NW * 64 * 4 : 0)];  // (+ the level-3 hit list)
-    int* hits = reinterpret_cast<int*>(lds_raw);
+    constexpr int BOXC_OFF = MQ_OFF + 3 * MQ_BYTES, BOXC_BYTES = HIER ? 0 : NWS * PRE * 2 * 64 * 16;
+    constexpr int SPST_OFF = BOXC_OFF + BOXC_BYTES, SPST_BYTES = HIER ? 0 : NWS * 8 * 4;   // per wave: what its speculative list was built for
+    constexpr int ROLE_OFF = SPST_OFF + SPST_BYTES + (HIER ? NWS * 64 * 4 : 0);   // (+ the level-3 hit list) then: the block's role {row, part, parts, -} and 2 x NWS wave totals
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[ROLE_OFF + (4 + 2 * NWS) * 4];
+    using hit_t = typename SpHit<HIER>::type;
+    hit_t* hits = reinterpret_cast<hit_t*>(lds_raw);
     // merge scratch: one (distance, index, wave) key per moving point, folded with LDS atomic mins -- the 64-bit
     // integer order is the lexicographic order the tie rule needs (d >= 0; index < 2^28; the wave id rides in the
     // low 4 bits and tells the closing wave whose coordinates to pick up)
     // (placed behind the 24 KB the cold start stages its samples in)
-    unsigned long long* mkey = reinterpret_cast<unsigned long long*>(lds_raw + 3 * 2048 * 4);
-    static_assert(3 * 2048 * 4 + 128 * 8 <= HITS_BYTES + 2 * MD_BYTES, "merge keys fit behind the sample stage");
-    unsigned int* smin = reinterpret_cast<unsigned int*>(lds_raw + HITS_BYTES + 2 * MD_BYTES);
-    int* hcount = reinterpret_cast<int*>(lds_raw + HITS_BYTES + 2 * MD_BYTES + 128 * 4);
+    unsigned long long* mkey = reinterpret_cast<unsigned long long*>(lds_raw + MKEY_OFF);
+    static_assert(MKEY_OFF + 128 * 8 <= OVL_BYTES, "merge keys fit behind the sample stage");
+    unsigned int* smin = reinterpret_cast<unsigned int*>(lds_raw + OVL_BYTES);
+    int* hcount = reinterpret_cast<int*>(lds_raw + OVL_BYTES + 128 * 4);
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ibase = blockIdx.x * 128 + lane;   // the block's slots; the moving point in slot s is p_perm[s] (spatially sorted groups)
+    // ---- the block's role: which row of 128 moving points, and which share of the model's chunks --------------------
+    // Ordinarily block (x, y) searches model segment y for row x.  SHARED ROWS (one launch per pass, a grid of more blocks
+    // than rows, one segment): a cloud of 33-65 k points has more rows than the machine has CUs but fewer than it has room
+    // for 8-wave blocks, and the time of a pass is set by its heaviest rows (Bunny.csv: 83 hit chunks per row on average
+    // late in a registration, 1100-4200 on the heaviest).  So the spare blocks go to the rows that need them: every block
+    // reads the hits each row had in the PREVIOUS launch (which row is heavy changes slowly), computes -- all blocks the
+    // same numbers -- parts(row) = ceil(hits / T) with T = max(ceil(total / spare), one batch per wave), and takes the
+    // role its own index falls on in the running sum.  The parts of a row interleave the model's 64-chunk tiles
+    // (part p searches tiles p, p + parts, ...), fold their results into the row's 64-bit (distance, index) keys and
+    // draw a ticket; the last one closes the row (the protocol of the segment blocks).  Any assignment is exact; the
+    // counts only decide how even the load is.  Blocks beyond the sum have no role and end at once.
+    // (the role of a shared-row block lives in LDS and is read where it is needed: the kernel has no scalar registers to
+    // carry it through the pass loop)
+    int* role = reinterpret_cast<int*>(lds_raw + ROLE_OFF);
+#define SP_SHARED (!HIER && TAIL != 0 && fuse.share_prev != nullptr)
+#define SP_ROW (SP_SHARED ? __builtin_amdgcn_readfirstlane(role[0]) : (int)blockIdx.x)
+#define SP_PART (SP_SHARED ? __builtin_amdgcn_readfirstlane(role[1]) : (int)blockIdx.y)
+#define SP_PARTS (SP_SHARED ? __builtin_amdgcn_readfirstlane(role[2]) : (int)gridDim.y)
+    if constexpr (!HIER && TAIL != 0) {
+        if (fuse.share_prev != nullptr) {
+            const int R = fuse.share_rows, t = threadIdx.x;
+            // (the counts were made by agent-scope atomics of the previous launch, at the memory side: they are read the same
+            // way -- a plain load may be served by a stale line of this XCD's L2, and blocks that disagree about the counts
+            // disagree about the roles)
+            const unsigned int h = t < R ? __hip_atomic_load(&fuse.share_prev[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (blockIdx.x == 0 && t < R) {
+                __hip_atomic_store(&fuse.share_next[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fuse.share_zero2 != nullptr) __hip_atomic_store(&fuse.share_zero2[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            unsigned int hs = h;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) hs += (unsigned int)__shfl_xor((int)hs, off, 64);
+            if (lane == 0) role[4 + w] = (int)hs;
+            if (t == 0) role[0] = -1;
+            __syncthreads();
+            unsigned int total = 0;
+#pragma unroll
+            for (int k = 0; k < NWS; ++k) total += (unsigned int)role[4 + k];
+            const unsigned int spare = gridDim.x > (unsigned)R ? gridDim.x - (unsigned)R : 0u;
+            // T0 = ceil(total / spare) always fits (sum of ceil(h / T0) <= total / T0 + rows), but leaves blocks unused -- the
+            // rounding costs half a block per split row, not a whole one.  Four tighter targets, 4/8 .. 7/8 of T0, are tried
+            // at once (their block counts added up in one reduction); the smallest one that fits is taken.
+            const unsigned int T0 = spare ? (total + spare - 1u) / spare : 0xffffffffu;
+            const unsigned int tiles = (unsigned)((((m_pad >> 3) + 63) >> 6));
+            const unsigned int cap = tiles < 32u ? tiles : 32u;
+            auto parts_for = [&](unsigned int T) {
+                unsigned int S = (h + T - 1u) / T;
+                S = S > cap ? cap : S;
+                return t < R ? (S < 1u ? 1u : S) : 0u;
+            };
+            const unsigned int Tmin = (unsigned int)fuse.share_min;
+            unsigned int T = T0 < Tmin ? Tmin : T0;
+            if (spare && T0 > Tmin && T0 < 0x10000000u) {
+                unsigned int c01 = 0, c23 = 0;   // two 16-bit counts each (<= 512 rows x 32 parts)
+                {
+                    const unsigned int Ta = (T0 * 4u + 7u) / 8u, Tb = (T0 * 5u + 7u) / 8u, Tc = (T0 * 6u + 7u) / 8u, Td = (T0 * 7u + 7u) / 8u;
+                    c01 = parts_for(Ta) | (parts_for(Tb) << 16);
+                    c23 = parts_for(Tc) | (parts_for(Td) << 16);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    c01 += (unsigned int)__shfl_xor((int)c01, off, 64);
+                    c23 += (unsigned int)__shfl_xor((int)c23, off, 64);
+                }
+                __syncthreads();   // (the wave totals of the hits have been read)
+                if (lane == 0) { role[4 + w] = (int)c01; role[4 + NWS + w] = (int)c23; }
+                __syncthreads();
+                unsigned int s01 = 0, s23 = 0;
+#pragma unroll
+                for (int k = 0; k < NWS; ++k) { s01 += (unsigned int)role[4 + k]; s23 += (unsigned int)role[4 + NWS + k]; }
+                __syncthreads();   // (... and these: the running sums below use the same words)
+                const unsigned int G = gridDim.x;
+                const unsigned int Tbest = (s01 & 0xffffu) <= G ? (T0 * 4u + 7u) / 8u : (s01 >> 16) <= G ? (T0 * 5u + 7u) / 8u :
+                                           (s23 & 0xffffu) <= G ? (T0 * 6u + 7u) / 8u : (s23 >> 16) <= G ? (T0 * 7u + 7u) / 8u : T0;
+                T = Tbest < Tmin ? Tmin : Tbest;
+            }
+            const unsigned int S = parts_for(T);
+            int v = (int)S;   // inclusive running sum within the wave, then across the waves
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); v += lane >= o ? u : 0; }
+            if (lane == 63) role[4 + NWS + w] = v;
+            __syncthreads();
+            int base = 0;
+#pragma unroll
+            for (int k = 0; k < NWS; ++k) base += k < w ? role[4 + NWS + k] : 0;
+            const int excl = base + v - (int)S;
+            if (t < R && (int)blockIdx.x >= excl && (int)blockIdx.x < excl + (int)S) { role[0] = t; role[1] = (int)blockIdx.x - excl; role[2] = (int)S; if constexpr (DIAG) { role[3] = (int)h; role[4] = (int)T; } }
+            __syncthreads();
+            if (role[0] < 0) return;
+        }
+    }
+    const int ibase = SP_ROW * 128 + lane;   // the block's slots; the moving point in slot s is p_perm[s] (spatially sorted groups)
     int pi[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) pi[t] = fuse.p_perm ? fuse.p_perm[ibase + t * 64] : ibase + t * 64;
     float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * STG);  // per wave: 8 hits x {box 8, x 8, y 8, z 8, model index 8}
     float* msg = reinterpret_cast<float*>(lds_raw + MSG_OFF);
     float (*seedq)[128] = reinterpret_cast<float (*)[128]>(lds_raw + SEED_OFF);
-    float (*mq)[SP_NW][128] = reinterpret_cast<float (*)[SP_NW][128]>(lds_raw + MQ_OFF);
+    float (*mq)[NWS][128] = reinterpret_cast<float (*)[NWS][128]>(lds_raw + MQ_OFF);
     int phase_pass_ = 0;  // (phase log)
-    constexpr int phase_nw_ = SP_NW;
+    constexpr int phase_nw_ = NWS;
     constexpr bool phase_diag_ = DIAG;
     ICP_PHASE(0)
-    const int q0 = blockIdx.y * seg_len;
+    const int q0 = SP_SHARED ? 0 : (int)blockIdx.y * seg_len;
     const int c_lo = q0 / 8, c_hi = min(q0 + seg_len, m_pad) / 8;
     // issued first, with everything else that does not depend on the points:
     // the seed gather does not depend on the points (the compiler cannot move these loads above the
@@ -1224,7 +1340,8 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         pb1 = bp[1];
     } else {
         static_assert(PRE == 2, "two passes are fetched together");
-        const int ca = c_lo + w * 64 + lane, cb = ca + SP_NW * 64;
+        const int tparts = SP_SHARED ? SP_PARTS : 1, tpart = SP_SHARED ? SP_PART : 0;   // (shared rows: the parts interleave the chunks, see find_round)
+        const int ca = c_lo + (w * 64 + lane) * tparts + tpart, cb = ca + NWS * 64 * tparts;
         const float4* bpa = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(ca < c_hi ? ca : 0) * 8);
         const float4* bpb = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(cb < c_hi ? cb : 0) * 8);
         const float4 a0 = bpa[0], a1 = bpa[1], b0 = bpb[0], b1 = bpb[1];
@@ -1321,13 +1438,13 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             float x = t ? px.y : px.x, y = t ? py.y : py.x, z = t ? pz.y : pz.x;
             apply_rt<float>(rt, x, y, z, x, y, z);
             if (t) { px.y = x; py.y = y; pz.y = z; } else { px.x = x; py.x = y; pz.x = z; }
-            if (blockIdx.y == 0 && w == 0) {
+            if (w == 0 && SP_PART == 0) {
                 const int i = fresh(pi[t]);
                 fuse.P_out[i] = x;
                 fuse.P_out[(size_t)n_pad + i] = y;
                 fuse.P_out[2 * (size_t)n_pad + i] = z;
                 if (fuse.slot_state != nullptr) {   // (and in slot order, for the next pass's front end)
-                    float* ss = fuse.slot_state + (fresh((int)blockIdx.x * 128) + lane + t * 64);   // (recomputed: no register held for it)
+                    float* ss = fuse.slot_state + (fresh(SP_ROW * 128) + lane + t * 64);   // (recomputed: no register held for it)
                     ss[0] = x; ss[(size_t)n_pad] = y; ss[2 * (size_t)n_pad] = z;
                 }
                 if (i < fuse.n) {
@@ -1342,19 +1459,19 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 }
             }
         }
-        if (blockIdx.y == 0 && w == 0) {
+        if (w == 0 && SP_PART == 0) {
             err_row = wave_sum(err);
             if (lane == 0) {
                 if constexpr (TAIL != 0) {
                     // read by whichever block closes this row: agent-scope store, drained before our ticket
-                    if (gridDim.y > 1) __hip_atomic_store(&tail.err_tile[blockIdx.x], err_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (SP_PARTS > 1) __hip_atomic_store(&tail.err_tile[SP_ROW], err_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
-                    fuse.err_rows[blockIdx.x] = err_row;
+                    fuse.err_rows[SP_ROW] = err_row;
                 }
             }
         }
     }
-    if (!apply && pass == 0 && fuse.store_first && blockIdx.y == 0 && w == 0) {
+    if (!apply && pass == 0 && fuse.store_first && w == 0 && SP_PART == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int i = fresh(pi[t]);
@@ -1365,16 +1482,17 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     }
     ICP_PHASE(1)
     if (cmd == ICP_CMD_TRANSFORM_ONLY) {
+        const int row_ = SP_ROW;
         // the loop's last pass: nothing is matched any more, the row carries the error alone
         if constexpr (TAIL != 0) {
-            if (w == 0) {
+            if (w == 0 && SP_PART == 0) {
                 if (TAIL == 1 && tail.compact != 0) {
-                    double* row = tail.rows + (size_t)blockIdx.x * NN_CROW;
+                    double* row = tail.rows + (size_t)row_ * NN_CROW;
                     if (lane >= 1 && lane < NN_CROW) __hip_atomic_store(&row[lane], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(&row[0], crow_pack(err_row, row_tag_lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else {
-                    double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
+                    double* row = tail.rows + (size_t)row_ * ICP_NMOM;
                     if (lane < ICP_NMOM - 1) row[lane] = lane == ICP_MOM_ERR ? err_row : 0.0;
                     __threadfence_system();
                     if (lane == 0) __hip_atomic_store(&row[ICP_NMOM - 1], row_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1409,8 +1527,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         // with 2048 instead of 512).  On a small model that many samples cost as much as they save unless the
         // relative-index seeds are poor (hall scan against its slightly moved self: 13.8 -> 12.0 us with 64 samples;
         // a 128 x 128 grid against a copy 0.8 away: 73 -> 53 us with 2048), so a probe round of 8 groups decides.
-        constexpr int SMAX = 2048;
-        static_assert(3 * SMAX * 4 <= HITS_BYTES + 2 * MD_BYTES, "the staged samples overlay the hit list and merge scratch");
+        static_assert(3 * SMAX * 4 <= MKEY_OFF, "the staged samples overlay the hit list and merge scratch");
         const int ns8 = ((m_pad / 8) + 7) / 8;                 // groups of 8 samples in the array
         const int ns_pad = ns8 * 8;
         float* sl = reinterpret_cast<float*>(lds_raw);         // [3][SMAX]
@@ -1424,14 +1541,14 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             // one round over <= gcap groups spread evenly over the model
             const int gs = (ns8 + gcap - 1) / gcap;            // group stride: <= gcap groups are staged
             const int ng = (ns8 + gs - 1) / gs;
-            for (int v = threadIdx.x; v < ng * 6; v += SP_NW * 64) {
+            for (int v = threadIdx.x; v < ng * 6; v += NWS * 64) {
                 const int gp = v / 6, r = v % 6, a = r >> 1, hh = r & 1;
                 *reinterpret_cast<float4*>(sl + a * SMAX + gp * 8 + hh * 4) =
                     *reinterpret_cast<const float4*>(fuse.samples + (size_t)a * ns_pad + (size_t)gp * gs * 8 + hh * 4);
             }
             __syncthreads();
             float sb[2] = {inf_<float>(), inf_<float>()};
-            for (int gp = w; gp < ng; gp += SP_NW) {
+            for (int gp = w; gp < ng; gp += NWS) {
                 const float4* a = reinterpret_cast<const float4*>(sl + gp * 8);
                 const float4* b = reinterpret_cast<const float4*>(sl + SMAX + gp * 8);
                 const float4* c = reinterpret_cast<const float4*>(sl + 2 * SMAX + gp * 8);
@@ -1462,24 +1579,25 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     float ghi[3] = {__builtin_fmaxf(px.x, px.y), __builtin_fmaxf(py.x, py.y), __builtin_fmaxf(pz.x, pz.y)};
     wave_box(glo, ghi);
 
-    const int round_chunks = SP_NW * 64 * round_passes;
+    const int round_tiles = NWS * round_passes;                                         // 64-chunk tiles a round of the find covers
+    // ... and the tiles this block searches (shared rows: every parts-th one)
+    const int own_tiles = SP_SHARED ? (((c_hi - c_lo - SP_PART + SP_PARTS - 1) / SP_PARTS) + 63) >> 6 : ((c_hi - c_lo + 63) >> 6);
     float B0_pass = -1.f;   // (flat search) the largest starting bound of this pass
-    // one find pass: lane l tests chunk c0 + l (box b0 = lo.xyz hi.x, b1 = hi.yz - -) and appends it to the hit list
-    auto find_pass = [&](int c0, const float4 b0, const float4 b1, float B, const float (&gl)[3], const float (&gh)[3]) {
-        const int cidx = c0 + lane;
+    // one find pass: the lane tests chunk cidx (box b0 = lo.xyz hi.x, b1 = hi.yz - -) and appends it to the hit list
+    auto find_pass = [&](const int cidx, const float4 b0, const float4 b1, float B, const float (&gl)[3], const float (&gh)[3]) {
         const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - gh[0], gl[0] - b0.w), 0.f);
         const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - gh[1], gl[1] - b1.x), 0.f);
         const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - gh[2], gl[2] - b1.y), 0.f);
         const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;
         const bool pass = cidx < c_hi && L < B;  // every candidate winner lies strictly below its point's starting bound
-        if constexpr (DIAG) wk_find += (unsigned int)max(0, min(64, c_hi - c0));
+        if constexpr (DIAG) wk_find += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cidx < c_hi));
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
         if (mask != 0ull) {
             int base = 0;
             if (lane == 0) base = atomicAdd(hcount, (int)__builtin_popcountll(mask));
             base = __builtin_amdgcn_readfirstlane(base);
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            if (pass) hits[base + rank] = cidx;
+            if (pass) hits[base + rank] = (hit_t)cidx;
         }
     };
     // The hits are dealt round-robin; a wave fetches the box and the coordinates of up to 8 of its hits with ONE
@@ -1489,9 +1607,9 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     auto gather_batch = [&](const int hb, const int h1) {
             {
                 const int r = lane >> 3, part = lane & 7;
-                const int h = hb + r * SP_NW + w;
+                const int h = hb + r * NWS + w;
                 if (h < h1) {
-                    const int chl = hits[h];
+                    const int chl = (int)hits[h];
                     const float* src = part < 2 ? fuse.boxes + (size_t)chl * 8 + part * 4
                                                 : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)chl * 8 + (part & 1) * 4;
                     *reinterpret_cast<float4*>(stage + r * STG + part * 4) = *reinterpret_cast<const float4*>(src);
@@ -1499,23 +1617,23 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 // a sorted view: the elements' model indices (the sort permutation) are staged too
                 if constexpr (PERM) {
                     const int r2 = lane >> 1, half = lane & 1;
-                    const int h2 = hb + r2 * SP_NW + w;
+                    const int h2 = hb + r2 * NWS + w;
                     if (lane < 16 && h2 < h1)
                         *reinterpret_cast<int4*>(stage + r2 * STG + 32 + half * 4) =
-                            *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)hits[h2] * 8 + half * 4);
+                            *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)(int)hits[h2] * 8 + half * 4);
                 }
             }
             lds_same_wave_order();
     };
     auto scan_batch = [&](const int hb, const int h1) {
-            const int mine = (h1 - hb - w + SP_NW - 1) / SP_NW;     // this wave's hits in the batch
+            const int mine = (h1 - hb - w + NWS - 1) / NWS;     // this wave's hits in the batch
             const int cnt = mine < 8 ? mine : 8;
             for (int rr = 0; rr < cnt; ++rr) {
                 int stage_reached;
                 if constexpr (PERM) {
                     stage_reached = scan_hit<true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
                 } else {
-                    const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * SP_NW + w]);
+                    const int ch = __builtin_amdgcn_readfirstlane((int)hits[hb + rr * NWS + w]);
                     stage_reached = scan_hit<false>(stage + rr * STG, ch, px, py, pz, best, bj, bq);
                 }
                 if constexpr (DIAG) {
@@ -1526,9 +1644,19 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             }
             lds_same_wave_order();
     };
+    // (phase log, flat search: wave 2 of every block stamps "the list is complete" and "the first batch is fetched" in slots 6, 7)
+    auto sub_stamp = [&](int k) {
+        if constexpr (DIAG && !HIER) {
+            if (fuse.tlog != nullptr && w == 2 && lane == 0 && (fuse.tlog_pass < 0 || fuse.tlog_pass == phase_pass_)) {
+                const long long slot_ = (((long long)blockIdx.y * gridDim.x + blockIdx.x) * phase_nw_ + w) * 10 + k;
+                if (slot_ < fuse.tlog_cap) fuse.tlog[slot_] = (long long)wall_clock64();
+            }
+        }
+    };
     auto process_hits = [&](const int h1) {
-        for (int hb = 0; hb < h1; hb += SP_NW * 8) {
+        for (int hb = 0; hb < h1; hb += NWS * 8) {
             gather_batch(hb, h1);
+            if (hb == 0) sub_stamp(7);
             scan_batch(hb, h1);
         }
     };
@@ -1546,26 +1674,36 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         }
     };
     // one round of the find: every wave tests its share of the round's chunks against the group box (gl, gh) and the bound B
-    auto find_round = [&](int rb, float B, const float (&gl)[3], const float (&gh)[3]) {
+    // (tb: the round's first tile, counted in the block's OWN chunks, 64 to a tile: own chunk u is chunk c_lo + u of the segment,
+    // or -- shared rows -- chunk u * parts + part of the model: the parts of a row interleave chunk by chunk, so that the hits
+    // of a row, which cluster, fall to its parts evenly)
+    auto find_round = [&](int tb, float B, const float (&gl)[3], const float (&gh)[3]) {
+        const int tparts = SP_SHARED ? SP_PARTS : 1, tpart = SP_SHARED ? SP_PART : 0;
         int r = 0;
-        if (rb == c_lo) {  // the first round's first passes use the boxes fetched at kernel entry
+        if (tb == 0) {  // the first round's first passes use the boxes fetched at kernel entry
 #pragma unroll
             for (; r < PRE; ++r) {
-                const int c0 = rb + (r * SP_NW + w) * 64;
+                const int cidx = c_lo + ((r * NWS + w) * 64 + lane) * tparts + tpart;
                 if constexpr (!HIER)
-                    if (r < round_passes && c0 < c_hi) find_pass(c0, boxc[r][0][lane], boxc[r][1][lane], B, gl, gh);
+                    if (r < round_passes && c_lo + ((r * NWS + w) * 64) * tparts + tpart < c_hi) find_pass(cidx, boxc[r][0][lane], boxc[r][1][lane], B, gl, gh);
             }
         }
-        // (the boxes of two passes are requested together: one memory latency for both)
-        for (; r < round_passes; r += 2) {
-            const int c0 = rb + (r * SP_NW + w) * 64, c1 = c0 + SP_NW * 64;
-            if (c0 >= c_hi) break;
-            const bool two = r + 1 < round_passes && c1 < c_hi;
-            const float4* bp0 = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
-            const float4* bp1 = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(two && c1 + lane < c_hi ? c1 + lane : c_lo) * 8);
-            const float4 a0 = bp0[0], a1 = bp0[1], d0 = bp1[0], d1 = bp1[1];
-            find_pass(c0, a0, a1, B, gl, gh);
-            if (two) find_pass(c1, d0, d1, B, gl, gh);
+        // (the boxes of four passes are requested together: one memory latency for all of them)
+        for (; r < round_passes; r += 4) {
+            int cidx[4];
+            float4 b0[4], b1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cidx[q] = c_lo + ((tb + (r + q) * NWS + w) * 64 + lane) * tparts + tpart;
+                const bool on = r + q < round_passes && cidx[q] < c_hi;
+                const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(on ? cidx[q] : c_lo) * 8);
+                b0[q] = bp[0]; b1[q] = bp[1];
+                cidx[q] = on ? cidx[q] : c_hi;   // (a pass that is not this round's lists nothing)
+            }
+            if (__builtin_amdgcn_readfirstlane(cidx[0]) >= c_hi) break;   // (lane 0 holds the pass's first chunk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (__builtin_amdgcn_readfirstlane(cidx[q]) < c_hi) find_pass(cidx[q], b0[q], b1[q], B, gl, gh);
         }
     };
     if constexpr (HIER) {
@@ -1576,9 +1714,9 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         // a chunk that passes its own test has ancestors that pass too: the hit list is the one the flat search
         // builds, the model is just not read where it cannot matter (10 M-point model: 40 MB of chunk boxes per
         // block -> 10 KB of level-3 boxes + the children of a few survivors).
-        constexpr int SCAP = 2 * SP_NW * 64;   // super-box hit list: the children of 32 level-3 boxes
-        constexpr int TCAP = SP_NW * 64;       // level-3 hit list = level-3 boxes per outermost round (33 M model points)
-        static_assert(SCAP * 4 <= 3 * 2048 * 4 - HITS_BYTES, "the super-box hit list lies between the chunk hit list and the merge keys");
+        constexpr int SCAP = 2 * NWS * 64;   // super-box hit list: the children of 32 level-3 boxes
+        constexpr int TCAP = NWS * 64;       // level-3 hit list = level-3 boxes per outermost round (33 M model points)
+        static_assert(SCAP * 4 <= MKEY_OFF - HITS_BYTES, "the super-box hit list lies between the chunk hit list and the merge keys");
         int* shits = reinterpret_cast<int*>(lds_raw + HITS_BYTES);
         int* thits = reinterpret_cast<int*>(lds_raw + SPST_OFF + SPST_BYTES);
         int* scount = hcount + 1;
@@ -1626,11 +1764,11 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
             }
             __syncthreads();   // the level-3 list is complete
             const int TH = *tcount;
-            for (int tg = 0; tg < TH; tg += 2 * SP_NW) {
+            for (int tg = 0; tg < TH; tg += 2 * NWS) {
                 // level 2: the children of up to 32 level-3 survivors, two per wave
                 const float Bs = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
-                const int tend = min(tg + 2 * SP_NW, TH);
-                for (int k = tg + w; k < tend; k += SP_NW) {
+                const int tend = min(tg + 2 * NWS, TH);
+                for (int k = tg + w; k < tend; k += NWS) {
                     const int sidx = (thits[k] << 6) + lane;
                     const bool in = sidx >= s_lo && sidx < s_hi;
                     const float4* bp = reinterpret_cast<const float4*>(sboxes + (size_t)(in ? sidx : s_lo) * 8);
@@ -1647,10 +1785,10 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                     const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
                     if (list_dirty && sh0 != 0) __syncthreads();  // (sh0 == 0: the barrier above)
                     const int send = min(sh0 + 64, SH);
-                    for (int k = sh0 + w; k < send; k += SP_NW) {
+                    for (int k = sh0 + w; k < send; k += NWS) {
                         const int c0 = shits[k] << 6;
                         const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
-                        find_pass(c0, bp[0], bp[1], B, glo, ghi);
+                        find_pass(c0 + lane, bp[0], bp[1], B, glo, ghi);
                     }
                     __syncthreads();
                     dg_lap(1);
@@ -1710,15 +1848,31 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         }
     }
     if (!searched) {
-    for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
+    for (int tb = 0; tb < own_tiles; tb += round_tiles) {
         // B only shrinks while the block works: refreshed once per round
-        const float B = rb == c_lo ? B0 : wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
-        if (rb != c_lo) __syncthreads();  // the list is empty and its counter reset (first round: the barrier above)
-        find_round(rb, B, glo, ghi);
+        const float B = tb == 0 ? B0 : wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
+        if (tb != 0) __syncthreads();  // the list is empty and its counter reset (first round: the barrier above)
+        find_round(tb, B, glo, ghi);
         __syncthreads();
+        if (tb == 0) sub_stamp(6);
+        if (SP_SHARED && threadIdx.x == 0) {   // what the next launch shares the rows by
+            __hip_atomic_fetch_add(&fuse.share_cur[SP_ROW], (unsigned int)*hcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fuse.share_cur2 != nullptr) __hip_atomic_fetch_add(&fuse.share_cur2[SP_ROW], (unsigned int)*hcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if constexpr (DIAG) {
+            // (phase log, flat search: wave 1 of every block leaves its role and the hits of its list in slots 6 and 7 -- tools/share_report.py)
+            if (fuse.tlog != nullptr && w == 1 && lane == 0 && (fuse.tlog_pass < 0 || fuse.tlog_pass == phase_pass_)) {
+                const long long slot_ = (((long long)blockIdx.y * gridDim.x + blockIdx.x) * phase_nw_ + w) * 10;
+                if (slot_ + 9 < fuse.tlog_cap) {
+                    fuse.tlog[slot_ + 6] = ((long long)SP_ROW << 32) | ((long long)SP_PART << 16) | (long long)SP_PARTS;
+                    fuse.tlog[slot_ + 7] = (tb == 0 ? 0ll : fuse.tlog[slot_ + 7]) + (long long)*hcount;
+                    if (SP_SHARED) fuse.tlog[slot_ + 8] = ((long long)role[4] << 32) | (long long)(unsigned int)role[3];   // (the target per block, the row's hits last time)
+                }
+            }
+        }
         if constexpr (DIAG) { if (fuse.work != nullptr && threadIdx.x == 0) atomicAdd(&fuse.work[NN_WORK_LIST_HITS], (unsigned long long)*hcount); }
         process_hits(*hcount);
-        if (rb + round_chunks < c_hi) exchange();
+        if (tb + round_tiles < own_tiles) exchange();
     }
     }
     spec_valid = false;
@@ -1776,21 +1930,22 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         }
         return;
     } else {
-        if (gridDim.y > 1) {
+        const int parts = SP_PARTS, row = SP_ROW;
+        if (parts > 1) {
             // several segment blocks share the row: fold into the 64-bit (d, idx) keys and draw a ticket, the
             // last arriver closes the row (protocol as in nn_match_f32_v2; only this wave takes part)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const unsigned long long key = ((unsigned long long)__float_as_uint(fb[t]) << 32) | (unsigned int)fj[t];
-                __hip_atomic_fetch_min(&tail.keys[fresh((int)blockIdx.x * 128 + lane) + t * 64], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (fresh: no address held across the pass loop)
+                __hip_atomic_fetch_min(&tail.keys[fresh(row * 128 + lane) + t * 64], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (fresh: no address held across the pass loop)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ICP_PHASE(6)
             unsigned int ticket = 0;
-            if (lane == 0) ticket = __hip_atomic_fetch_add(&tail.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&tail.tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ticket = __builtin_amdgcn_readfirstlane(ticket);
             ICP_PHASE(7)
-            if (ticket != gridDim.y - 1) return;
+            if (ticket != (unsigned int)(parts - 1)) return;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int i = fresh(ibase) + t * 64;  // keys live per slot
@@ -1798,8 +1953,8 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 tail.keys[i] = ~0ull;  // ready for the next launch (nobody touches this row again in this one)
                 fj[t] = (int)(unsigned int)(key & 0xffffffffull);
             }
-            if (lane == 0) tail.tickets[blockIdx.x] = 0u;
-            if (fuse.apply) err_row = __hip_atomic_load(&tail.err_tile[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) tail.tickets[row] = 0u;
+            if (fuse.apply) err_row = __hip_atomic_load(&tail.err_tile[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) fj[t] = ((unsigned)fj[t] < (unsigned)fuse.m) ? fj[t] : fuse.m - 1;  // unreachable clamp
@@ -1808,13 +1963,14 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
         tl.tag_lo = row_tag_lo;
         tl.idx_out = (pass & 1) ? tail.idx_out_odd : tail.idx_out;
         // (a row closed over several segment blocks may have been won elsewhere: its coordinates are gathered)
-        if (gridDim.y == 1) { ICP_PHASE(6) }
-        tail_close_row<TAIL, DIAG>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gridDim.y > 1, pass);
+        tl.row = row;
+        if (parts == 1) { ICP_PHASE(6) }
+        tail_close_row<TAIL, DIAG, NWS>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, parts > 1, pass);
         ICP_PHASE(9)
-        if (fuse.slot_state != nullptr && gridDim.y == 1) {   // the matched model points, in slot order, for the next pass
+        if (fuse.slot_state != nullptr) {   // the matched model points, in slot order, for the next pass (one segment; a shared row: gathered by the tail)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                float* ss = fuse.slot_state + 3 * (size_t)n_pad + (fresh((int)blockIdx.x * 128) + lane + t * 64);
+                float* ss = fuse.slot_state + 3 * (size_t)n_pad + (fresh(SP_ROW * 128) + lane + t * 64);
                 ss[0] = sq[t][0]; ss[(size_t)n_pad] = sq[t][1]; ss[2 * (size_t)n_pad] = sq[t][2];
             }
         }
@@ -1840,7 +1996,7 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     // as before; nothing but idle time was spent.
     if constexpr (!HIER) {
         if (threadIdx.x == 0) *hcount = 0;   // (this pass's list is consumed; ordered before its next use by the barriers below / the message barrier)
-        const bool single_round = c_hi - c_lo <= round_chunks;
+        const bool single_round = own_tiles <= round_tiles;
         if (fuse.speculate && single_round && apply && B0_pass >= 0.f && B0_pass < inf_<float>()) {
             // displacement of the block's points under this pass's transform, per axis, bounded over their (new) group box:
             // p_old = R^T (p_new - t)  =>  p_new - p_old = (I - R^T) p_new + R^T t
@@ -1868,10 +2024,10 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
                 *reinterpret_cast<float4*>(spst + 4) = float4{sp_hi[0], sp_hi[1], sp_hi[2], 0.f};
             }
             __syncthreads();   // wave 0 is through with the row (its transpose buffer overlays the hit list); the counter is reset
-            find_round(c_lo, sp_B, sp_lo, sp_hi);
+            find_round(0, sp_B, sp_lo, sp_hi);
             __syncthreads();
             const int spec_n = *hcount;
-            if (spec_n <= SP_NW * 8) {
+            if (spec_n <= NWS * 8) {
                 gather_batch(0, spec_n);
                 spec_valid = true;
             } else {
@@ -1882,6 +2038,10 @@ __global__ __launch_bounds__(SP_NW * 64) void nn_match_sparse(const float* __res
     }
     }  // pass loop
 }
+#undef SP_SHARED
+#undef SP_ROW
+#undef SP_PART
+#undef SP_PARTS
 
 // ------------------------------------------------------------------------------------------------
 // matching, fp32, sparse, 64-point rows -- the shipped kernel for clouds that cannot fill the machine with 128-point rows
@@ -3903,10 +4063,21 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense)
             // flat pass over the chunk boxes starts to dominate (ICP_NN_HIER = 0 / 1 overrides)
             const int env_hier = env_int("ICP_NN_HIER", -1);   // (not cached: the tests switch it between contexts)
             pl.hier = env_hier >= 0 ? (env_hier ? 1 : 0) : (pl.m_pad >= (1 << 17) ? 1 : 0);
+            if ((pl.m_pad >> 3) > 65536) pl.hier = 1;   // (the flat search lists 16-bit chunk numbers)
             int seg = round_up((pl.m_pad + S - 1) / S, pl.hier ? 512 : 8);   // (a segment starts on a super-box boundary)
             S = (pl.m_pad + seg - 1) / seg;
             pl.splits = S;
             pl.seg_len = seg;
+            // Rows of 128 that outnumber the CUs (one 16-wave block each: a second round of blocks) but fit the machine as
+            // 8-wave blocks, two to a CU: the 8-wave form, and -- one launch per pass -- the blocks the machine has room for
+            // beyond the rows go to the heavy rows (shared rows, see nn_match_sparse).  ICP_NN_WAVES128 = 8 / 16 and
+            // ICP_NN_SHARE = 0 override (not cached: the tests switch them between contexts).
+            const int env_w128 = env_int("ICP_NN_WAVES128", 0), env_share = env_int("ICP_NN_SHARE", 1);
+            pl.nw = 16;
+            if (!pl.hier && S == 1 && (env_w128 == 8 || (env_w128 != 16 && pl.blocks_x > num_cus && pl.blocks_x <= 2 * num_cus))) {
+                pl.nw = 8;
+                if (env_share && pl.blocks_x < 2 * num_cus && pl.blocks_x <= 8 * 64) pl.share_blocks = 2 * num_cus;
+            }
             return pl;
         }
         const int bpc = env_bpc > 0 ? env_bpc : 8;
@@ -3997,7 +4168,7 @@ bool nn_can_fuse_tail(const NNPlan& pl)
     return ((pl.version == 2 && pl.pts_per_thread == 2 && pl.chunk == 8) || pl.version == 3) && pl.n > 0 && pl.m > 0;
 }
 
-int nn_block_threads(const NNPlan& pl) { return pl.sparse ? (pl.row == 64 ? R64_NW * 64 : SP_NW * 64) : NN_BLOCK; }
+int nn_block_threads(const NNPlan& pl) { return pl.sparse ? (pl.row == 64 ? R64_NW * 64 : (pl.nw == 8 ? 8 : SP_NW) * 64) : NN_BLOCK; }
 
 static long long* g_phase_log = nullptr;
 static long long g_phase_log_cap = 0;
@@ -4054,6 +4225,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         fuse.err_rows = ft->err_rows;
     }
     NNTail tail{};
+    tail.row = -1;
     if (ta) {
         if (!nn_can_fuse_tail(pl)) return hipErrorInvalidValue;
         tail.keys = ta->keys;
@@ -4095,7 +4267,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         int cus64 = 0, dev64 = 0;
         if (pl.row == 64 && (hipGetDevice(&dev64) != hipSuccess || hipDeviceGetAttribute(&cus64, hipDeviceAttributeMultiprocessorCount, dev64) != hipSuccess)) cus64 = 256;
         const int nw64 = (pl.row == 64 && env_waves == 16 && pl.blocks_x <= cus64) ? 16 : R64_NW;
-        const int max_passes = pl.row == 64 ? SP_HCAP / (nw64 * 64) : SP_MAX_PASSES;
+        const int max_passes = pl.row == 64 ? SP_HCAP / (nw64 * 64) : pl.hier ? SP_MAX_PASSES : SP_HCAP_FLAT / (((pl.nw == 8 && ta) ? 8 : SP_NW) * 64);
         int passes = env_passes > 0 ? env_passes : ((fuse.seed_idx || fuse.samples) ? max_passes : 1);
         if (passes > max_passes) passes = max_passes;
         if (pl.row == 64) {
@@ -4140,67 +4312,94 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             }
             return hipLaunchKernel(fn, g64, dim3(nw64 * 64), args, 0, st);
         }
-        if (fuse.resident) {
-            if (!ta || pl.splits != 1) return hipErrorInvalidValue;
+        {
+            // ---- 128-point rows: one table of instantiations; 8-wave blocks exist with a fused tail and a flat search only ----
+            const bool diag = fuse.tlog != nullptr || fuse.work != nullptr, perm = fuse.q_perm != nullptr, hier = pl.hier != 0;
+            const int tl = !ta ? 0 : (ta->metric == ICP_POINT_TO_PLANE ? 2 : 1);
+            const int nw = (pl.nw == 8 && tl != 0 && !hier) ? 8 : SP_NW;
+            if (passes > (hier ? SP_MAX_PASSES : SP_HCAP_FLAT / (nw * 64))) passes = hier ? SP_MAX_PASSES : SP_HCAP_FLAT / (nw * 64);
+            if (!hier && (pl.m_pad >> 3) > 65536) return hipErrorInvalidValue;   // (the flat search lists 16-bit chunk numbers; nn_plan never asks for it)
+#define ICP_SP_FN(TL, DG, PM) {(const void*)nn_match_sparse<TL, DG, PM, false>, (const void*)nn_match_sparse<TL, DG, PM, true>}
+#define ICP_SP_FN8(TL, DG, PM) {(const void*)nn_match_sparse<TL, DG, PM, false, 8>, nullptr}
+            static const void* const fns[2][3][2][2][2] = {
+                {{{ICP_SP_FN(0, false, false), ICP_SP_FN(0, false, true)}, {ICP_SP_FN(0, true, false), ICP_SP_FN(0, true, true)}},
+                 {{ICP_SP_FN(1, false, false), ICP_SP_FN(1, false, true)}, {ICP_SP_FN(1, true, false), ICP_SP_FN(1, true, true)}},
+                 {{ICP_SP_FN(2, false, false), ICP_SP_FN(2, false, true)}, {ICP_SP_FN(2, true, false), ICP_SP_FN(2, true, true)}}},
+                {{{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}},
+                 {{ICP_SP_FN8(1, false, false), ICP_SP_FN8(1, false, true)}, {ICP_SP_FN8(1, true, false), ICP_SP_FN8(1, true, true)}},
+                 {{ICP_SP_FN8(2, false, false), ICP_SP_FN8(2, false, true)}, {ICP_SP_FN8(2, true, false), ICP_SP_FN8(2, true, true)}}}};
+#undef ICP_SP_FN
+#undef ICP_SP_FN8
+            const void* fn = fns[nw == 8 ? 1 : 0][tl][diag ? 1 : 0][perm ? 1 : 0][hier ? 1 : 0];
+            if (fn == nullptr) return hipErrorInvalidValue;
             const float* Pp = (const float*)P;
             const float* Qp = (const float*)Qsp;
             int n_pad = pl.n_pad, m_pad = pl.m_pad, seg = pl.seg_len;
             float* pd = (float*)part_d;
             void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
-            const bool diag = fuse.tlog != nullptr || fuse.work != nullptr, perm = fuse.q_perm != nullptr, hier = pl.hier != 0;
-#define ICP_SP_FN(TL, DG, PM) {(const void*)nn_match_sparse<TL, DG, PM, false>, (const void*)nn_match_sparse<TL, DG, PM, true>}
-            const void* fns[2][2][2][2] = {{{ICP_SP_FN(1, false, false), ICP_SP_FN(1, false, true)}, {ICP_SP_FN(1, true, false), ICP_SP_FN(1, true, true)}},
-                                           {{ICP_SP_FN(2, false, false), ICP_SP_FN(2, false, true)}, {ICP_SP_FN(2, true, false), ICP_SP_FN(2, true, true)}}};
-#undef ICP_SP_FN
-            const int variant = (((ta->metric == ICP_POINT_TO_PLANE ? 1 : 0) * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0)) * 2 + (hier ? 1 : 0);
-            const void* fn = (&fns[0][0][0][0])[variant];
-            // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
-            // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
-            // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that
-            // start late (behind the previous kernel of the stream) only delay the first pass, nothing waits on them
-            // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
-            static const int env_coop = env_int("ICP_COOP", 0);
-            if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
-            // blocks the machine holds at once, per (device, variant): asked once, remembered under a lock (contexts of
-            // several devices and threads share this table)
-            long long cap = 0;
-            {
-                static std::mutex mu;
-                static std::map<std::pair<int, int>, long long> capacity;
-                int dev = 0;
-                if (hipGetDevice(&dev) != hipSuccess) return hipErrorCooperativeLaunchTooLarge;
-                std::lock_guard<std::mutex> lock(mu);
-                long long& slot = capacity[std::make_pair(dev, variant)];
-                if (slot <= 0) {
-                    int per_cu = 0, cus = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SP_NW * 64, 0) != hipSuccess ||
-                        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-                        return hipErrorCooperativeLaunchTooLarge;
-                    slot = (long long)per_cu * cus;
+            if (fuse.resident) {
+                if (!ta || pl.splits != 1) return hipErrorInvalidValue;
+                const int variant = ((((nw == 8 ? 2 : 0) + (tl == 2 ? 1 : 0)) * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0)) * 2 + (hier ? 1 : 0);
+                // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
+                // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
+                // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that
+                // start late (behind the previous kernel of the stream) only delay the first pass, nothing waits on them
+                // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
+                static const int env_coop = env_int("ICP_COOP", 0);
+                if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(nw * 64), args, 0, st);
+                // blocks the machine holds at once, per (device, variant): asked once, remembered under a lock (contexts of
+                // several devices and threads share this table)
+                long long cap = 0;
+                {
+                    static std::mutex mu;
+                    static std::map<std::pair<int, int>, long long> capacity;
+                    int dev = 0;
+                    if (hipGetDevice(&dev) != hipSuccess) return hipErrorCooperativeLaunchTooLarge;
+                    std::lock_guard<std::mutex> lock(mu);
+                    long long& slot = capacity[std::make_pair(dev, variant)];
+                    if (slot <= 0) {
+                        int per_cu = 0, cus = 0;
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nw * 64, 0) != hipSuccess ||
+                            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                            return hipErrorCooperativeLaunchTooLarge;
+                        slot = (long long)per_cu * cus;
+                    }
+                    cap = slot;
                 }
-                cap = slot;
+                if ((long long)grid.x * grid.y > cap) return hipErrorCooperativeLaunchTooLarge;
+                return hipLaunchKernel(fn, grid, dim3(nw * 64), args, 0, st);
             }
-            if ((long long)grid.x * grid.y > cap) return hipErrorCooperativeLaunchTooLarge;
-            return hipLaunchKernel(fn, grid, dim3(SP_NW * 64), args, 0, st);
+            // one launch per pass.  Shared rows: a grid of more blocks than rows, the roles dealt out inside the kernel from the
+            // hits each row had in the previous launch (three count arrays in rotation: read, add to, zero for the next)
+            dim3 g = grid;
+            if (nw == 8 && pl.share_blocks > pl.blocks_x && pl.splits == 1 && opt->share_counts != nullptr && opt->share_seq != nullptr && opt->share_cold_seq != nullptr &&
+                pl.blocks_x <= nw * 64) {
+                const unsigned long long seq = (*opt->share_seq)++;
+                const size_t R = (size_t)pl.blocks_x;
+                fuse.share_prev = opt->share_counts + ((seq + 2) % 3) * R;
+                fuse.share_cur = opt->share_counts + (seq % 3) * R;
+                fuse.share_next = opt->share_counts + ((seq + 1) % 3) * R;
+                // The first pass of a registration (no previous match: the launch has no seeds) has no previous pass to go by:
+                // it takes the counts of the PREVIOUS registration's first pass (two more arrays, alternating) -- a sensor's
+                // consecutive scans are heavy in the same places; a first registration finds zeros there and runs unshared.
+                // The array the next first pass adds to is zeroed by every ordinary pass in between.
+                unsigned int* cold = opt->share_counts + 3 * R;
+                if (fuse.seed_idx == nullptr) {
+                    const unsigned long long k = (*opt->share_cold_seq)++;
+                    fuse.share_prev = cold + ((k + 1) % 2) * R;
+                    fuse.share_cur2 = cold + (k % 2) * R;
+                } else {
+                    fuse.share_zero2 = cold + (*opt->share_cold_seq % 2) * R;
+                }
+                fuse.share_rows = pl.blocks_x;
+                {
+                    const int env_min = env_int("ICP_NN_SHARE_MIN", 0);   // (A/B runs)
+                    fuse.share_min = env_min > 0 ? env_min : 8 * nw;      // one batch for every wave
+                }
+                g = dim3(pl.share_blocks, 1);
+            }
+            return hipLaunchKernel(fn, g, dim3(nw * 64), args, 0, st);
         }
-#define ICP_LAUNCH_SP4(TL, DG, PM, HR)                                                                             \
-    hipLaunchKernelGGL((nn_match_sparse<TL, DG, PM, HR>), grid, dim3(SP_NW * 64), 0, st, (const float*)P, pl.n_pad, \
-                       (const float*)Qsp, pl.m_pad, pl.seg_len, passes, (float*)part_d, part_idx, rt, fuse, tail)
-#define ICP_LAUNCH_SP3(TL, DG, PM)                                                                                 \
-    do { if (pl.hier) ICP_LAUNCH_SP4(TL, DG, PM, true); else ICP_LAUNCH_SP4(TL, DG, PM, false); } while (0)
-#define ICP_LAUNCH_SP(TL)                                                                                          \
-    do {                                                                                                           \
-        const bool dg_ = fuse.tlog != nullptr || fuse.work != nullptr, pm_ = fuse.q_perm != nullptr;                                       \
-        if (dg_) { if (pm_) ICP_LAUNCH_SP3(TL, true, true); else ICP_LAUNCH_SP3(TL, true, false); }                 \
-        else { if (pm_) ICP_LAUNCH_SP3(TL, false, true); else ICP_LAUNCH_SP3(TL, false, false); }                   \
-    } while (0)
-        if (!ta) ICP_LAUNCH_SP(0);
-        else if (ta->metric == ICP_POINT_TO_PLANE) ICP_LAUNCH_SP(2);
-        else ICP_LAUNCH_SP(1);
-#undef ICP_LAUNCH_SP3
-#undef ICP_LAUNCH_SP4
-#undef ICP_LAUNCH_SP
-        return hipGetLastError();
     }
     // measured (profiles/r1/03_nn_sweep_cull.txt): without a seed the early-out variant loses to the plain
     // packed kernel on every cloud (its bound starts at +inf), with one it wins on every cloud
@@ -4259,6 +4458,7 @@ static hipError_t launch_row64_f64(const NNPlan& pl, const void* P, const void* 
         fuse.err_rows = ft->err_rows;
     }
     NNTail tail{};
+    tail.row = -1;
     if (ta) {
         tail.idx_out = ta->idx_out;
         tail.idx_out_odd = ta->idx_out_odd ? ta->idx_out_odd : ta->idx_out;

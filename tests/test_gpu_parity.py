@@ -458,8 +458,19 @@ def test_fused_and_two_kernel_forms_agree(pkg, orc, golden, tail):
 # ---------------------------------------------------------------------------------------------------
 # the three forms of the loop (resident kernel, armed launches, one launch per pass) are the same computation
 # ---------------------------------------------------------------------------------------------------
+def _set_row(monkeypatch, row):
+    """ICP_NN_ROW = 64 / 128, and "128w8": rows of 128 as 8-wave blocks, two to a CU, whose launches (one per pass) share the
+    rows -- the form clouds of 33-65 k points get by themselves, forced here onto small ones (few rows, hundreds of spare blocks)"""
+    monkeypatch.setenv("ICP_NN_ROW", row[:3] if row.startswith("128") else row)
+    if row == "128w8":
+        monkeypatch.setenv("ICP_NN_WAVES128", "8")
+    else:
+        monkeypatch.delenv("ICP_NN_WAVES128", raising=False)
+
+
 LOOP_FORMS = {
     "resident": {},
+    "resident_forced": {"ICP_RESIDENT": "2"},           # (a plan with shared rows runs armed unless told otherwise)
     "resident_no_speculation": {"ICP_NN_SPECULATE": "0"},   # (cached per process: effective only in a run that starts with it)
     "resident_host_mailbox": {"ICP_MAILBOX": "host"},
     "resident_plain_stores": {"ICP_MAILBOX_AVX": "0"},   # the mailbox line written word by word (a CPU without AVX)
@@ -477,13 +488,13 @@ def _run_form(pkg, monkeypatch, env, fn):
         return fn(c)
 
 
-@pytest.mark.parametrize("row", ["64", "128"])
+@pytest.mark.parametrize("row", ["64", "128", "128w8"])
 @pytest.mark.parametrize("metric", ["point_to_point", "point_to_plane"])
 def test_loop_forms_are_bit_identical(pkg, orc, golden, monkeypatch, metric, row):
     """icp_loop_run keeps one resident kernel for the registration (mailbox in BAR-visible device memory, or in
     pinned host memory relayed by block 0), or arms the next pass ahead of its (R, t), or launches pass by pass:
     same rows, same host half -> the same bits, and the oracle's run."""
-    monkeypatch.setenv("ICP_NN_ROW", row)     # rows of 64 points (nn_match_row64, the default here) / of 128 (nn_match_sparse)
+    _set_row(monkeypatch, row)     # rows of 64 points (nn_match_row64, the default here) / of 128 (nn_match_sparse, 16 waves / 8 waves + shared rows)
     P, Q = orc.hall_clouds(golden)
     if metric == "point_to_point":
         fn = lambda c: c.point_to_point(P, Q, max_iter=100, tol=1e-6)
@@ -523,17 +534,32 @@ def test_resident_kernel_resumes_and_fixed_iterations(pkg, orc, golden, monkeypa
     assert rel(st["T"], want["T"]) < TOL_T and np.array_equal(idx, want["idx"])
 
 
-def test_moving_cloud_too_large_for_a_resident_kernel(ctx, pkg, orc):
-    """36 864 moving points are 576 rows of 64 -- more than two blocks per CU hold -- so the plan falls back to rows of 128
-    (288 blocks: more than one per CU cannot be resident together either): the resident launch is refused once and the
-    loop runs pass by pass (armed) -- same answer"""
+def test_moving_cloud_with_shared_rows(pkg, orc, monkeypatch):
+    """36 864 moving points are 576 rows of 64 -- more than two blocks per CU hold -- so the plan is rows of 128 as 8-wave blocks
+    (288 rows, two blocks to a CU) and one armed launch per pass whose spare blocks go to the heavy rows (shared rows); the same
+    run with 16-wave blocks, with the rows unshared, resident, and launched pass by pass: the same bits, and the oracle's run"""
     D = pkg.datasets.synthetic_grid(192, np.float32)
     M = pkg.datasets.make_model_gpu(D[:4096], *pkg.datasets.P2P_GPU)
-    res = ctx.point_to_point(D, M, max_iter=4, tol=1e-6)
-    want = orc.icp_p2p_f32x(D, M, 4, 1e-6)
-    assert res.iterations == want["iterations"] and np.array_equal(res.idx, want["idx"])
-    assert rel(res.T, want["T"]) < TOL_T
-    assert ctx.nn_launch_info()["threads"] == 1024
+    want = orc.icp_p2p_f32x(D, M, 6, 1e-6)
+    forms = {"shared": {}, "unshared": {"ICP_NN_SHARE": "0"}, "resident": {"ICP_RESIDENT": "2"}, "stepwise": {"ICP_RESIDENT": "0", "ICP_ARMED": "0"},
+             "waves16": {"ICP_NN_WAVES128": "16"}}
+    res = {}
+    for name, env in forms.items():
+        for k in ("ICP_NN_SHARE", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_WAVES128"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.Context(0) as c:
+            res[name] = c.point_to_point(D, M, max_iter=6, tol=1e-6)
+            assert c.nn_launch_info()["threads"] == (1024 if name == "waves16" else 512), name
+    ref = res["shared"]
+    assert ref.iterations == want["iterations"] and np.array_equal(ref.idx, want["idx"])
+    assert rel(ref.T, want["T"]) < TOL_T
+    for name, r in res.items():
+        assert r.iterations == ref.iterations and np.array_equal(r.T, ref.T) and np.array_equal(r.idx, ref.idx), name
+        # (the loop ends at max_iter: the last entry is the error-only pass -- a TRANSFORM_ONLY message to the resident kernel, whose
+        # compact rows carry their tag in the low 16 mantissa bits of the error share, or the stand-alone transform kernel)
+        assert np.array_equal(r.err[:-1], ref.err[:-1]) and abs(r.err[-1] - ref.err[-1]) <= 1e-10 * ref.err[-1], name
 
 
 @pytest.mark.parametrize("width", [176, 181])
@@ -644,7 +670,8 @@ def _fuzz_cloud(rng, n, kind, scale):
 
 # (sort, hier, row): Morton views forbidden / forced; flat search with 64-point rows (nn_match_row64) and with 128-point rows
 # (nn_match_sparse), and the box hierarchy (128-point rows only)
-FUZZ_VARIANTS = [("0", "0", "64"), ("1", "0", "64"), ("0", "0", "128"), ("1", "0", "128"), ("0", "1", "128"), ("1", "1", "128")]
+FUZZ_VARIANTS = [("0", "0", "64"), ("1", "0", "64"), ("0", "0", "128"), ("1", "0", "128"), ("0", "1", "128"), ("1", "1", "128"),
+                 ("0", "0", "128w8"), ("1", "0", "128w8")]
 
 
 @pytest.mark.parametrize("sort,hier,row", FUZZ_VARIANTS)
@@ -654,7 +681,7 @@ def test_matching_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier, row
     large models (forced onto models of one or two super boxes): indices bit-exact against the CPU oracle"""
     monkeypatch.setenv("ICP_SORT", sort)
     monkeypatch.setenv("ICP_NN_HIER", hier)
-    monkeypatch.setenv("ICP_NN_ROW", row)
+    _set_row(monkeypatch, row)
     rng = np.random.default_rng(20260210 + int(sort))
     with pkg.Context(0) as c:
         for case in range(int(os.environ.get("ICP_FUZZ_CASES", "40"))):     # (a longer soak: ICP_FUZZ_CASES=1000)
@@ -672,7 +699,7 @@ def test_registration_fuzz_against_the_oracle(pkg, orc, monkeypatch, sort, hier,
     flat search and box hierarchy: error series, transform and final correspondences against the oracle's run"""
     monkeypatch.setenv("ICP_SORT", sort)
     monkeypatch.setenv("ICP_NN_HIER", hier)
-    monkeypatch.setenv("ICP_NN_ROW", row)
+    _set_row(monkeypatch, row)
     rng = np.random.default_rng(7300 + int(sort))
     with pkg.Context(0) as c:
         for case in range(max(1, int(os.environ.get("ICP_FUZZ_CASES", "40")) // 5)):
