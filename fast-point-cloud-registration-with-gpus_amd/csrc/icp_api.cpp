@@ -240,6 +240,8 @@ struct icp_ctx {
     DevBuf share_counts;                        // shared rows (NNPlan::share_blocks): 5 x blocks_x hit counters (3 in rotation from launch to launch, 2 for first passes)
     mutable unsigned long long share_seq = 0;   // ... the launches so far (advanced by the launcher)
     mutable unsigned long long share_cold_seq = 0;   // ... and those that were the first pass of a registration
+    DevBuf seed_pub;                            // ... resident launches: blocks_x x 384 floats, the matches of split rows for their other blocks
+    int share_resident_after = -1;              // ... ICP_SHARE_RESIDENT_AFTER=n: a registration runs armed launches for n passes, then one resident kernel (< 0, the default: armed throughout)
     bool model_sorted = false, moving_sorted = false;
     // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
     DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
@@ -377,6 +379,7 @@ int ensure_work_buffers(icp_ctx* c)
             c->share_seq = 0;
             c->share_cold_seq = 0;
         }
+        HIP_TRY(c->seed_pub.ensure((size_t)pl.blocks_x * 384 * sizeof(float)));
     }
     // one error row per matching block row (fused transform) or per transform block
     size_t err_rows = (size_t)icp::MOM_MAX_BLOCKS;
@@ -634,6 +637,7 @@ int icp_create(int device, icp_ctx** out)
     if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
     if (const char* v = std::getenv("ICP_ARMED")) c->arm = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1);
+    if (const char* v = std::getenv("ICP_SHARE_RESIDENT_AFTER")) c->share_resident_after = std::atoi(v);
     if (const char* v = std::getenv("ICP_TRACE")) { c->trace = v[0] == '1' || v[0] == '2'; c->trace_passes = v[0] == '2'; }
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
@@ -672,7 +676,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->work, &c->slot_state, &c->share_counts, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->work, &c->slot_state, &c->share_counts, &c->seed_pub, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -986,7 +990,7 @@ static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
     if (c->count_work) o.work = (unsigned long long*)c->work.p;
-    if (c->plan.share_blocks > 0 && c->share_counts.p != nullptr) { o.share_counts = (unsigned int*)c->share_counts.p; o.share_seq = &c->share_seq; o.share_cold_seq = &c->share_cold_seq; }
+    if (c->plan.share_blocks > 0 && c->share_counts.p != nullptr) { o.share_counts = (unsigned int*)c->share_counts.p; o.share_seq = &c->share_seq; o.share_cold_seq = &c->share_cold_seq; o.seed_pub = (float*)c->seed_pub.p; }
     return o;
 }
 
@@ -1499,11 +1503,24 @@ int icp_loop_complete(icp_ctx* c, int* done)
 // without having touched anything.
 namespace {
 
+// A plan with shared rows (33-57 k moving points) runs armed launches: every launch deals its blocks anew, by the hits of the
+// launch before.  A resident kernel can share its rows too -- its blocks keep, for the whole launch, the roles the counts at
+// its start give them; whichever block closes a split row publishes the matches for the others -- and is what ICP_RESIDENT=2
+// (from the first pass, by the counts of the registration before) and ICP_SHARE_RESIDENT_AFTER=n (after n armed passes) select.
+// Measured on Bunny.csv, registrations repeated in one context: 32.9 us per iteration armed, 30.7 resident from the start,
+// 33.2 switching after 6 passes; a context's FIRST registration has no counts and runs a resident launch unshared (late passes
+// of 42 us instead of 24), which is why armed is the default.
+bool share_wants_resident(const icp_ctx* c)
+{
+    return c->plan.share_blocks > 0 && c->resident == 1 && !c->resident_refused && c->share_resident_after >= 0 &&
+           c->loop.H.applied + 1 >= c->share_resident_after;
+}
+
 bool can_arm(icp_ctx* c)
 {
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    return c->arm && c->prec == ICP_F32 && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
+    return c->arm && !share_wants_resident(c) && c->prec == ICP_F32 && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
            icp::nn_can_fuse_transform(pl) && c->have_scan_copy && c->use_boxes && L.active && L.pending && !L.armed &&
            L.matched && !L.H.done && !L.H.have_rt &&
            !L.timed_nn &&  // a timed pass is completed with a stream synchronisation: nothing may wait behind it
@@ -1598,10 +1615,8 @@ bool can_reside(icp_ctx* c)
 {
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    // (a plan with shared rows -- 33-65 k moving points -- runs one armed launch per pass: its 8-wave blocks would all fit the
-    // machine, but a resident kernel cannot move blocks to the heavy rows from pass to pass; measured on Bunny.csv: 55 us per
-    // iteration resident, 32 us armed with shared rows.  ICP_RESIDENT=2 keeps such a plan resident.)
-    return c->resident && (c->resident > 1 || pl.share_blocks == 0) && (c->prec == ICP_F32 || pl.version == 3) && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
+    // (a plan with shared rows starts with armed launches, see share_wants_resident; ICP_RESIDENT=2: resident from the first pass)
+    return c->resident && (c->resident > 1 || pl.share_blocks == 0 || share_wants_resident(c)) && (c->prec == ICP_F32 || pl.version == 3) && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
            icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done;
 }
 
@@ -1644,6 +1659,10 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     // after icp_reset_moving the kernel reads the pristine copy and (re)writes c->P itself -- no copy is enqueued
     const void* P_in = c->moving_is_pristine ? c->P0.p : c->P.p;
     ft.store_first = c->moving_is_pristine;
+    // shared rows: several blocks read a row's points at kernel entry, one of them stores the moved points in pass 0 -- not into
+    // the buffer a block that starts late is still reading: the cloud goes to the second buffer (as an armed launch does)
+    const bool two_buffers = rp.share_blocks > 0 && !c->moving_is_pristine && c->P2.p != nullptr;
+    if (two_buffers) { ft.P_out = c->P2.p; ft.store_first = true; }
     const hipError_t le = icp::launch_nn(rp, P_in, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream);
     if (le != hipSuccess) {
         (void)hipGetLastError();
@@ -1652,6 +1671,7 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
         return ICP_OK;
     }
     c->moving_is_pristine = false;
+    if (two_buffers) std::swap(c->P, c->P2);
     *fell_back = false;
     if (time_this) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     if (c->trace_passes) std::fprintf(stderr, "[icp trace] resident launch: mailbox %p relay %p base %.0f\n", (void*)mb, (void*)c->relay, base);

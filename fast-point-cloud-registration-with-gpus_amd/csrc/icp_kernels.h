@@ -126,6 +126,7 @@ struct NNCullInputs {
     unsigned int* share_counts = nullptr;
     unsigned long long* share_seq = nullptr;
     unsigned long long* share_cold_seq = nullptr;
+    float* seed_pub = nullptr;   // resident launches with shared rows: blocks_x x 384 floats (NNFuse::seed_pub)
 };
 // What the sparse kernel EXECUTED (it returns the brute-force answer without evaluating most pairs): wave-level tallies.
 // One "hit" = one 8-point model chunk processed by one wave = 64 lanes x 2 moving points against that chunk.

@@ -436,6 +436,8 @@ struct NNTail {
     int compact;
     unsigned int tag_lo;       // low 32 bits of `tag` as an integer (a double -> integer conversion on the device expands to f64 fma code)
     int row;                   // the row this block closes, or -1: blockIdx.x (shared rows: a block's row is not its index)
+    int idx_through;           // the correspondences leave as agent-scope (write-through) stores: a resident launch whose rows are closed now by one
+                               // block, now by another -- two XCDs' L2s holding dirty copies of one line would write them back in no order
 };
 __device__ __forceinline__ double crow_pack(double err, unsigned int tag_lo)
 {
@@ -505,6 +507,8 @@ struct NNFuse {
     unsigned int* share_zero2; // ... a second array to zero (the one the next first pass will add to) or NULL
     int share_rows;            // rows of the launch (<= threads of a block)
     int share_min;             // a part is never made smaller than this many hits (of the previous launch)
+    float* seed_pub;           // resident launch with shared rows: [rows][3][128] -- whichever block closes a split row leaves the matches' coordinates
+                               // here (they seed the next pass and are what its error is measured against) for the row's other blocks
 };
 
 // phase stamp of the diagnostic log: one scalar branch when the log is off
@@ -998,7 +1002,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
         double ppx = 0.0, ppy = 0.0, ppz = 0.0, qx = 0.0, qy = 0.0, qz = 0.0;
         if (live) {
             const int jj = j[0];
-            tail.idx_out[i] = jj;
+            if (tail.idx_through) __hip_atomic_store(&tail.idx_out[i], jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else tail.idx_out[i] = jj;
             ppx = (double)px.x; ppy = (double)py.x; ppz = (double)pz.x;
             if (gather) { qio[0][0] = Qg[jj]; qio[0][1] = Qg[(size_t)m_pad + jj]; qio[0][2] = Qg[2 * (size_t)m_pad + jj]; }
             qx = (double)qio[0][0]; qy = (double)qio[0][1]; qz = (double)qio[0][2];
@@ -1022,7 +1026,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
             const int i = fresh(pi[t]);
             if (i < fuse.n) {
                 const int jj = j[t];
-                tail.idx_out[i] = jj;
+                if (tail.idx_through) __hip_atomic_store(&tail.idx_out[i], jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else tail.idx_out[i] = jj;
                 const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
                 if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
                 const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
@@ -1049,7 +1053,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
             double cn[6] = {0, 0, 0, 0, 0, 0}, bb = 0.0;
             if (live) {
                 const int jj = j[t];
-                tail.idx_out[i] = jj;
+                if (tail.idx_through) __hip_atomic_store(&tail.idx_out[i], jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else tail.idx_out[i] = jj;
                 const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
                 if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
                 const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
@@ -1264,6 +1268,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             if (t < R && (int)blockIdx.x >= excl && (int)blockIdx.x < excl + (int)S) { role[0] = t; role[1] = (int)blockIdx.x - excl; role[2] = (int)S; if constexpr (DIAG) { role[3] = (int)h; role[4] = (int)T; } }
             __syncthreads();
             if (role[0] < 0) return;
+            if (t == 0) role[5] = 0;   // (wave 0's note to itself, resident launches: "the row's last pass was closed elsewhere")
         }
     }
     const int ibase = SP_ROW * 128 + lane;   // the block's slots; the moving point in slot s is p_perm[s] (spatially sorted groups)
@@ -1406,6 +1411,18 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             if (first && fuse.relay != nullptr && lane < 16)
                 __hip_atomic_store(&fuse.relay->w[lane], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one line, one store
             if (lane < 16) reinterpret_cast<uint32_t*>(msg)[lane] = word;
+            if constexpr (!HIER && TAIL != 0) {
+                // shared rows, resident: the last pass of this row was closed by another of its blocks -- the matches are in the
+                // row's publication (complete before the row's tag left, so before this message was written)
+                if (pass > 0 && fuse.share_prev != nullptr && role[5] != 0) {
+                    const float* pub = fuse.seed_pub + (size_t)SP_ROW * 384;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        seedq[a][lane] = __hip_atomic_load(&pub[a * 128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        seedq[a][lane + 64] = __hip_atomic_load(&pub[a * 128 + lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
         }
         __syncthreads();
         cmd = reinterpret_cast<const int*>(msg)[ICP_MB_CMD];
@@ -1840,7 +1857,9 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             }
         }
         if (covered) {
-            scan_batch(0, *hcount);   // (the list's length is still in the counter)
+            const int h1 = *hcount;   // (the list's length is still in the counter)
+            scan_batch(0, h1);        // the first batch sits in the stages
+            for (int hb = NWS * 8; hb < h1; hb += NWS * 8) { gather_batch(hb, h1); scan_batch(hb, h1); }
             searched = true;
         } else {
             if (threadIdx.x == 0) *hcount = 0;   // the guess did not hold: forget the list and search as usual
@@ -1931,6 +1950,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
         return;
     } else {
         const int parts = SP_PARTS, row = SP_ROW;
+        bool closer = true;   // this block closes the row (always, unless the row is split)
         if (parts > 1) {
             // several segment blocks share the row: fold into the 64-bit (d, idx) keys and draw a ticket, the
             // last arriver closes the row (protocol as in nn_match_f32_v2; only this wave takes part)
@@ -1945,27 +1965,52 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             if (lane == 0) ticket = __hip_atomic_fetch_add(&tail.tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ticket = __builtin_amdgcn_readfirstlane(ticket);
             ICP_PHASE(7)
-            if (ticket != (unsigned int)(parts - 1)) return;
+            if (ticket != (unsigned int)(parts - 1)) {
+                if (!fuse.resident) return;
+                closer = false;   // (resident: on to the wait; the row's matches will be fetched from its publication)
+            } else {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int i = fresh(ibase) + t * 64;  // keys live per slot
-                const unsigned long long key = __hip_atomic_load(&tail.keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tail.keys[i] = ~0ull;  // ready for the next launch (nobody touches this row again in this one)
-                fj[t] = (int)(unsigned int)(key & 0xffffffffull);
+                for (int t = 0; t < 2; ++t) {
+                    const int i = fresh(ibase) + t * 64;  // keys live per slot
+                    const unsigned long long key = __hip_atomic_load(&tail.keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // ready for the next pass / launch (nobody touches this row again in this one; agent scope: in a resident
+                    // launch the next pass's atomics follow without a kernel boundary)
+                    __hip_atomic_store(&tail.keys[i], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    fj[t] = (int)(unsigned int)(key & 0xffffffffull);
+                }
+                if (lane == 0) __hip_atomic_store(&tail.tickets[row], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fuse.apply) err_row = __hip_atomic_load(&tail.err_tile[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (lane == 0) tail.tickets[row] = 0u;
-            if (fuse.apply) err_row = __hip_atomic_load(&tail.err_tile[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if constexpr (!HIER) { if (SP_SHARED && fuse.resident && lane == 0) role[5] = closer ? 0 : 1; }
+        if (closer) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) fj[t] = ((unsigned)fj[t] < (unsigned)fuse.m) ? fj[t] : fuse.m - 1;  // unreachable clamp
+        bool gather_in_tail = parts > 1;
+        if constexpr (!HIER) {
+            if (parts > 1 && fuse.resident && SP_SHARED) {
+                // resident, split row: the coordinates of the matches (some were won by other blocks) are gathered here and
+                // published for the row's other blocks BEFORE the row's tag leaves (the tail drains its stores first)
+                float* pub = fuse.seed_pub + (size_t)row * 384;
+                const float* Qg = fuse.Q_gather;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (fresh(pi[t]) < fuse.n) { sq[t][0] = Qg[fj[t]]; sq[t][1] = Qg[(size_t)m_pad + fj[t]]; sq[t][2] = Qg[2 * (size_t)m_pad + fj[t]]; }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) __hip_atomic_store(&pub[a * 128 + lane + t * 64], sq[t][a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                gather_in_tail = false;
+            }
+        }
         NNTail tl = tail;
         tl.tag = row_tag;
         tl.tag_lo = row_tag_lo;
         tl.idx_out = (pass & 1) ? tail.idx_out_odd : tail.idx_out;
         // (a row closed over several segment blocks may have been won elsewhere: its coordinates are gathered)
         tl.row = row;
+        tl.idx_through = (SP_SHARED && fuse.resident) ? 1 : 0;
         if (parts == 1) { ICP_PHASE(6) }
-        tail_close_row<TAIL, DIAG, NWS>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, parts > 1, pass);
+        tail_close_row<TAIL, DIAG, NWS>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gather_in_tail, pass);
         ICP_PHASE(9)
         if (fuse.slot_state != nullptr) {   // the matched model points, in slot order, for the next pass (one segment; a shared row: gathered by the tail)
 #pragma unroll
@@ -1981,6 +2026,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             sok[t] = real[t];
             seedq[0][lane + t * 64] = sq[t][0]; seedq[1][lane + t * 64] = sq[t][1]; seedq[2][lane + t * 64] = sq[t][2];
         }
+        }  // (closer)
     }
     }  // (wave 0)
 
@@ -2027,7 +2073,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             find_round(0, sp_B, sp_lo, sp_hi);
             __syncthreads();
             const int spec_n = *hcount;
-            if (spec_n <= NWS * 8) {
+            if (spec_n <= 4 * NWS * 8) {   // (up to four batches: the first is fetched now, the others when the list is used)
                 gather_batch(0, spec_n);
                 spec_valid = true;
             } else {
@@ -4339,42 +4385,12 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             int n_pad = pl.n_pad, m_pad = pl.m_pad, seg = pl.seg_len;
             float* pd = (float*)part_d;
             void* args[] = {&Pp, &n_pad, &Qp, &m_pad, &seg, &passes, &pd, &part_idx, &rt, &fuse, &tail};
-            if (fuse.resident) {
-                if (!ta || pl.splits != 1) return hipErrorInvalidValue;
-                const int variant = ((((nw == 8 ? 2 : 0) + (tl == 2 ? 1 : 0)) * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0)) * 2 + (hier ? 1 : 0);
-                // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
-                // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
-                // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that
-                // start late (behind the previous kernel of the stream) only delay the first pass, nothing waits on them
-                // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
-                static const int env_coop = env_int("ICP_COOP", 0);
-                if (env_coop) return hipLaunchCooperativeKernel(fn, grid, dim3(nw * 64), args, 0, st);
-                // blocks the machine holds at once, per (device, variant): asked once, remembered under a lock (contexts of
-                // several devices and threads share this table)
-                long long cap = 0;
-                {
-                    static std::mutex mu;
-                    static std::map<std::pair<int, int>, long long> capacity;
-                    int dev = 0;
-                    if (hipGetDevice(&dev) != hipSuccess) return hipErrorCooperativeLaunchTooLarge;
-                    std::lock_guard<std::mutex> lock(mu);
-                    long long& slot = capacity[std::make_pair(dev, variant)];
-                    if (slot <= 0) {
-                        int per_cu = 0, cus = 0;
-                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nw * 64, 0) != hipSuccess ||
-                            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-                            return hipErrorCooperativeLaunchTooLarge;
-                        slot = (long long)per_cu * cus;
-                    }
-                    cap = slot;
-                }
-                if ((long long)grid.x * grid.y > cap) return hipErrorCooperativeLaunchTooLarge;
-                return hipLaunchKernel(fn, grid, dim3(nw * 64), args, 0, st);
-            }
-            // one launch per pass.  Shared rows: a grid of more blocks than rows, the roles dealt out inside the kernel from the
+            // Shared rows: a grid of more blocks than rows, the roles dealt out inside the kernel from the
             // hits each row had in the previous launch (three count arrays in rotation: read, add to, zero for the next)
             dim3 g = grid;
             if (nw == 8 && pl.share_blocks > pl.blocks_x && pl.splits == 1 && opt->share_counts != nullptr && opt->share_seq != nullptr && opt->share_cold_seq != nullptr &&
+                (!fuse.resident || (opt->seed_pub != nullptr && env_int("ICP_NN_SHARE_RESIDENT", 1))) &&   // (0: a resident launch keeps one block per row -- A/B runs)
+               
                 pl.blocks_x <= nw * 64) {
                 const unsigned long long seq = (*opt->share_seq)++;
                 const size_t R = (size_t)pl.blocks_x;
@@ -4399,6 +4415,39 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
                     fuse.share_min = env_min > 0 ? env_min : 8 * nw;      // one batch for every wave
                 }
                 g = dim3(pl.share_blocks, 1);
+            }
+            fuse.seed_pub = opt->seed_pub;
+            if (fuse.resident) {
+                if (!ta || pl.splits != 1) return hipErrorInvalidValue;
+                const int variant = ((((nw == 8 ? 2 : 0) + (tl == 2 ? 1 : 0)) * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0)) * 2 + (hier ? 1 : 0);
+                // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
+                // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
+                // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that
+                // start late (behind the previous kernel of the stream) only delay the first pass, nothing waits on them
+                // that they cannot deliver.  ICP_COOP=1 uses the cooperative launch.
+                static const int env_coop = env_int("ICP_COOP", 0);
+                if (env_coop) return hipLaunchCooperativeKernel(fn, g, dim3(nw * 64), args, 0, st);
+                // blocks the machine holds at once, per (device, variant): asked once, remembered under a lock (contexts of
+                // several devices and threads share this table)
+                long long cap = 0;
+                {
+                    static std::mutex mu;
+                    static std::map<std::pair<int, int>, long long> capacity;
+                    int dev = 0;
+                    if (hipGetDevice(&dev) != hipSuccess) return hipErrorCooperativeLaunchTooLarge;
+                    std::lock_guard<std::mutex> lock(mu);
+                    long long& slot = capacity[std::make_pair(dev, variant)];
+                    if (slot <= 0) {
+                        int per_cu = 0, cus = 0;
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nw * 64, 0) != hipSuccess ||
+                            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                            return hipErrorCooperativeLaunchTooLarge;
+                        slot = (long long)per_cu * cus;
+                    }
+                    cap = slot;
+                }
+                if ((long long)g.x * g.y > cap) return hipErrorCooperativeLaunchTooLarge;
+                return hipLaunchKernel(fn, g, dim3(nw * 64), args, 0, st);
             }
             return hipLaunchKernel(fn, g, dim3(nw * 64), args, 0, st);
         }

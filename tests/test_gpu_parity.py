@@ -136,6 +136,36 @@ def test_matching_full_size_properties(ctx, pkg, golden):
     assert np.array_equal(d2(B, M[perm], idx2), best)
 
 
+@pytest.mark.parametrize("form", ["armed_shared", "armed_then_resident", "resident_second_registration", "waves16"])
+def test_bunny_registration_full_size_against_the_oracle(pkg, orc, golden, monkeypatch, form):
+    """BASELINE configs[1] at full size (Bunny.csv against its moved copy, 35 947^2): nine fixed iterations through the loop the
+    plan picks for this size -- rows of 128 as 8-wave blocks, one armed launch per pass, the spare blocks of every launch
+    dealt to the heavy rows -- through the resident forms of the same (taking over after four passes; from the first pass of a
+    second registration) and through the 16-wave blocks of rounds 1-2: correspondences bit-exact against the oracle's run
+    (all threads of the host), transform within the tolerance"""
+    env = {"armed_shared": {}, "armed_then_resident": {"ICP_SHARE_RESIDENT_AFTER": "4"}, "resident_second_registration": {"ICP_RESIDENT": "2"},
+           "waves16": {"ICP_NN_WAVES128": "16"}}[form]
+    for k in ("ICP_NN_SHARE", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_WAVES128", "ICP_NN_SHARE_RESIDENT", "ICP_SHARE_RESIDENT_AFTER"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    B = np.fromfile(os.path.join(golden, "bunny_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
+    M = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
+    orc.set_threads(os.cpu_count() or 1)
+    try:
+        want = orc.icp_p2p_f32x(B, M, 9, 0.0, fixed=True)
+    finally:
+        orc.set_threads(1)
+    with pkg.Context(0) as c:
+        for _ in range(2 if form == "resident_second_registration" else 1):
+            res = c.point_to_point(B, M, max_iter=9, tol=0.0, fixed_iterations=True)
+        assert c.nn_launch_info()["threads"] == (1024 if form == "waves16" else 512)
+    assert res.iterations == want["iterations"] == 9
+    assert np.array_equal(res.idx, want["idx"])
+    assert rel(res.T, want["T"]) < TOL_T
+    assert np.allclose(res.err[1:], want["err"][1:], rtol=1e-6)
+
+
 # ---------------------------------------------------------------------------------------------------
 # the loop, pass by pass, from captured inputs
 # ---------------------------------------------------------------------------------------------------
@@ -537,20 +567,26 @@ def test_resident_kernel_resumes_and_fixed_iterations(pkg, orc, golden, monkeypa
 def test_moving_cloud_with_shared_rows(pkg, orc, monkeypatch):
     """36 864 moving points are 576 rows of 64 -- more than two blocks per CU hold -- so the plan is rows of 128 as 8-wave blocks
     (288 rows, two blocks to a CU) and one armed launch per pass whose spare blocks go to the heavy rows (shared rows); the same
-    run with 16-wave blocks, with the rows unshared, resident, and launched pass by pass: the same bits, and the oracle's run"""
+    run with 16-wave blocks, with the rows unshared, launched pass by pass, and as a resident kernel (sharing its rows or not,
+    from the first pass or taking over after a few armed ones): the same bits, and the oracle's run"""
     D = pkg.datasets.synthetic_grid(192, np.float32)
     M = pkg.datasets.make_model_gpu(D[:4096], *pkg.datasets.P2P_GPU)
     want = orc.icp_p2p_f32x(D, M, 6, 1e-6)
-    forms = {"shared": {}, "unshared": {"ICP_NN_SHARE": "0"}, "resident": {"ICP_RESIDENT": "2"}, "stepwise": {"ICP_RESIDENT": "0", "ICP_ARMED": "0"},
-             "waves16": {"ICP_NN_WAVES128": "16"}}
+    forms = {"shared": {}, "unshared": {"ICP_NN_SHARE": "0"}, "stepwise": {"ICP_RESIDENT": "0", "ICP_ARMED": "0"}, "waves16": {"ICP_NN_WAVES128": "16"},
+             # a resident kernel that shares its rows (roles fixed for the launch, the matches of a split row published by whichever
+             # block closes it): from the first pass -- in a second registration, which has the first one's counts to go by --
+             # without sharing, and taking over from the armed launches after two / four passes
+             "resident": {"ICP_RESIDENT": "2"}, "resident_unshared": {"ICP_RESIDENT": "2", "ICP_NN_SHARE_RESIDENT": "0"},
+             "armed_then_resident_2": {"ICP_SHARE_RESIDENT_AFTER": "2"}, "armed_then_resident_4": {"ICP_SHARE_RESIDENT_AFTER": "4"}}
     res = {}
     for name, env in forms.items():
-        for k in ("ICP_NN_SHARE", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_WAVES128"):
+        for k in ("ICP_NN_SHARE", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_WAVES128", "ICP_NN_SHARE_RESIDENT", "ICP_SHARE_RESIDENT_AFTER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with pkg.Context(0) as c:
-            res[name] = c.point_to_point(D, M, max_iter=6, tol=1e-6)
+            for _ in range(2 if name == "resident" else 1):
+                res[name] = c.point_to_point(D, M, max_iter=6, tol=1e-6)
             assert c.nn_launch_info()["threads"] == (1024 if name == "waves16" else 512), name
     ref = res["shared"]
     assert ref.iterations == want["iterations"] and np.array_equal(ref.idx, want["idx"])
