@@ -35,6 +35,18 @@ for row in 64 128; do
 done
 python3 tools/r2_diag.py > $O/${T}_work_counters_one_registration.json 2> /dev/null
 python3 bench.py --config s5 > $O/${T}_bench_s5_1gpu.json 2> $O/s5.err || echo "s5 exit $?"
+# configs[1], Bunny.csv: the loop forms side by side (one box), what a pass costs early and late in a registration, the blocks of a late pass
+python3 bench.py --config bunny > $O/${T}_bench_bunny.json 2> $O/bunny.err || echo "bunny exit $?"
+{
+  echo "# Bunny.csv 35 947^2, us per iteration of whole registrations (tools/bunny_time.py), same box:"
+  VARIANTS="f a d i" bash tools/r2_share_ab.sh 2> /dev/null | grep -v "^\["
+  if [ -f ab/libicp_r2_02.so ]; then echo "== previous build (r2_02: 16-wave blocks, 4096-entry hit list)"; ICP_LIB_PATH=$R/ab/libicp_r2_02.so python3 tools/bunny_time.py; fi
+  echo "# what a pass costs (registrations of K fixed iterations): this build, then ICP_NN_WAVES128=16"
+  python3 tools/bunny_marginal.py; ICP_NN_WAVES128=16 python3 tools/bunny_marginal.py
+  echo "# other clouds of the size class (tools/grid_time.py): this build, then ICP_NN_WAVES128=16"
+  python3 tools/grid_time.py; ICP_NN_WAVES128=16 python3 tools/grid_time.py
+} > $O/${T}_bunny_shared_rows.txt 2>&1
+PASSES="2 10 20" bash tools/r2_bunny_diag.sh > /dev/null 2>&1; grep -v "^phase [0-9]" gpurun_out/bunny_diag/phases.txt > $O/${T}_bunny_blocks_of_a_pass.txt
 rm -rf $O/kt $O/pf $O/pw
 ls -la $O
 head -12 $O/${T}_kernel_summary.txt

@@ -9,7 +9,7 @@ b) run ICP_RESIDENT=2 ICP_NN_SHARE_RESIDENT=0 ;;
 c) run ICP_SHARE_RESIDENT_AFTER=-1 ;;
 d) run ICP_RESIDENT=0 ICP_NN_SHARE=0 ;;
 e) run ICP_RESIDENT=0 ICP_ARMED=0 ;;
-f) run ICP_TRACE=0 ;;
+f) run ICP_DEFAULT=1 ;;
 g) run ICP_SHARE_RESIDENT_AFTER=3 ;;
 h) run ICP_SHARE_RESIDENT_AFTER=10 ;;
 i) run ICP_RESIDENT=2 ;;
