@@ -976,7 +976,7 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
     }
 }
 
-template <int TAIL, bool phase_diag_, int NWP>
+template <int TAIL, bool phase_diag_, int NWP, bool ROWARG = false>
 __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, const NNFuse& fuse, const NNTail& tail, double err_row, int phase_pass_);
 
 // moment row of one row of 128 moving points, by ONE wave holding them two per lane (px.x = point lane,
@@ -985,7 +985,9 @@ __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, co
 // (qio: the coordinates of the correspondences -- gathered here when `gather`, else supplied by the caller)
 // (ONE: only the lane's first point exists -- rows of 64 points; its contributions go straight to the transpose buffer
 // instead of through 18 register pairs)
-template <int TAIL, bool phase_diag_, int NWP = SP_NW, bool ONE = false>
+// (ROWARG: the row and the kind of index store come with the tail arguments -- nn_match_sparse, whose blocks may share rows; the
+// other kernels close row blockIdx.x with plain stores, and do not pay for the choice)
+template <int TAIL, bool phase_diag_, int NWP = SP_NW, bool ONE = false, bool ROWARG = false>
 __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f2 pz, const int (&j)[2], int lane, const int (&pi)[2],
                                                int m_pad, const NNFuse& fuse, const NNTail& tail, double err_row,
                                                unsigned char* lds_raw, float (&qio)[2][3], bool gather, int phase_pass_ = 0)
@@ -1002,7 +1004,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
         double ppx = 0.0, ppy = 0.0, ppz = 0.0, qx = 0.0, qy = 0.0, qz = 0.0;
         if (live) {
             const int jj = j[0];
-            if (tail.idx_through) __hip_atomic_store(&tail.idx_out[i], jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else tail.idx_out[i] = jj;
+            if (ROWARG && tail.idx_through) __hip_atomic_store(&tail.idx_out[i], jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else tail.idx_out[i] = jj;
             ppx = (double)px.x; ppy = (double)py.x; ppz = (double)pz.x;
             if (gather) { qio[0][0] = Qg[jj]; qio[0][1] = Qg[(size_t)m_pad + jj]; qio[0][2] = Qg[2 * (size_t)m_pad + jj]; }
             qx = (double)qio[0][0]; qy = (double)qio[0][1]; qz = (double)qio[0][2];
@@ -1026,7 +1028,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
             const int i = fresh(pi[t]);
             if (i < fuse.n) {
                 const int jj = j[t];
-                if (tail.idx_through) __hip_atomic_store(&tail.idx_out[i], jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else tail.idx_out[i] = jj;
+                if (ROWARG && tail.idx_through) __hip_atomic_store(&tail.idx_out[i], jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else tail.idx_out[i] = jj;
                 const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
                 if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
                 const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
@@ -1053,7 +1055,7 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
             double cn[6] = {0, 0, 0, 0, 0, 0}, bb = 0.0;
             if (live) {
                 const int jj = j[t];
-                if (tail.idx_through) __hip_atomic_store(&tail.idx_out[i], jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else tail.idx_out[i] = jj;
+                if (ROWARG && tail.idx_through) __hip_atomic_store(&tail.idx_out[i], jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else tail.idx_out[i] = jj;
                 const double ppx = (double)(t ? px.y : px.x), ppy = (double)(t ? py.y : py.x), ppz = (double)(t ? pz.y : pz.x);
                 if (gather) { qio[t][0] = Qg[jj]; qio[t][1] = Qg[(size_t)m_pad + jj]; qio[t][2] = Qg[2 * (size_t)m_pad + jj]; }
                 const double qx = (double)qio[t][0], qy = (double)qio[t][1], qz = (double)qio[t][2];
@@ -1079,17 +1081,17 @@ __device__ __forceinline__ void tail_close_row(const f2 px, const f2 py, const f
         }
         ICP_PHASE(7)
     }
-    tail_reduce_store<TAIL, phase_diag_, NWP>(tr, lane, fuse, tail, err_row, phase_pass_);
+    tail_reduce_store<TAIL, phase_diag_, NWP, ROWARG>(tr, lane, fuse, tail, err_row, phase_pass_);
 }
 
 // second half of a row tail: the transpose buffer is summed slot by slot in a fixed order and the row goes out
-template <int TAIL, bool phase_diag_, int NWP>
+template <int TAIL, bool phase_diag_, int NWP, bool ROWARG>
 __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, const NNFuse& fuse, const NNTail& tail, double err_row, int phase_pass_)
 {
     constexpr int w = 0, phase_nw_ = NWP;  // (phase log) the closing wave of a sparse-kernel block
     constexpr int NACC = TAIL == 2 ? 28 : 18;
     lds_same_wave_order();
-    const unsigned int rowi = tail.row >= 0 ? (unsigned int)tail.row : blockIdx.x;
+    const unsigned int rowi = (ROWARG && tail.row >= 0) ? (unsigned int)tail.row : blockIdx.x;
     double* row = tail.rows + (size_t)rowi * ICP_NMOM;
     // Slot k is the sum of its 64 lane entries in a FIXED order: PARTS lanes per slot add a contiguous share each
     // (loaded first, added after: the LDS latencies overlap), the shares are then added in part order.
@@ -2010,7 +2012,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
         tl.row = row;
         tl.idx_through = (SP_SHARED && fuse.resident) ? 1 : 0;
         if (parts == 1) { ICP_PHASE(6) }
-        tail_close_row<TAIL, DIAG, NWS>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gather_in_tail, pass);
+        tail_close_row<TAIL, DIAG, NWS, false, true>(px, py, pz, fj, lane, pi, m_pad, fuse, tl, apply ? err_row : 0.0, lds_raw, sq, gather_in_tail, pass);
         ICP_PHASE(9)
         if (fuse.slot_state != nullptr) {   // the matched model points, in slot order, for the next pass (one segment; a shared row: gathered by the tail)
 #pragma unroll
