@@ -1158,7 +1158,11 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     constexpr int OVL_BYTES = NWS == 8 ? MKEY_OFF + 128 * 8 : HITS_BYTES + 2 * SP_NW * 128 * 4;
     constexpr int TR_BYTES = TAIL ? ((TAIL == 2 ? 28 : 18) * 65 + 64) * 8 : 0;
     static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
-    constexpr int STAGE_OFF = OVL_BYTES + 128 * 4 + 16, STAGE_BYTES = NWS * 8 * STG * 4;
+    // hits a wave fetches per trip to memory (its stage holds them): 8 per gather instruction; the hierarchical search (no box
+    // cache in LDS) has the room for two -- a block with 9..16 hits per wave makes one trip, not two, and the median block of a
+    // late pass on the 10 M-point model has 8.3
+    constexpr int HB = (HIER && NWS == 16) ? 16 : 8;
+    constexpr int STAGE_OFF = OVL_BYTES + 128 * 4 + 16, STAGE_BYTES = NWS * HB * STG * 4;
     constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
     constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x NWS x 128
     // flat search: the chunk boxes of every wave's first PRE find passes are cached in LDS (the model does not change during
@@ -1277,7 +1281,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     int pi[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) pi[t] = fuse.p_perm ? fuse.p_perm[ibase + t * 64] : ibase + t * 64;
-    float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (8 * STG);  // per wave: 8 hits x {box 8, x 8, y 8, z 8, model index 8}
+    float* stage = reinterpret_cast<float*>(lds_raw + STAGE_OFF) + w * (HB * STG);  // per wave: HB hits x {box 8, x 8, y 8, z 8, model index 8}
     float* msg = reinterpret_cast<float*>(lds_raw + MSG_OFF);
     float (*seedq)[128] = reinterpret_cast<float (*)[128]>(lds_raw + SEED_OFF);
     float (*mq)[NWS][128] = reinterpret_cast<float (*)[NWS][128]>(lds_raw + MQ_OFF);
@@ -1625,19 +1629,23 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     // (exchanging minima between the batches of a cold pass was measured too: the barriers cost more than they save)
     auto gather_batch = [&](const int hb, const int h1) {
             {
-                const int r = lane >> 3, part = lane & 7;
-                const int h = hb + r * NWS + w;
-                if (h < h1) {
-                    const int chl = (int)hits[h];
-                    const float* src = part < 2 ? fuse.boxes + (size_t)chl * 8 + part * 4
-                                                : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)chl * 8 + (part & 1) * 4;
-                    *reinterpret_cast<float4*>(stage + r * STG + part * 4) = *reinterpret_cast<const float4*>(src);
-                }
+                const int part = lane & 7;
+                // (the loads of a trip are issued together; named values, not an array: the compiler moves private arrays to LDS)
+                const int r0 = lane >> 3, h0 = hb + r0 * NWS + w, h8 = hb + (r0 + 8) * NWS + w;
+                const bool on0 = h0 < h1, on8 = HB > 8 && h8 < h1;
+                const int ch0 = on0 ? (int)hits[h0] : 0, ch8 = on8 ? (int)hits[h8] : 0;
+                const float* src0 = part < 2 ? fuse.boxes + (size_t)ch0 * 8 + part * 4 : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)ch0 * 8 + (part & 1) * 4;
+                const float* src8 = part < 2 ? fuse.boxes + (size_t)ch8 * 8 + part * 4 : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)ch8 * 8 + (part & 1) * 4;
+                float4 v0 = float4{0.f, 0.f, 0.f, 0.f}, v8 = v0;
+                if (on0) v0 = *reinterpret_cast<const float4*>(src0);
+                if constexpr (HB > 8) { if (on8) v8 = *reinterpret_cast<const float4*>(src8); }
+                if (on0) *reinterpret_cast<float4*>(stage + r0 * STG + part * 4) = v0;
+                if constexpr (HB > 8) { if (on8) *reinterpret_cast<float4*>(stage + (r0 + 8) * STG + part * 4) = v8; }
                 // a sorted view: the elements' model indices (the sort permutation) are staged too
                 if constexpr (PERM) {
                     const int r2 = lane >> 1, half = lane & 1;
                     const int h2 = hb + r2 * NWS + w;
-                    if (lane < 16 && h2 < h1)
+                    if (lane < 2 * HB && h2 < h1)
                         *reinterpret_cast<int4*>(stage + r2 * STG + 32 + half * 4) =
                             *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)(int)hits[h2] * 8 + half * 4);
                 }
@@ -1646,7 +1654,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     };
     auto scan_batch = [&](const int hb, const int h1) {
             const int mine = (h1 - hb - w + NWS - 1) / NWS;     // this wave's hits in the batch
-            const int cnt = mine < 8 ? mine : 8;
+            const int cnt = mine < HB ? mine : HB;
             for (int rr = 0; rr < cnt; ++rr) {
                 int stage_reached;
                 if constexpr (PERM) {
@@ -1673,7 +1681,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
         }
     };
     auto process_hits = [&](const int h1) {
-        for (int hb = 0; hb < h1; hb += NWS * 8) {
+        for (int hb = 0; hb < h1; hb += NWS * HB) {
             gather_batch(hb, h1);
             if (hb == 0) sub_stamp(7);
             scan_batch(hb, h1);
@@ -1861,7 +1869,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
         if (covered) {
             const int h1 = *hcount;   // (the list's length is still in the counter)
             scan_batch(0, h1);        // the first batch sits in the stages
-            for (int hb = NWS * 8; hb < h1; hb += NWS * 8) { gather_batch(hb, h1); scan_batch(hb, h1); }
+            for (int hb = NWS * HB; hb < h1; hb += NWS * HB) { gather_batch(hb, h1); scan_batch(hb, h1); }
             searched = true;
         } else {
             if (threadIdx.x == 0) *hcount = 0;   // the guess did not hold: forget the list and search as usual
@@ -2075,7 +2083,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             find_round(0, sp_B, sp_lo, sp_hi);
             __syncthreads();
             const int spec_n = *hcount;
-            if (spec_n <= 4 * NWS * 8) {   // (up to four batches: the first is fetched now, the others when the list is used)
+            if (spec_n <= 4 * NWS * HB) {   // (up to four batches: the first is fetched now, the others when the list is used)
                 gather_batch(0, spec_n);
                 spec_valid = true;
             } else {
