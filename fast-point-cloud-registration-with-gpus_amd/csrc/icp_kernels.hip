@@ -1209,7 +1209,10 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             // (the counts were made by agent-scope atomics of the previous launch, at the memory side: they are read the same
             // way -- a plain load may be served by a stale line of this XCD's L2, and blocks that disagree about the counts
             // disagree about the roles)
-            const unsigned int h = t < R ? __hip_atomic_load(&fuse.share_prev[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            // (clamped: the sums below stay within 32 bits whatever the counters hold, and with them the guarantee that the parts
+            // fit the grid -- a wrapped total once dealt more roles than there were blocks: rows without all their parts never close)
+            unsigned int h = t < R ? __hip_atomic_load(&fuse.share_prev[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            h = h > (1u << 20) ? (1u << 20) : h;
             if (blockIdx.x == 0 && t < R) {
                 __hip_atomic_store(&fuse.share_next[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (fuse.share_zero2 != nullptr) __hip_atomic_store(&fuse.share_zero2[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1261,7 +1264,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
                                            (s23 & 0xffffu) <= G ? (T0 * 6u + 7u) / 8u : (s23 >> 16) <= G ? (T0 * 7u + 7u) / 8u : T0;
                 T = Tbest < Tmin ? Tmin : Tbest;
             }
-            const unsigned int S = parts_for(T);
+            unsigned int S = parts_for(T);
             int v = (int)S;   // inclusive running sum within the wave, then across the waves
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); v += lane >= o ? u : 0; }
@@ -1270,7 +1273,12 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             int base = 0;
 #pragma unroll
             for (int k = 0; k < NWS; ++k) base += k < w ? role[4 + NWS + k] : 0;
-            const int excl = base + v - (int)S;
+            int all = 0;   // every role of the launch; belt and braces: if they do not fit the grid, every row is one block
+#pragma unroll
+            for (int k = 0; k < NWS; ++k) all += role[4 + NWS + k];
+            const bool fits = all <= (int)gridDim.x;
+            const int excl = fits ? base + v - (int)S : t;
+            if (!fits) S = t < R ? 1u : 0u;
             if (t < R && (int)blockIdx.x >= excl && (int)blockIdx.x < excl + (int)S) { role[0] = t; role[1] = (int)blockIdx.x - excl; role[2] = (int)S; if constexpr (DIAG) { role[3] = (int)h; role[4] = (int)T; } }
             __syncthreads();
             if (role[0] < 0) return;
@@ -4416,6 +4424,9 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
                     const unsigned long long k = (*opt->share_cold_seq)++;
                     fuse.share_prev = cold + ((k + 1) % 2) * R;
                     fuse.share_cur2 = cold + (k % 2) * R;
+                    // (zeroed by block 0 as it starts, long before any block has a list to count: where every launch is a first pass --
+                    // resident kernels, one per registration -- nothing else would, and the counts of all registrations would pile up)
+                    fuse.share_zero2 = fuse.share_cur2;
                 } else {
                     fuse.share_zero2 = cold + (*opt->share_cold_seq % 2) * R;
                 }
