@@ -593,6 +593,7 @@ def test_moving_cloud_with_shared_rows(pkg, orc, monkeypatch):
     assert rel(ref.T, want["T"]) < TOL_T
     for name, r in res.items():
         assert r.iterations == ref.iterations and np.array_equal(r.T, ref.T) and np.array_equal(r.idx, ref.idx), name
+        assert np.array_equal(r.moved, ref.moved), name   # (the moved cloud as the device holds it after the loop)
         # (the loop ends at max_iter: the last entry is the error-only pass -- a TRANSFORM_ONLY message to the resident kernel, whose
         # compact rows carry their tag in the low 16 mantissa bits of the error share, or the stand-alone transform kernel)
         assert np.array_equal(r.err[:-1], ref.err[:-1]) and abs(r.err[-1] - ref.err[-1]) <= 1e-10 * ref.err[-1], name
