@@ -166,6 +166,27 @@ def test_bunny_registration_full_size_against_the_oracle(pkg, orc, golden, monke
     assert np.allclose(res.err[1:], want["err"][1:], rtol=1e-6)
 
 
+def test_bunny_point_to_plane_forms_are_bit_identical(pkg, golden, monkeypatch):
+    """configs[1]'s cloud through the point-to-plane loop (6 x 6 rows; 8-wave blocks with shared rows, 16-wave blocks, a resident
+    kernel sharing its rows in a second registration, one launch per pass): the same iterations, transform, error series
+    and correspondences"""
+    B = np.fromfile(os.path.join(golden, "bunny_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
+    M = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
+    res = {}
+    for name, env in (("shared", {}), ("waves16", {"ICP_NN_WAVES128": "16"}), ("resident", {"ICP_RESIDENT": "2"}), ("stepwise", {"ICP_RESIDENT": "0", "ICP_ARMED": "0"})):
+        for k in ("ICP_NN_SHARE", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_WAVES128", "ICP_NN_SHARE_RESIDENT", "ICP_SHARE_RESIDENT_AFTER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.Context(0) as c:
+            for _ in range(2 if name == "resident" else 1):
+                res[name] = c.point_to_plane(B, M, max_iter=30, tol=1e-6)
+    ref = res["stepwise"]
+    assert ref.iterations >= 3
+    for name, r in res.items():
+        assert r.iterations == ref.iterations and np.array_equal(r.T, ref.T) and np.array_equal(r.err, ref.err) and np.array_equal(r.idx, ref.idx), name
+
+
 # ---------------------------------------------------------------------------------------------------
 # the loop, pass by pass, from captured inputs
 # ---------------------------------------------------------------------------------------------------
