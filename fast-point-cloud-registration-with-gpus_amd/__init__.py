@@ -5,4 +5,4 @@ from . import _capi as capi  # noqa: F401
 from . import datasets  # noqa: F401
 from . import distributed  # noqa: F401
 from ._capi import ICP_F32, ICP_F64, ICP_NMOM, ICP_POINT_TO_PLANE, ICP_POINT_TO_POINT, IcpError, load  # noqa: F401
-from .engine import Context, LocalComm, Result, eigh3, shard_range, solve_point_to_plane, solve_point_to_point  # noqa: F401
+from .engine import Context, LocalComm, Result, eigh3, shard_range, share_rows_plan, solve_point_to_plane, solve_point_to_point  # noqa: F401

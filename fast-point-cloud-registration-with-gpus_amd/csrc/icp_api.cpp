@@ -1117,6 +1117,14 @@ int icp_nn_match_bench_launches(icp_ctx* c, int reps, int warmups, int mode, flo
     return ICP_OK;
 }
 
+int icp_share_rows_plan(const uint32_t* hits, int rows, int blocks, int model_points, int min_hits, int32_t* parts, uint32_t* target)
+{
+    if (!hits || !parts || rows < 1 || blocks < rows || model_points < 1 || min_hits < 1) return fail(ICP_ERR_INVALID, "icp_share_rows_plan: bad arguments");
+    const unsigned int T = icp::share_rows_plan(hits, rows, blocks, icp::pad_model(model_points), min_hits, parts);
+    if (target) *target = T;
+    return ICP_OK;
+}
+
 int icp_nn_launch_info_ex(icp_ctx* c, int dense, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad)
 {
     if (!c) return fail(ICP_ERR_INVALID, "null context");

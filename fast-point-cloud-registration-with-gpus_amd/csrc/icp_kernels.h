@@ -145,6 +145,40 @@ enum {
     NN_WORK_LIST_HITS = 11,       // hits on the lists built by the ordinary find
     NN_WORK_SLOTS = 12
 };
+// Shared rows: how a launch of `blocks` blocks deals itself to `rows` rows, given the hits every row had in the launch
+// before (nn_match_sparse computes this in every block, from the same counters: the pieces below are what it is made of,
+// and share_rows_plan is the same computation on the host -- icp_share_rows_plan, tests/test_host.py).
+//   parts(row) = clamp(ceil(h / T), 1, cap),  cap = min(64-chunk tiles of the model, 32)
+//   T0 = ceil(total / spare) always fits (sum of ceil(h / T0) <= total / T0 + rows = blocks); four tighter targets, 4/8 .. 7/8
+//   of T0, are tried and the smallest that fits is taken; never below `min_hits`.  The counts are clamped to 2^20 before
+//   anything is added up: 512 rows x 2^20 stays within 32 bits, and with it the guarantee that the parts fit the grid.
+constexpr unsigned int SHARE_COUNT_CLAMP = 1u << 20;
+constexpr unsigned int SHARE_MAX_PARTS = 32u;
+ICP_HOST_DEVICE inline unsigned int share_clamp(unsigned int h) { return h > SHARE_COUNT_CLAMP ? SHARE_COUNT_CLAMP : h; }
+ICP_HOST_DEVICE inline unsigned int share_cap(int m_pad)
+{
+    const unsigned int tiles = (unsigned int)((((m_pad >> 3) + 63) >> 6));
+    return tiles < SHARE_MAX_PARTS ? (tiles < 1u ? 1u : tiles) : SHARE_MAX_PARTS;
+}
+ICP_HOST_DEVICE inline unsigned int share_parts(unsigned int h, unsigned int T, unsigned int cap)
+{
+    unsigned int S = (h + T - 1u) / T;
+    S = S > cap ? cap : S;
+    return S < 1u ? 1u : S;
+}
+ICP_HOST_DEVICE inline unsigned int share_first_target(unsigned int total, unsigned int spare) { return spare ? (total + spare - 1u) / spare : 0xffffffffu; }
+ICP_HOST_DEVICE inline unsigned int share_candidate(unsigned int T0, int k) { return (T0 * (unsigned int)(4 + k) + 7u) / 8u; }   // k = 0..3
+ICP_HOST_DEVICE inline bool share_tries_candidates(unsigned int T0, unsigned int Tmin, unsigned int spare) { return spare != 0u && T0 > Tmin && T0 < 0x10000000u; }
+// sums[k] = blocks the launch would need with candidate k
+ICP_HOST_DEVICE inline unsigned int share_pick(unsigned int T0, unsigned int Tmin, const unsigned int (&sums)[4], unsigned int blocks)
+{
+    unsigned int T = T0;
+    for (int k = 3; k >= 0; --k) T = sums[k] <= blocks ? share_candidate(T0, k) : T;   // (the smallest candidate that fits: k = 0 last)
+    return T < Tmin ? Tmin : T;
+}
+// the same on the host: parts_out[rows]; returns the target (hits per block)
+unsigned int share_rows_plan(const unsigned int* hits, int rows, int blocks, int m_pad, int min_hits, int* parts_out);
+
 // device-side preparation of the sparse kernel's views (icp_set_model / icp_set_moving): scratch owned by the caller
 struct PrepBuffers {
     unsigned int* keys[2];   // >= count each

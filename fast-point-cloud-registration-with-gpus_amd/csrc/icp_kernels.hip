@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             // (clamped: the sums below stay within 32 bits whatever the counters hold, and with them the guarantee that the parts
             // fit the grid -- a wrapped total once dealt more roles than there were blocks: rows without all their parts never close)
             unsigned int h = t < R ? __hip_atomic_load(&fuse.share_prev[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            h = h > (1u << 20) ? (1u << 20) : h;
+            h = share_clamp(h);
             if (blockIdx.x == 0 && t < R) {
                 __hip_atomic_store(&fuse.share_next[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (fuse.share_zero2 != nullptr) __hip_atomic_store(&fuse.share_zero2[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1227,26 +1227,17 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
 #pragma unroll
             for (int k = 0; k < NWS; ++k) total += (unsigned int)role[4 + k];
             const unsigned int spare = gridDim.x > (unsigned)R ? gridDim.x - (unsigned)R : 0u;
-            // T0 = ceil(total / spare) always fits (sum of ceil(h / T0) <= total / T0 + rows), but leaves blocks unused -- the
-            // rounding costs half a block per split row, not a whole one.  Four tighter targets, 4/8 .. 7/8 of T0, are tried
-            // at once (their block counts added up in one reduction); the smallest one that fits is taken.
-            const unsigned int T0 = spare ? (total + spare - 1u) / spare : 0xffffffffu;
-            const unsigned int tiles = (unsigned)((((m_pad >> 3) + 63) >> 6));
-            const unsigned int cap = tiles < 32u ? tiles : 32u;
-            auto parts_for = [&](unsigned int T) {
-                unsigned int S = (h + T - 1u) / T;
-                S = S > cap ? cap : S;
-                return t < R ? (S < 1u ? 1u : S) : 0u;
-            };
+            // (the arithmetic of the assignment is in icp_kernels.h, share_*: the host computes the same for the tests)
+            const unsigned int T0 = share_first_target(total, spare);
+            const unsigned int cap = share_cap(m_pad);
+            auto parts_for = [&](unsigned int T) { return t < R ? share_parts(h, T, cap) : 0u; };
             const unsigned int Tmin = (unsigned int)fuse.share_min;
             unsigned int T = T0 < Tmin ? Tmin : T0;
-            if (spare && T0 > Tmin && T0 < 0x10000000u) {
-                unsigned int c01 = 0, c23 = 0;   // two 16-bit counts each (<= 512 rows x 32 parts)
-                {
-                    const unsigned int Ta = (T0 * 4u + 7u) / 8u, Tb = (T0 * 5u + 7u) / 8u, Tc = (T0 * 6u + 7u) / 8u, Td = (T0 * 7u + 7u) / 8u;
-                    c01 = parts_for(Ta) | (parts_for(Tb) << 16);
-                    c23 = parts_for(Tc) | (parts_for(Td) << 16);
-                }
+            if (share_tries_candidates(T0, Tmin, spare)) {
+                // four tighter targets at once: their block counts are added up in one reduction (two 16-bit counts a word:
+                // <= 512 rows x 32 parts)
+                unsigned int c01 = parts_for(share_candidate(T0, 0)) | (parts_for(share_candidate(T0, 1)) << 16);
+                unsigned int c23 = parts_for(share_candidate(T0, 2)) | (parts_for(share_candidate(T0, 3)) << 16);
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
                     c01 += (unsigned int)__shfl_xor((int)c01, off, 64);
@@ -1259,10 +1250,8 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
 #pragma unroll
                 for (int k = 0; k < NWS; ++k) { s01 += (unsigned int)role[4 + k]; s23 += (unsigned int)role[4 + NWS + k]; }
                 __syncthreads();   // (... and these: the running sums below use the same words)
-                const unsigned int G = gridDim.x;
-                const unsigned int Tbest = (s01 & 0xffffu) <= G ? (T0 * 4u + 7u) / 8u : (s01 >> 16) <= G ? (T0 * 5u + 7u) / 8u :
-                                           (s23 & 0xffffu) <= G ? (T0 * 6u + 7u) / 8u : (s23 >> 16) <= G ? (T0 * 7u + 7u) / 8u : T0;
-                T = Tbest < Tmin ? Tmin : Tbest;
+                const unsigned int sums[4] = {s01 & 0xffffu, s01 >> 16, s23 & 0xffffu, s23 >> 16};
+                T = share_pick(T0, Tmin, sums, gridDim.x);
             }
             unsigned int S = parts_for(T);
             int v = (int)S;   // inclusive running sum within the wave, then across the waves
@@ -4067,6 +4056,29 @@ static int env_int(const char* name, int dflt)
     const char* v = getenv(name);
     if (!v || !*v) return dflt;
     return atoi(v);
+}
+
+unsigned int share_rows_plan(const unsigned int* hits, int rows, int blocks, int m_pad, int min_hits, int* parts_out)
+{
+    // (statement by statement what a block of nn_match_sparse computes; the block's reductions are plain loops here)
+    unsigned int total = 0;
+    for (int r = 0; r < rows; ++r) total += share_clamp(hits[r]);
+    const unsigned int spare = blocks > rows ? (unsigned int)(blocks - rows) : 0u;
+    const unsigned int T0 = share_first_target(total, spare), cap = share_cap(m_pad), Tmin = (unsigned int)min_hits;
+    unsigned int T = T0 < Tmin ? Tmin : T0;
+    if (share_tries_candidates(T0, Tmin, spare)) {
+        unsigned int sums[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; ++k) {
+            for (int r = 0; r < rows; ++r) sums[k] += share_parts(share_clamp(hits[r]), share_candidate(T0, k), cap);
+            sums[k] &= 0xffffu;   // (16-bit fields in the kernel; <= 512 x 32 never reaches them)
+        }
+        T = share_pick(T0, Tmin, sums, (unsigned int)blocks);
+    }
+    long long all = 0;
+    for (int r = 0; r < rows; ++r) { parts_out[r] = (int)share_parts(share_clamp(hits[r]), T, cap); all += parts_out[r]; }
+    if (all > blocks)
+        for (int r = 0; r < rows; ++r) parts_out[r] = 1;   // (cannot happen with clamped counts and blocks >= rows; the kernel falls back the same way)
+    return T;
 }
 
 NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense)

@@ -335,6 +335,18 @@ def shard_range(n, rank, world):
     return b.value, c.value
 
 
+def share_rows_plan(hits, blocks, model_points, min_hits=64):
+    """how a launch of `blocks` matching blocks deals itself to the rows whose hit counts of the previous launch are `hits`
+    (icp_share_rows_plan): returns (parts per row, target hits per block)"""
+    lib = capi.load()
+    hits = np.ascontiguousarray(hits, dtype=np.uint32)
+    parts = np.zeros(hits.shape[0], dtype=np.int32)
+    target = C.c_uint32(0)
+    capi.check(lib.icp_share_rows_plan(hits.ctypes.data_as(C.POINTER(C.c_uint32)), int(hits.shape[0]), int(blocks), int(model_points), int(min_hits),
+                                       parts.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(target)), "icp_share_rows_plan")
+    return parts, int(target.value)
+
+
 def eigh3(A):
     lib = capi.load()
     A = np.ascontiguousarray(A, dtype=np.float64).reshape(9)

@@ -240,6 +240,11 @@ int icp_host_loop_note_applied(icp_host_loop* h);
 int icp_host_loop_state(icp_host_loop* h, int* iterations, int* passes, double* err, int err_cap, double* T16);
 /* contiguous shard [begin, begin+count) of n moving points for `rank` of `world` */
 int icp_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t* count);
+/* shared rows (clouds of 33-57 k moving points): how a matching launch of `blocks` blocks deals itself to `rows`
+ * rows of 128 moving points, given the hit chunks every row listed in the launch before -- parts[r] blocks search row r
+ * (>= 1 each, their sum <= blocks whatever the counts hold), *target = hits per block the split aims at.  The kernel computes
+ * exactly this in every block; no device is involved here (no reference counterpart: its kernels are thread-per-point). */
+int icp_share_rows_plan(const uint32_t* hits, int rows, int blocks, int model_points, int min_hits, int32_t* parts, uint32_t* target);
 /* symmetric 3x3 eigen-solve used for the normals (upper triangle of row-major A read);
  * w ascending, Z[i*3+k] = component i of eigenvector k */
 int icp_eigh3(const double* A9, double* w3, double* Z9);

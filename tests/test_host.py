@@ -204,3 +204,43 @@ def test_bench_refuses_a_rank_count_that_does_not_match_the_launcher():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+def test_shared_rows_plan_always_fits_the_grid(pkg):
+    """the role assignment of a launch with shared rows (the arithmetic nn_match_sparse runs in every block, mirrored on the host
+    by icp_share_rows_plan): every row gets at least one block, never more than 32, the parts never outnumber the blocks --
+    whatever the counters hold, including the sums past 2^32 that a soak once produced (rows missing a part never close) --
+    a heavy row gets more parts than a light one, and the split is as fine as the grid allows"""
+    rng = np.random.default_rng(11)
+    cases = []
+    for _ in range(300):
+        rows = int(rng.integers(1, 513))
+        blocks = int(rows + rng.integers(0, 513))
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            hits = rng.integers(0, 200, rows)
+        elif kind == 1:
+            hits = (rng.pareto(1.2, rows) * 80).astype(np.int64)
+        elif kind == 2:
+            hits = rng.integers(0, 2**32, rows)                    # counters that were never zeroed
+        elif kind == 3:
+            hits = np.zeros(rows, dtype=np.int64)
+        else:
+            hits = np.full(rows, 2**32 - 1)
+        cases.append((np.minimum(hits, 2**32 - 1).astype(np.uint32), blocks, int(rng.choice([300, 4096, 35947, 65536]))))
+    for hits, blocks, m in cases:
+        parts, target = pkg.share_rows_plan(hits, blocks, m)
+        assert parts.min() >= 1 and parts.max() <= 32 and parts.sum() <= blocks, (hits[:8], blocks, m)
+        assert target >= 64
+        o = np.argsort(np.minimum(hits, 1 << 20), kind="stable")
+        assert (np.diff(parts[o]) >= 0).all()                       # monotone in the (clamped) count
+    # Bunny.csv late in a registration: 288 rows, 512 blocks, a few rows far heavier than the rest
+    hits = np.full(288, 70, dtype=np.uint32); hits[[175, 244, 90]] = (1147, 934, 538)
+    parts, target = pkg.share_rows_plan(hits, 512, 35947)
+    assert parts[175] >= 8 and parts[244] >= 6 and parts[90] >= 4 and target <= 128
+    assert int(np.ceil(hits / parts).max()) <= target
+    # no spare blocks, or nothing known: one block per row
+    assert (pkg.share_rows_plan(hits, 288, 35947)[0] == 1).all()
+    assert (pkg.share_rows_plan(np.zeros(288, dtype=np.uint32), 512, 35947)[0] == 1).all()
+    with pytest.raises(pkg.IcpError):
+        pkg.share_rows_plan(hits, 100, 35947)                      # fewer blocks than rows
