@@ -249,6 +249,7 @@ struct icp_ctx {
     DevBuf work;             // icp_set_work_counting: NN_WORK_SLOTS counters of the work the sparse kernel executes
     bool count_work = false;
     DevBuf phase_log;        // ICP_NN_PHASES diagnostic
+    size_t phase_slots = 0;
     std::string phase_path;
     DevBuf P, P2, Q, Qs, Nrm, stage;  // Qs: duplicate-voided scan copy of the model (fp32 early-out kernel)
     bool have_scan_copy = false;
@@ -645,10 +646,14 @@ int icp_create(int device, icp_ctx** out)
     if (const char* v = std::getenv("ICP_NN_PHASES")) {
         // diagnostic: the matching kernel stamps its phases per wave; the last launch's stamps are written to the
         // named file (raw int64) when the context is destroyed -- tools/phase_report.py reads it
-        if (v[0] && c->phase_log.ensure(kPhaseSlots * sizeof(long long)) == hipSuccess &&
-            hipMemset(c->phase_log.p, 0, kPhaseSlots * sizeof(long long)) == hipSuccess) {
+        // (ICP_NN_PHASE_SLOTS: room for more than the default 3277 sixteen-wave blocks -- 160 stamps a block)
+        size_t slots = kPhaseSlots;
+        if (const char* sl = std::getenv("ICP_NN_PHASE_SLOTS")) { const long long w = std::atoll(sl); if (w > 0 && w <= (1ll << 28)) slots = (size_t)w; }
+        if (v[0] && c->phase_log.ensure(slots * sizeof(long long)) == hipSuccess &&
+            hipMemset(c->phase_log.p, 0, slots * sizeof(long long)) == hipSuccess) {
             c->phase_path = v;
-            icp::set_phase_log((long long*)c->phase_log.p, (long long)kPhaseSlots);
+            c->phase_slots = slots;
+            icp::set_phase_log((long long*)c->phase_log.p, (long long)slots);
         }
     }
     if (const char* v = std::getenv("ICP_SELFTEST"))
@@ -670,8 +675,8 @@ void icp_destroy(icp_ctx* c)
     if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
     if (c->phase_log.p && !c->phase_path.empty()) {
         icp::set_phase_log(nullptr, 0);
-        std::vector<long long> h(kPhaseSlots);
-        if (hipMemcpy(h.data(), c->phase_log.p, kPhaseSlots * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+        std::vector<long long> h(c->phase_slots);
+        if (hipMemcpy(h.data(), c->phase_log.p, c->phase_slots * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
             if (FILE* f = std::fopen(c->phase_path.c_str(), "wb")) { std::fwrite(h.data(), sizeof(long long), h.size(), f); std::fclose(f); }
         }
         c->phase_log.release();

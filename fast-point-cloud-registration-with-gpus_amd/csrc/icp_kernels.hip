@@ -1594,9 +1594,14 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     }
     ICP_PHASE(2)
 
-    // bounding box of the block's 128 moving points (every wave derives the same one)
-    float glo[3] = {__builtin_fminf(px.x, px.y), __builtin_fminf(py.x, py.y), __builtin_fminf(pz.x, pz.y)};
-    float ghi[3] = {__builtin_fmaxf(px.x, px.y), __builtin_fmaxf(py.x, py.y), __builtin_fmaxf(pz.x, pz.y)};
+    // bounding box of the block's 128 moving points (every wave derives the same one) -- of its REAL points: the padding of a
+    // partly filled last row never asks for a chunk, and wherever it lies it must not widen the box the chunks are listed by
+    // (the 10 M-point share of one rank of 8 ends in such a row: 122 544 chunks on its list, 2.1 ms of a 3.0 ms pass, alone)
+    const float binf = inf_<float>();
+    float glo[3] = {__builtin_fminf(real[0] ? px.x : binf, real[1] ? px.y : binf), __builtin_fminf(real[0] ? py.x : binf, real[1] ? py.y : binf),
+                    __builtin_fminf(real[0] ? pz.x : binf, real[1] ? pz.y : binf)};
+    float ghi[3] = {__builtin_fmaxf(real[0] ? px.x : -binf, real[1] ? px.y : -binf), __builtin_fmaxf(real[0] ? py.x : -binf, real[1] ? py.y : -binf),
+                    __builtin_fmaxf(real[0] ? pz.x : -binf, real[1] ? pz.y : -binf)};
     wave_box(glo, ghi);
 
     const int round_tiles = NWS * round_passes;                                         // 64-chunk tiles a round of the find covers
@@ -2526,8 +2531,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64(const
             __syncthreads();
         }
     }
-    // bounding box of the block's 64 moving points (every wave derives the same one)
-    float glo[3] = {x, y, z}, ghi[3] = {x, y, z};
+    // bounding box of the block's 64 moving points (every wave derives the same one; of its real points: see nn_match_sparse)
+    const float binf = inf_<float>();
+    float glo[3] = {real ? x : binf, real ? y : binf, real ? z : binf}, ghi[3] = {real ? x : -binf, real ? y : -binf, real ? z : -binf};
     if (!searched) {
         wave_box(glo, ghi);
         for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
@@ -2888,8 +2894,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(c
         if (w == 0) smin[lane] = kInfBits;
     }
     // bounding box of the block's 64 points (every wave derives the same one)
-    const double glo[3] = {wave_min_f64(x), wave_min_f64(y), wave_min_f64(z)};
-    const double ghi[3] = {wave_max_f64(x), wave_max_f64(y), wave_max_f64(z)};
+    const double binf = inf_<double>();   // (the box of the REAL points: see nn_match_sparse)
+    const double glo[3] = {wave_min_f64(real ? x : binf), wave_min_f64(real ? y : binf), wave_min_f64(real ? z : binf)};
+    const double ghi[3] = {wave_max_f64(real ? x : -binf), wave_max_f64(real ? y : -binf), wave_max_f64(real ? z : -binf)};
     const int round_chunks = NW * 64 * round_passes;
     for (int rb = c_lo; rb < c_hi; rb += round_chunks) {
         const double B = wave_max_f64(best);   // only shrinks while the block works: refreshed once per round
