@@ -240,6 +240,8 @@ struct icp_ctx {
     DevBuf share_counts;                        // shared rows (NNPlan::share_blocks): 5 x blocks_x hit counters (3 in rotation from launch to launch, 2 for first passes)
     mutable unsigned long long share_seq = 0;   // ... the launches so far (advanced by the launcher)
     mutable unsigned long long share_cold_seq = 0;   // ... and those that were the first pass of a registration
+    DevBuf row_hits, order_keys[2], order_vals[2], order_tmp;   // ordered rows (NNPlan::order): hits per row, and the sort that turns them into the next launch's order
+    const int32_t* row_order = nullptr;          // ... the order the next launch follows (device; NULL: index order)
     DevBuf seed_pub;                            // ... resident launches: blocks_x x 384 floats, the matches of split rows for their other blocks
     int share_resident_after = -1;              // ... ICP_SHARE_RESIDENT_AFTER=n: a registration runs armed launches for n passes, then one resident kernel (< 0, the default: armed throughout)
     bool model_sorted = false, moving_sorted = false;
@@ -381,6 +383,16 @@ int ensure_work_buffers(icp_ctx* c)
             c->share_cold_seq = 0;
         }
         HIP_TRY(c->seed_pub.ensure((size_t)pl.blocks_x * 384 * sizeof(float)));
+    }
+    c->row_order = nullptr;
+    if (pl.order) {
+        const size_t rb = (size_t)pl.blocks_x * sizeof(unsigned int);
+        if (rb > c->row_hits.cap || before.blocks_x != pl.blocks_x) {
+            HIP_TRY(c->row_hits.ensure(rb));
+            HIP_TRY(hipMemsetAsync(c->row_hits.p, 0, c->row_hits.cap, c->stream));   // "nothing known": index order
+        }
+        for (int k = 0; k < 2; ++k) { HIP_TRY(c->order_keys[k].ensure(rb)); HIP_TRY(c->order_vals[k].ensure(rb)); }
+        HIP_TRY(c->order_tmp.ensure(icp::row_order_temp_bytes(pl.blocks_x)));
     }
     // one error row per matching block row (fused transform) or per transform block
     size_t err_rows = (size_t)icp::MOM_MAX_BLOCKS;
@@ -681,7 +693,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->work, &c->slot_state, &c->share_counts, &c->seed_pub, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->work, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -987,6 +999,18 @@ static void prepare_rows_format(icp_ctx* c, bool compact)
     c->rows_format = want;
 }
 
+// ordered rows: sort the rows by the hits of the launch before (and zero the counters) -- enqueued right before a pass of the loop
+static int prepare_row_order(icp_ctx* c)
+{
+    if (!c->plan.order || c->row_hits.p == nullptr) { c->row_order = nullptr; return ICP_OK; }
+    icp::RowOrderBuffers b{};
+    for (int k = 0; k < 2; ++k) { b.keys[k] = (unsigned int*)c->order_keys[k].p; b.vals[k] = (int32_t*)c->order_vals[k].p; }
+    b.temp = c->order_tmp.p;
+    b.temp_bytes = c->order_tmp.cap;
+    HIP_TRY(icp::launch_row_order(b, (unsigned int*)c->row_hits.p, c->plan.blocks_x, &c->row_order, c->stream));
+    return ICP_OK;
+}
+
 static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
 {
     if (c->prec == ICP_F64)   // (fp64: no sorted views)
@@ -995,6 +1019,7 @@ static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
     if (c->count_work) o.work = (unsigned long long*)c->work.p;
+    if (c->plan.order && c->row_order != nullptr) { o.row_order = c->row_order; o.row_hits = (unsigned int*)c->row_hits.p; }
     if (c->plan.share_blocks > 0 && c->share_counts.p != nullptr) { o.share_counts = (unsigned int*)c->share_counts.p; o.share_seq = &c->share_seq; o.share_cold_seq = &c->share_cold_seq; o.seed_pub = (float*)c->seed_pub.p; }
     return o;
 }
@@ -1268,6 +1293,7 @@ int icp_loop_enqueue(icp_ctx* c)
     L.timed_nn = false;
     if (!final_only) {
         // the previous pass's matches seed the early-out bound (any valid index would do)
+        if (c->fused_tail && icp::nn_can_fuse_tail(pl)) { if (int rc = prepare_row_order(c)) return rc; } else c->row_order = nullptr;
         const icp::NNCullInputs cull = make_cull(c, L.matched ? (const int32_t*)c->idx[c->cur].p : nullptr);
         c->cur ^= 1;
         L.matched = true;
@@ -1545,6 +1571,7 @@ int loop_arm(icp_ctx* c)
 {
     LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
+    if (int rc = prepare_row_order(c)) return rc;
     const icp::NNCullInputs cull = make_cull(c, (const int32_t*)c->idx[c->cur].p);
     const int prev_cur = c->cur;
     const int slot = (int)(c->mail_seq++ % kMailSlots);

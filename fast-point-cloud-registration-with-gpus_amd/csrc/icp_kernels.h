@@ -33,6 +33,8 @@ struct NNPlan {
     int row;            // sparse geometry: moving points per block row -- 128 (nn_match_sparse, 16 waves) or 64 (nn_match_row64, 8 waves)
     int nw;             // rows of 128: waves per block -- 16, or 8 (two blocks per CU: clouds whose rows outnumber the CUs; launches with a fused tail)
     int share_blocks;   // rows of 128, 8 waves, one launch per pass: blocks of a launch (> blocks_x: the spare ones go to the heavy rows), or 0
+    int order;          // rows of 128, many more rows than the machine holds at once: the blocks of a launch take the rows heaviest first
+                        // (by the hits of the launch before) -- see launch_row_order
 };
 int nn_block_threads(const NNPlan& pl);
 
@@ -127,6 +129,9 @@ struct NNCullInputs {
     unsigned long long* share_seq = nullptr;
     unsigned long long* share_cold_seq = nullptr;
     float* seed_pub = nullptr;   // resident launches with shared rows: blocks_x x 384 floats (NNFuse::seed_pub)
+    // ordered rows (NNPlan::order): block b of the launch works on row row_order[b]; every block adds the hits of its lists to row_hits[row]
+    const int32_t* row_order = nullptr;
+    unsigned int* row_hits = nullptr;
 };
 // What the sparse kernel EXECUTED (it returns the brute-force answer without evaluating most pairs): wave-level tallies.
 // One "hit" = one 8-point model chunk processed by one wave = 64 lanes x 2 moving points against that chunk.
@@ -178,6 +183,21 @@ ICP_HOST_DEVICE inline unsigned int share_pick(unsigned int T0, unsigned int Tmi
 }
 // the same on the host: parts_out[rows]; returns the target (hits per block)
 unsigned int share_rows_plan(const unsigned int* hits, int rows, int blocks, int m_pad, int min_hits, int* parts_out);
+
+// Ordered rows.  A cloud with many more rows than the machine holds blocks runs them in rounds, in index order, and a pass
+// lasts until its last block ends: a heavy row that starts late is the tail of the pass (10 M x 10 M, one GPU, pass 12:
+// one row lists 468 000 chunks and takes 8.3 ms; it started at 5.9 ms of a 14.2 ms pass whose blocks add up to 10.0 ms per
+// CU).  So the rows are taken heaviest first: every block adds the hits of its lists to its row's counter, and before the
+// next launch the counters are sorted (stable, descending; 20 bits) into the order its blocks follow.  Any order is exact.
+struct RowOrderBuffers {
+    unsigned int* keys[2];   // >= rows each
+    int32_t* vals[2];        // >= rows each; the order ends up in vals[1]
+    void* temp;              // rocPRIM scratch, row_order_temp_bytes(rows)
+    size_t temp_bytes;
+};
+size_t row_order_temp_bytes(int rows);
+// reads AND zeroes hits[rows] (the next launch counts afresh); *order_out = the sorted rows (device pointer)
+hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int rows, const int32_t** order_out, hipStream_t st);
 
 // device-side preparation of the sparse kernel's views (icp_set_model / icp_set_moving): scratch owned by the caller
 struct PrepBuffers {

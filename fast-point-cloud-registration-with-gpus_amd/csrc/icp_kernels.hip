@@ -507,6 +507,8 @@ struct NNFuse {
     unsigned int* share_zero2; // ... a second array to zero (the one the next first pass will add to) or NULL
     int share_rows;            // rows of the launch (<= threads of a block)
     int share_min;             // a part is never made smaller than this many hits (of the previous launch)
+    const int32_t* row_order;  // ordered rows: block b works on row row_order[b] (heaviest first) -- or NULL
+    unsigned int* row_hits;    // ... and adds the hits of its lists to row_hits[row]
     float* seed_pub;           // resident launch with shared rows: [rows][3][128] -- whichever block closes a split row leaves the matches' coordinates
                                // here (they seed the next pass and are what its error is measured against) for the row's other blocks
 };
@@ -1200,7 +1202,8 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     // carry it through the pass loop)
     int* role = reinterpret_cast<int*>(lds_raw + ROLE_OFF);
 #define SP_SHARED (!HIER && TAIL != 0 && fuse.share_prev != nullptr)
-#define SP_ROW (SP_SHARED ? __builtin_amdgcn_readfirstlane(role[0]) : (int)blockIdx.x)
+#define SP_ORDERED (HIER && TAIL != 0 && fuse.row_order != nullptr)   // (compiled into the hierarchical search only: the flat kernels have no register to spare)
+#define SP_ROW ((SP_SHARED || SP_ORDERED) ? __builtin_amdgcn_readfirstlane(role[0]) : (int)blockIdx.x)
 #define SP_PART (SP_SHARED ? __builtin_amdgcn_readfirstlane(role[1]) : (int)blockIdx.y)
 #define SP_PARTS (SP_SHARED ? __builtin_amdgcn_readfirstlane(role[2]) : (int)gridDim.y)
     if constexpr (!HIER && TAIL != 0) {
@@ -1274,6 +1277,14 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
             if (t == 0) role[5] = 0;   // (wave 0's note to itself, resident launches: "the row's last pass was closed elsewhere")
         }
     }
+    if constexpr (HIER && TAIL != 0) {
+        // ordered rows (many more rows than the machine holds blocks): the blocks take the rows heaviest first (launch_row_order)
+        if (fuse.row_order != nullptr) {
+            if (threadIdx.x == 0) role[0] = fuse.row_order[blockIdx.x];
+            __syncthreads();
+        }
+    }
+    unsigned int hsum = 0;   // (thread 0, ordered rows: the hits of this block's lists)
     const int ibase = SP_ROW * 128 + lane;   // the block's slots; the moving point in slot s is p_perm[s] (spatially sorted groups)
     int pi[2];
 #pragma unroll
@@ -1822,6 +1833,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
                     __syncthreads();
                     dg_lap(1);
                     dg_h += *hcount;
+                    if (SP_ORDERED && threadIdx.x == 0) hsum += (unsigned int)*hcount;
                     process_hits(*hcount);
                     if (send < SH || more_above) { exchange(); list_dirty = true; }
                     dg_lap(2);
@@ -1924,6 +1936,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
         wk_find = wk_upper = wk_samp = 0; wk_hit[0] = wk_hit[1] = wk_hit[2] = 0;
     }
 
+    if (SP_ORDERED && threadIdx.x == 0 && hsum != 0u) __hip_atomic_fetch_add(&fuse.row_hits[SP_ROW], hsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // in-block merge: every wave that lowered its bound folds its candidate into the point's key
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -2097,6 +2110,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     }  // pass loop
 }
 #undef SP_SHARED
+#undef SP_ORDERED
 #undef SP_ROW
 #undef SP_PART
 #undef SP_PARTS
@@ -3260,6 +3274,36 @@ __global__ void prep_slot_map_kernel(const int32_t* __restrict__ perm, int n, in
     if (k < n_pad) out[k] = k < n ? perm[k] : k;
 }
 
+__global__ void row_order_keys_kernel(unsigned int* __restrict__ hits, int rows, unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const unsigned int h = hits[r];
+    hits[r] = 0u;                                          // (the next launch counts afresh)
+    keys[r] = 0xfffffu - (h > 0xfffffu ? 0xfffffu : h);   // ascending sort of this = descending hits; ties keep the row order (stable)
+    vals[r] = r;
+}
+
+size_t row_order_temp_bytes(int rows)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned int*)nullptr, (unsigned int*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                    (unsigned int)(rows > 0 ? rows : 1), 0, 20);
+    return bytes;
+}
+
+hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int rows, const int32_t** order_out, hipStream_t st)
+{
+    if (rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(row_order_keys_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, hits, rows, b.keys[0], b.vals[0]);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    size_t bytes = b.temp_bytes;
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.keys[0], b.keys[1], b.vals[0], b.vals[1], (unsigned int)rows, 0, 20, st);
+    *order_out = b.vals[1];
+    return e;
+}
+
 size_t prep_sort_temp_bytes(int count)
 {
     size_t bytes = 0;
@@ -4163,6 +4207,12 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense)
                 pl.nw = 8;
                 if (env_share && pl.blocks_x < 2 * num_cus && pl.blocks_x <= 8 * 64) pl.share_blocks = 2 * num_cus;
             }
+            // large models (hierarchical search), at least four rounds of blocks: the rows are taken heaviest first (launch_row_order)
+            // (ICP_NN_ORDER = 0: index order; 2: also where the rows are few -- the parity tests; not cached)
+            {
+                const int env_order = env_int("ICP_NN_ORDER", 1);
+                pl.order = (pl.hier && S == 1 && env_order && (env_order == 2 || pl.blocks_x >= 4 * num_cus)) ? 1 : 0;
+            }
             return pl;
         }
         const int bpc = env_bpc > 0 ? env_bpc : 8;
@@ -4457,6 +4507,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
                 g = dim3(pl.share_blocks, 1);
             }
             fuse.seed_pub = opt->seed_pub;
+            if (pl.order && ta && !fuse.resident && opt->row_order != nullptr && opt->row_hits != nullptr) { fuse.row_order = opt->row_order; fuse.row_hits = opt->row_hits; }
             if (fuse.resident) {
                 if (!ta || pl.splits != 1) return hipErrorInvalidValue;
                 const int variant = ((((nw == 8 ? 2 : 0) + (tl == 2 ? 1 : 0)) * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0)) * 2 + (hier ? 1 : 0);

@@ -562,6 +562,31 @@ def test_loop_forms_are_bit_identical(pkg, orc, golden, monkeypatch, metric, row
         assert np.array_equal(ref.idx, want["idx"]) or ref.iterations != want["iterations"]
 
 
+@pytest.mark.parametrize("metric", ["point_to_point", "point_to_plane"])
+def test_ordered_rows_are_the_same_computation(pkg, orc, golden, monkeypatch, metric):
+    """large models are searched through the box hierarchy, and when their rows outnumber the machine's blocks several times
+    over, every launch takes the rows heaviest first (sorted by the hits of the launch before: launch_row_order).  Forced
+    here onto the hall pair (128 rows): armed launches and launches pass by pass, rows ordered or in index order -- the same
+    bits, and the oracle's run"""
+    monkeypatch.setenv("ICP_NN_ROW", "128")
+    monkeypatch.setenv("ICP_NN_HIER", "1")
+    monkeypatch.delenv("ICP_NN_WAVES128", raising=False)
+    P, Q = orc.hall_clouds(golden)
+    fn = (lambda c: c.point_to_point(P, Q, max_iter=100, tol=1e-6)) if metric == "point_to_point" else (lambda c: c.point_to_plane(P, Q, max_iter=50, tol=1e-6))
+    res = {}
+    for name, env in (("index_order", {"ICP_NN_ORDER": "0", "ICP_RESIDENT": "0"}), ("ordered_armed", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0"}),
+                      ("ordered_stepwise", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_ARMED": "0"})):
+        monkeypatch.delenv("ICP_NN_ORDER", raising=False)
+        res[name] = _run_form(pkg, monkeypatch, env, fn)
+    monkeypatch.delenv("ICP_NN_ORDER", raising=False)
+    ref = res["index_order"]
+    for name, r in res.items():
+        assert r.iterations == ref.iterations and np.array_equal(r.T, ref.T) and np.array_equal(r.err, ref.err) and np.array_equal(r.idx, ref.idx), name
+    if metric == "point_to_point":
+        want = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
+        assert_same_run(ref.iterations, ref.err, ref.T, want, 1e-6, fp32=True)
+
+
 def test_resident_kernel_resumes_and_fixed_iterations(pkg, orc, golden, monkeypatch):
     """a resident registration cut by max_steps leaves memory as the step-wise kernels do: the next icp_loop_run (a new
     resident kernel, seeded from the index buffer) continues it; fixed_iterations ends with the transform-only pass"""
