@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
-for width, full in ((192, False), (224, True), (256, True), (300, True), (362, True), (512, True)):
+for width, full in [(int(w), True) for w in os.environ["GRID_WIDTHS"].split(",")] if os.environ.get("GRID_WIDTHS") else ((192, False), (224, True), (256, True), (300, True), (362, True), (512, True)):
     D = pkg.datasets.synthetic_grid(width, np.float32)
     M = pkg.datasets.make_model_gpu(D if full else D[:4096], *pkg.datasets.P2P_GPU)
     with pkg.Context(0) as ctx:
