@@ -981,6 +981,41 @@ def test_configs4_full_size_properties(ctx, pkg):
     assert np.array_equal(ctx.get_indices(), cold)
 
 
+def test_configs4_share_loop_ordered_rows_and_padding(pkg, monkeypatch):
+    """the same share (1.25 M points: 9766 rows, the last one partly filled) through five iterations of the loop: the launches
+    take the rows heaviest first (sorted by the hits of the launch before) or in index order -- the same bits; the error
+    falls; and the correspondences of sampled points -- the last, padded row's among them -- are numpy's brute-force
+    matches of the cloud as it stood one transform earlier"""
+    N = 10_000_000
+    W = int(np.ceil(np.sqrt(N)))
+    D = pkg.datasets.synthetic_grid(W, np.float32)[:N]
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    lo, cnt = pkg.shard_range(N, 3, 8)
+    P = np.ascontiguousarray(D[lo:lo + cnt])
+    del D
+    res = {}
+    for name, env in (("ordered", {}), ("index_order", {"ICP_NN_ORDER": "0"})):
+        monkeypatch.delenv("ICP_NN_ORDER", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.Context(0) as c:
+            res[name] = c.point_to_point(P, M, max_iter=5, tol=0.0, fixed_iterations=True)
+            if name == "ordered":
+                # one more matching pass on the moved cloud, stand-alone: what the NEXT pass of the loop would have matched
+                c.set_model(M); c.set_moving(res[name].moved)
+                c.nn_match_resident()
+                after = c.get_indices()
+    monkeypatch.delenv("ICP_NN_ORDER", raising=False)
+    a, b = res["ordered"], res["index_order"]
+    assert a.iterations == b.iterations == 5
+    assert np.array_equal(a.T, b.T) and np.array_equal(a.err[:-1], b.err[:-1]) and np.array_equal(a.idx, b.idx) and np.array_equal(a.moved, b.moved)
+    assert (np.diff(a.err[1:]) < 0).all()
+    sample = np.concatenate([np.random.default_rng(5).integers(0, cnt, 24), np.arange(cnt - 16, cnt)])   # (+ the padded last row)
+    for i in sample:
+        d = (a.moved[i][None, :] - M) ** 2
+        assert int(((d[:, 0] + d[:, 1]) + d[:, 2]).argmin()) == int(after[i])
+
+
 def test_armed_loop_in_single_steps_equals_one_run(pkg, orc, golden, monkeypatch):
     """one launch per pass (ICP_RESIDENT=0: armed launches that start from the previous pass's slot-ordered points and matches):
     driving the loop one step per call -- the pass armed ahead is withdrawn and armed again every time -- gives the bits of one
