@@ -300,6 +300,7 @@ struct icp_ctx {
     std::chrono::steady_clock::time_point rows_done_at{};   // when the host last saw a pass's rows complete (mailbox lease)
     bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
     bool arm = true;                   // ICP_ARMED=0: icp_loop_run never enqueues a pass ahead of its (R, t)
+    bool shares_device = false;        // a rank of the attached node communicator runs on the same device: nothing is armed ahead (see icp_comm_init_local)
     int resident = 1;                  // ICP_RESIDENT=0: icp_loop_run never keeps one kernel for a whole registration; 2: also where shared rows are preferred
     bool resident_refused = false;     // the resident kernel does not fit the machine with this plan: do not try again
     // ring of mailboxes for armed / resident launches, in pinned mapped host memory, and the device-memory relay.
@@ -734,7 +735,7 @@ int icp_comm_destroy(icp_ctx* c)
     if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
-    if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
+    if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; c->shares_device = false; }
     return ICP_OK;
 }
 
@@ -762,7 +763,23 @@ int icp_comm_init_local(icp_ctx* c, const void* id_bytes, int rank, int world)
     if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
     std::string err;
     const int rc = icp::lcomm_create(id_bytes, rank, world, &c->lcomm, err);
-    return rc == ICP_OK ? ICP_OK : fail(rc, err);
+    if (rc != ICP_OK) return fail(rc, err);
+    // Do two ranks of this communicator sit on ONE device (a rehearsal; the deployment is one process per GPU)?  Then no pass is
+    // armed ahead of its (R, t): the waiting blocks of one rank can keep the running pass of the other off the CUs, and with an
+    // exchange between the ranks that is a circular wait (seen with two ranks of the 10 M-point configuration on one GPU: a
+    // pass missing its last rows after the 2 s poll budget).  Every rank leaves its device's PCI address in its slot of one
+    // sum; plain launches wait on nothing that is not running.
+    c->shares_device = false;
+    if (world > 1 && world <= ICP_NMOM) {
+        hipDeviceProp_t prop{};
+        double ids[ICP_NMOM] = {0};
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess)
+            ids[rank] = 1.0 + (double)(((long long)prop.pciDomainID << 16) | ((long long)prop.pciBusID << 8) | (long long)prop.pciDeviceID);
+        if (int rc2 = icp::lcomm_allreduce_sum_f64(c->lcomm, ids, world, err)) return fail(rc2, err);
+        for (int r = 0; r < world; ++r)
+            if (r != rank && ids[r] != 0.0 && ids[r] == ids[rank]) c->shares_device = true;
+    }
+    return ICP_OK;
 }
 
 struct icp_lcomm { icp::LocalComm* p; };
@@ -1559,7 +1576,7 @@ bool can_arm(icp_ctx* c)
 {
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    return c->arm && !share_wants_resident(c) && c->prec == ICP_F32 && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
+    return c->arm && !c->shares_device && !share_wants_resident(c) && c->prec == ICP_F32 && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
            icp::nn_can_fuse_transform(pl) && c->have_scan_copy && c->use_boxes && L.active && L.pending && !L.armed &&
            L.matched && !L.H.done && !L.H.have_rt &&
            !L.timed_nn &&  // a timed pass is completed with a stream synchronisation: nothing may wait behind it
