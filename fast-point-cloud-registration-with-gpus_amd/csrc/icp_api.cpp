@@ -773,8 +773,9 @@ int icp_comm_init_local(icp_ctx* c, const void* id_bytes, int rank, int world)
     if (world > 1 && world <= ICP_NMOM) {
         hipDeviceProp_t prop{};
         double ids[ICP_NMOM] = {0};
-        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess)
-            ids[rank] = 1.0 + (double)(((long long)prop.pciDomainID << 16) | ((long long)prop.pciBusID << 8) | (long long)prop.pciDeviceID);
+        // (an address of all zeros is "unknown": such ranks are not taken to share anything)
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && (prop.pciDomainID | prop.pciBusID | prop.pciDeviceID) != 0)
+            ids[rank] = (double)(((long long)prop.pciDomainID << 16) | ((long long)prop.pciBusID << 8) | (long long)prop.pciDeviceID);
         if (int rc2 = icp::lcomm_allreduce_sum_f64(c->lcomm, ids, world, err)) return fail(rc2, err);
         for (int r = 0; r < world; ++r)
             if (r != rank && ids[r] != 0.0 && ids[r] == ids[rank]) c->shares_device = true;
