@@ -836,9 +836,12 @@ __global__ __launch_bounds__(NN_BLOCK, (T == 2 ? 8 : 4)) void nn_match_f32_v2(co
 // pruning tests therefore let ties through (<=).  Between rounds of the find step the waves exchange their
 // minima through LDS and restart from the best one bumped by an ulp (the seeded-bound argument again), which is
 // what makes an unseeded (cold) pass converge quickly too.  Results are bit-identical to the plain scan.
+// Round 2 added, on the same skeleton: 8-wave blocks (two to a CU) whose launches deal their spare blocks to the heavy rows
+// (shared rows, clouds of 33-57 k points); for the hierarchical search the rows taken heaviest first (ordered rows) and 16
+// hits per trip to memory; group boxes over a row's real points only; a 16-bit hit list for the flat search.
 // ------------------------------------------------------------------------------------------------
-constexpr int SP_NW = 16;                       // waves per block
-constexpr int SP_HCAP = 4096;                   // hit-list entries = chunks per round (SP_NW * 64 * passes <= this)
+constexpr int SP_NW = 16;                       // waves per block (the default; NWS = 8 is the other instantiation)
+constexpr int SP_HCAP = 4096;                   // hit-list entries of the hierarchical search = chunks per round (SP_NW * 64 * passes <= this)
 constexpr int SP_MAX_PASSES = SP_HCAP / (SP_NW * 64);
 // flat search (models below 2^19 points = 65 536 chunks): the list holds 16-bit chunk numbers, twice as many in the same
 // 16 KB -- a model of up to 65 536 points is one round of the find (Bunny.csv: 5040 chunks, two rounds with 4096 entries)
