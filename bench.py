@@ -1,34 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- the hot path's headline measurement on MI355X.
+"""bench.py -- the hot path's measurements on MI355X, one JSON line per run.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config hall|s5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config hall|hall_plane|bunny|s5|cpu_f64]
 
 N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* from the environment), or plainly as `python bench.py --gpus N`, in which case this process starts
-the N ranks itself as fresh child processes (before anything here has touched a GPU) and relays rank 0's line.
+the N ranks itself and relays rank 0's line.
 
-Workload `hall` (default; BASELINE.json `metric`, configs[2]): point-to-point ICP on the hall LiDAR scan, 16 384 moving x
-16 384 model points, fp32, clouds resident in HBM.  A *step* is one full ICP iteration of the loop in libicp_mi355x.so
-(icp_loop_run): ONE resident kernel per registration; per iteration the host sends a mailbox message (command, R, t),
-the kernel does [transform + error of the previous pass] -> matching (exact, sparse) -> moment rows into pinned host
-memory, the host adds the rows in fixed order as they arrive and solves the 3x3 SVD.  The K timed steps are the
-iterations of back-to-back REAL registrations of the pair (tol 1e-6, MAX_ITER 100 as in
-src/CUDA/GPU_point_to_point_real.cu): each one restarts from the pristine moving cloud, pays its kernel launch and its
-cold first matching pass and stops by the reference's rule -- not K iterations of an already converged pose.
-N > 1 is weak scaling: every rank holds a hall-sized shard of the moving cloud (the global moving cloud is N x 16 384
-points) and the full model; the only data that crosses ranks is the 32-double moment vector, summed once per iteration.
-`value` uses the node-local route (icp_comm_init_local: the vector is already in host memory, the ranks exchange it
-through shared memory in ~1-2 us and keep their resident kernels); the same K steps are then repeated with ONE RCCL
-all-reduce per iteration issued by the library on the loop's stream (icp_comm_init) and reported beside it as `rccl`.
+Processes.  The process the launcher starts is a SUPERVISOR: it makes no GPU call, ever.  It runs the measurement (`--leg
+main`) in a fresh child process and -- for N > 1 -- the RCCL leg (`--leg rccl`) in a second one, each under a time limit.
+A child that does not answer in time is killed (its exact PID), the line is still printed, and the supervisor exits
+non-zero: a stuck communicator can neither hold the line back nor end as rc 0.  To profile, put the measuring process
+itself behind the profiler: `rocprofv3 --kernel-trace --stats -- python3 bench.py --leg main [--config ...]`.
 
-Workload `s5` (BASELINE configs[4]): synthetic z = x^2 - y^2 grid truncated to --points (default 10 M) points, model = the
-moved copy; the MOVING cloud is sharded over the ranks (strong scaling), the model replicated.  A step is one iteration
-of the whole cloud; the timed region is one registration of K fixed iterations from the initial pose.
+Workloads (`--config`; every BASELINE.json config has one; each line carries `roofline` and `cpu_baseline`):
+  hall        configs[2], the one BASELINE.json's metric is quoted on (default): point-to-point ICP on the hall LiDAR scan,
+              16 384 x 16 384 points, fp32.  A step = one ICP iteration of back-to-back REAL registrations of the pair
+              (tol 1e-6, MAX_ITER 100, src/CUDA/GPU_point_to_point_real.cu:18,404-405): each restarts from the pristine
+              cloud, pays its launch and its cold first matching pass and stops by the reference's rule.
+              N > 1: weak scaling, a hall-sized shard of the moving cloud per rank, the full model on every rank.
+  hall_plane  configs[3]: the same pair, point-to-plane (kNN(4) + PCA normals of the model on the device, 6x6 solve on the
+              host; MAX_ITER 50, tol 1e-6 as src/ICP_point_to_plane.cu).  Same regime.
+  bunny       configs[1]: Bunny.csv 35 947 points against its moved copy, point-to-point, fp32, same regime; one replica
+              per rank.
+  s5          configs[4]: synthetic z = x^2 - y^2 grid truncated to --points (10 M) points against its moved copy; the
+              MOVING cloud is sharded over the ranks (strong scaling), the model replicated.  A step = one iteration of
+              the whole cloud; the timed region is ONE registration of K fixed iterations from the initial pose.
+  cpu_f64     configs[0]: src/ICP_CPU.c's own run -- synthetic grid WIDTH x WIDTH (--width, 32 -> 1024 points), fp64,
+              tol 1e-5, MAX_ITER 200 -- through the fp64 path (ICP_F64); same regime as hall.
+The only data that crosses ranks is the loop's 32-double moment vector, summed once per iteration.  `value` is measured
+with the node-local route (icp_comm_init_local: the vector is already in host memory; shared memory, ~1-2 us); the same
+steps are then repeated in the RCCL leg with ONE library-issued ncclAllReduce per iteration (icp_comm_init) and reported
+beside it as `rccl` -- for hall and for s5, the config north_star shards.
 
-One JSON line on stdout (rank 0).  Extra objects: `roofline` (the loop's kernel timed with HIP events on its own stream
-inside the timed region, the EXECUTED arithmetic counted by the kernel's instrumented instantiation, the stand-alone
-matching kernel by the reference's min-of-10 method and the dense kernel that executes every pair), `cpu_baseline` (the
-CPU oracle on this box's host cores, bounded sample).
+`roofline`: the dominant kernel of the config, its average launch duration by HIP events on the loop's own stream, the
+arithmetic it EXECUTED (kernel-side tallies of its instrumented instantiation, icp_get_work_counters) over that time,
+against the vector peak of the precision (fp32 157.3, fp64 78.6 TFLOP/s).  `cpu_baseline`: the CPU oracle on this box's
+host cores, a bounded sample per BASELINE.md section 3.
 """
 import argparse
 import json
@@ -36,7 +44,7 @@ import os
 import socket
 import subprocess
 import sys
-import threading
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -44,23 +52,24 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X fp32 vector (packed FMA) == fp32 MFMA peak (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector (half the fp32 rate)
 HBM_PEAK_GBPS = 8000.0     # HBM3E peak (MI355X_MICROARCH.md)
-TOL, MAX_ITER = 1e-6, 100  # src/CUDA/GPU_point_to_point_real.cu:18,404-405
+CONFIGS = ("hall", "hall_plane", "bunny", "s5", "cpu_f64")
 
-# fp32 operations behind each tally of the sparse kernel's instrumented instantiation (include/icp_mi355x.h,
+# operations behind each tally of a sparse kernel's instrumented instantiation (include/icp_mi355x.h,
 # icp_get_work_counters; sub/mul/add counted, compare/select/min not -- the convention of SURVEY 8d's 8 flop per pair):
 #   box test of one point or one group box against one chunk box: 6 sub + 3 mul + 2 add + 1 mul (safety factor) = 12
 #   xy half of one pair: 2 sub + 2 mul + 1 add = 5;  z half: 1 sub + 1 mul + 1 add = 3;  a full pair: 8
-#   transform of one point: 9 mul + 9 add = 18 (every one of a block's 16 waves re-derives the block's 128 points)
+#   transform of one point: 9 mul + 9 add = 18 (every one of a block's waves re-derives the block's points)
 FLOP_BOX, FLOP_XY, FLOP_Z, FLOP_PAIR, FLOP_RT = 12, 5, 3, 8, 18
 PTS_PER_HIT = 128          # one hit = one wave (64 lanes x 2 moving points) against one 8-point model chunk
 WAVES_PER_BLOCK = 16
 
 
 def executed_flop(work, pts_per_hit=PTS_PER_HIT, waves_per_block=WAVES_PER_BLOCK):
-    """fp32 flop the sparse kernel EXECUTED, from its work counters (the fp64 moment sums of the row tail -- ~45 flop per
-    point and pass -- are left out: another unit, <2 % of the total).  pts_per_hit: the moving points one wave holds
-    (128 with rows of 128 points, 64 with rows of 64); waves_per_block: every wave re-derives the block's points"""
+    """flop a sparse kernel EXECUTED, from its work counters (the fp64 moment sums of the row tail -- ~45 flop per point
+    and pass -- are left out: <2 % of the total).  pts_per_hit: the moving points one wave holds (128 with rows of 128
+    points, 64 with rows of 64); waves_per_block: every wave re-derives the block's points"""
     parts = {
         "find (group box vs chunk boxes)": (work["find_boxes"] + work["upper_boxes"]) * FLOP_BOX,
         "per-point box tests": work["hits_box"] * pts_per_hit * FLOP_BOX,
@@ -73,24 +82,7 @@ def executed_flop(work, pts_per_hit=PTS_PER_HIT, waves_per_block=WAVES_PER_BLOCK
     return float(sum(parts.values())), {k: float(v) for k, v in parts.items()}
 
 
-def cpu_baseline(P, Q, budget_s=12.0):
-    """the CPU oracle (scalar C restatement of src/ICP_CPU.c's loop in fp32) on this host, bounded sample"""
-    import oracle_lib
-    orc = oracle_lib.Oracle()
-    t0 = time.perf_counter()
-    orc.icp_p2p(P, Q, 1, 0.0, fixed=True)
-    one = time.perf_counter() - t0
-    iters = max(2, min(40, int(budget_s / max(one, 1e-3))))
-    t0 = time.perf_counter()
-    r = orc.icp_p2p(P, Q, iters, 0.0, fixed=True)
-    dt = time.perf_counter() - t0
-    assert r["passes"] == iters
-    out = {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
-           "sample": f"{iters} fixed point-to-point iterations of the same hall workload (16384x16384, fp32), "
-                     f"oracle/icp_oracle.c single thread, {dt:.1f} s",
-           "host_cpus": os.cpu_count()}
-    # beside it: the same port with its matching loop spread over the cores this process may use (OpenMP over the
-    # moving points; the minimisation stays scalar) -- the strongest thing the host can do with the reference's algorithm
+def usable_cores():
     cores = len(os.sched_getaffinity(0))
     try:   # a container's CPU quota counts, not the CPUs it can see (threads beyond it only queue up)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -98,45 +90,384 @@ def cpu_baseline(P, Q, budget_s=12.0):
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    if cores > 1:
-        orc.set_threads(cores)
-        try:
-            orc.icp_p2p(P, Q, 2, 0.0, fixed=True)          # (thread pool start-up)
-            it2 = 200
+    return cores
+
+
+# ======================================================================================================================
+# workloads
+# ======================================================================================================================
+class Workload:
+    """one BASELINE config: the clouds, how a registration is started, what its numbers mean"""
+    name = ""
+    metric_id = ""
+    dtype = "f32"
+    peak = FP32_PEAK_TFLOPS
+    scaling = "weak"
+    regime = "registrations"     # back-to-back real registrations, cut at K steps | "fixed": one registration of K iterations
+    max_iter, tol = 100, 1e-6
+    block_regs = 20              # registrations of the kernel-timing block that follows the timed region
+    elem = 4
+
+    def __init__(self, pkg, args, rank, local_rank, world):
+        self.pkg, self.args, self.rank, self.local_rank, self.world = pkg, args, rank, local_rank, world
+        self.metric = pkg.ICP_POINT_TO_POINT
+        self.ctx = pkg.Context(local_rank)     # raises when the HIP library / a gfx950 device is missing
+        self.setup_s = 0.0
+        self.build()
+
+    # -- the loop ---------------------------------------------------------------------------------------------------
+    def begin(self, iters=None):
+        self.ctx.reset_moving()
+        self.ctx.loop_begin(self.metric, max_iter=iters if iters else self.max_iter, tol=self.tol, fixed_iterations=self.regime == "fixed")
+
+    def registration(self, iters=None):
+        """one whole registration from the initial pose; returns its iterations"""
+        self.begin(iters)
+        k, done = 0, False
+        while not done:
+            kk, done = self.ctx.loop_run(1 << 20)
+            k += kk
+        return k
+
+    def run_steps(self, count, stats=None):
+        """`count` ICP iterations.  registrations: back-to-back REAL registrations, every one from the pristine moving cloud
+        (reset inside the timed region), a cold matching pass first, iterating until the reference's stop rule fires; the last
+        one is cut when `count` is reached.  fixed: ONE registration of `count` iterations from the initial pose."""
+        if self.regime == "fixed":
+            k = self.registration(count)
+            if stats is not None:
+                stats["registrations"] += 1
+                stats["iterations"] += k
+            return
+        left = count
+        while left > 0:
+            self.begin()
+            k, _ = self.ctx.loop_run(left)
+            left -= k
+            if stats is not None:
+                stats["registrations"] += 1
+                stats["iterations"] += k
+
+    def sanity(self):
+        """one complete registration, untimed (loads the code objects, sizes the work buffers); the bench refuses to print a
+        rate for a loop that does not converge"""
+        if self.regime == "fixed":
+            return self.args.steps
+        self.registration()
+        st = self.ctx.loop_state()
+        passes = int(st["passes"])
+        self.check_converged(passes, float(st["err"][-1]))
+        return passes
+
+    def check_converged(self, passes, err):
+        if not (2 <= passes <= self.max_iter and err < 1e-3):
+            raise SystemExit(f"[bench] the {self.name} registration did not converge: {passes} passes, rms error {err}")
+
+    # -- numbers ----------------------------------------------------------------------------------------------------
+    def alg_flop_pass(self):
+        return float(FLOP_PAIR) * self.n * self.m            # the brute-force scan's arithmetic (SURVEY 8d)
+
+    def alg_bytes_pass(self):
+        return (3.0 * self.elem) * (self.n + self.m) + 4.0 * self.n   # read P, read Q, write idx
+
+    def geometry(self, info):
+        """(moving points a wave holds = points of a row, waves per block) of the loop's matching kernel"""
+        return info["n_pad"] // max(1, info["blocks"] // max(1, info["splits"])), info["threads"] // 64
+
+
+def _hall_pair(pkg, ctx):
+    import numpy as np
+    g = os.path.join(ROOT, "tests", "golden")
+    ranges = np.fromfile(os.path.join(g, "hall_ranges_u32.bin"), dtype=np.uint32)
+    enc = json.load(open(os.path.join(g, "hall_meta.json")))["encoder_count0"]
+    alt, az = pkg.datasets.read_os1_intrinsics(os.path.join(g, "beam_intrinsics.csv"))
+    return pkg.datasets.hall_clouds(ctx, ranges, enc, alt, az)   # polar -> Cartesian by the device kernel
+
+
+class Hall(Workload):
+    name = "hall"
+    metric_id = "ICP iterations/sec + NN HBM GB/s (% roofline), hall cloud"
+    data = ("hall LiDAR scan fixture (tests/golden/hall_ranges_u32.bin, decoded from the reference's Donut_1024x16.csv; "
+            "polar->Cartesian by the device kernel)")
+    workload = "hall LiDAR scan point-to-point ICP (BASELINE configs[2])"
+    kernel = "nn_match_row64<1> (rows of 64 points, 8 waves per block, point-to-point row tail)"
+
+    def build(self):
+        self.P, self.Q = _hall_pair(self.pkg, self.ctx)
+        self.n, self.m = self.P.shape[0], self.Q.shape[0]
+        self.n_global = self.n * self.world
+        self.ctx.set_model(self.Q)
+        self.ctx.set_moving(self.P)
+
+    def cpu_baseline(self, budget_s=12.0):
+        """the CPU oracle (scalar C restatement of src/ICP_CPU.c's loop in fp32) on this host, bounded sample"""
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        P, Q = self.P, self.Q
+        t0 = time.perf_counter()
+        orc.icp_p2p(P, Q, 1, 0.0, fixed=True)
+        one = time.perf_counter() - t0
+        iters = max(2, min(40, int(budget_s / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        r = orc.icp_p2p(P, Q, iters, 0.0, fixed=True)
+        dt = time.perf_counter() - t0
+        assert r["passes"] == iters
+        out = {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+               "sample": f"{iters} fixed point-to-point iterations of the same hall workload (16384x16384, fp32), "
+                         f"oracle/icp_oracle.c single thread, {dt:.1f} s",
+               "host_cpus": os.cpu_count()}
+        # beside it: the same port with its matching loop spread over the cores this process may use (OpenMP over the
+        # moving points; the minimisation stays scalar) -- the strongest thing the host can do with the reference's algorithm
+        cores = usable_cores()
+        if cores > 1:
+            orc.set_threads(cores)
+            try:
+                orc.icp_p2p(P, Q, 2, 0.0, fixed=True)          # (thread pool start-up)
+                it2 = 200
+                t0 = time.perf_counter()
+                orc.icp_p2p(P, Q, it2, 0.0, fixed=True)
+                dt2 = time.perf_counter() - t0
+                out["all_cores"] = {"value": it2 / dt2, "unit": "iterations/s", "cores": cores,
+                                    "sample": f"{it2} fixed iterations, matching loop over {cores} OpenMP threads, {dt2:.1f} s"}
+            finally:
+                orc.set_threads(1)
+        return out
+
+
+class HallPlane(Hall):
+    name = "hall_plane"
+    metric_id = "ICP iterations/sec, hall cloud, point-to-plane (BASELINE configs[3])"
+    workload = "hall LiDAR scan point-to-plane ICP, 6x6 solve on the host (BASELINE configs[3])"
+    kernel = "nn_match_row64<2> (rows of 64 points, 8 waves per block, point-to-plane row tail: 21 + 6 sums)"
+    max_iter, tol = 50, 1e-6      # src/ICP_point_to_plane.cu
+
+    def build(self):
+        super().build()
+        self.metric = self.pkg.ICP_POINT_TO_PLANE
+        t0 = time.perf_counter()
+        self.normals = self.ctx.estimate_normals()     # kNN(4) + PCA on the device; the context keeps them
+        self.normals_s = time.perf_counter() - t0
+
+    def cpu_baseline(self, budget_s=12.0):
+        """src/CUDA/CPU_ICP_point_to-plane.cpp restated (oracle/icp_oracle.c), fixed iterations on the normals of the device"""
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        P, Q, Nr = self.P, self.Q, self.normals
+        t0 = time.perf_counter()
+        orc.icp_p2plane(P, Q, Nr, 1, 0.0, fixed=True)
+        one = time.perf_counter() - t0
+        iters = max(2, min(40, int(budget_s / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        orc.icp_p2plane(P, Q, Nr, iters, 0.0, fixed=True)
+        dt = time.perf_counter() - t0
+        out = {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+               "sample": f"{iters} fixed point-to-plane iterations of the same hall workload (16384x16384, fp32), oracle/icp_oracle.c "
+                         f"single thread, {dt:.1f} s; the normals are not in the rate",
+               "host_cpus": os.cpu_count()}
+        t0 = time.perf_counter()
+        nbr = orc.knn4(Q)
+        orc.normals(Q, nbr)
+        out["normals_once_s"] = time.perf_counter() - t0     # (the one-off front end: brute-force kNN(4) + eigenvectors on one core)
+        out["normals_once_device_s"] = self.normals_s
+        cores = usable_cores()
+        if cores > 1:
+            orc.set_threads(cores)
+            try:
+                orc.icp_p2plane(P, Q, Nr, 2, 0.0, fixed=True)
+                it2 = 100
+                t0 = time.perf_counter()
+                orc.icp_p2plane(P, Q, Nr, it2, 0.0, fixed=True)
+                dt2 = time.perf_counter() - t0
+                out["all_cores"] = {"value": it2 / dt2, "unit": "iterations/s", "cores": cores,
+                                    "sample": f"{it2} fixed iterations, matching loop over {cores} OpenMP threads, {dt2:.1f} s"}
+            finally:
+                orc.set_threads(1)
+        return out
+
+
+class Bunny(Workload):
+    name = "bunny"
+    metric_id = "ICP iterations/sec, Bunny.csv 35 947-point cloud (BASELINE configs[1])"
+    data = "tests/golden/bunny_xyz_f32.bin (the reference's Bunny.csv as float32) and its moved copy"
+    workload = "Bunny.csv point-to-point ICP (BASELINE configs[1]), one replica per rank"
+    kernel = ("nn_match_sparse<1, ..., NWS = 8> (rows of 128 points, 8-wave blocks, shared rows: a grid of 2 x CUs blocks, the spare "
+              "ones dealt to the heaviest rows; Morton-ordered views of both clouds)")
+    block_regs = 6
+
+    def build(self):
+        import numpy as np
+        B = np.fromfile(os.path.join(ROOT, "tests", "golden", "bunny_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
+        self.P = B
+        self.Q = self.pkg.datasets.make_model_gpu(B, *self.pkg.datasets.BUNNY)
+        self.n, self.m = self.P.shape[0], self.Q.shape[0]
+        self.n_global = self.n
+        self.ctx.set_model(self.Q)
+        self.ctx.set_moving(self.P)
+
+    def cpu_baseline(self, budget_s=12.0):
+        """Bunny.csv, ONE iteration x 3, the minimum"""
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        ts = []
+        for _ in range(3):
             t0 = time.perf_counter()
-            r = orc.icp_p2p(P, Q, it2, 0.0, fixed=True)
-            dt2 = time.perf_counter() - t0
-            out["all_cores"] = {"value": it2 / dt2, "unit": "iterations/s", "cores": cores,
-                                "sample": f"{it2} fixed iterations, matching loop over {cores} OpenMP threads, {dt2:.1f} s"}
-        finally:
-            orc.set_threads(1)
-    return out
+            orc.icp_p2p(self.P, self.Q, 1, 0.0, fixed=True)
+            ts.append(time.perf_counter() - t0)
+        out = {"value": 1.0 / min(ts), "unit": "iterations/s", "cores": 1, "kind": "port",
+               "sample": "ONE point-to-point iteration of the same Bunny.csv workload (35947x35947, fp32) x 3, the minimum "
+                         f"({min(ts):.2f} s; oracle/icp_oracle.c single thread, {sum(ts):.1f} s in all)",
+               "host_cpus": os.cpu_count()}
+        cores = usable_cores()
+        if cores > 1:
+            orc.set_threads(cores)
+            try:
+                orc.icp_p2p(self.P, self.Q, 1, 0.0, fixed=True)
+                it2 = 20
+                t0 = time.perf_counter()
+                orc.icp_p2p(self.P, self.Q, it2, 0.0, fixed=True)
+                dt2 = time.perf_counter() - t0
+                out["all_cores"] = {"value": it2 / dt2, "unit": "iterations/s", "cores": cores,
+                                    "sample": f"{it2} fixed iterations, matching loop over {cores} OpenMP threads, {dt2:.1f} s"}
+            finally:
+                orc.set_threads(1)
+        return out
 
 
-# ---- N > 1 without a launcher: start the ranks ourselves -------------------------------------------------------------
-def spawn_ranks(n):
-    """`python bench.py --gpus N` with no WORLD_SIZE: N fresh child processes, one rank each.  This (parent) process has
-    made no GPU call -- torch is not even imported yet -- and never will: it only relays rank 0's line."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    bad = [rc for rc in rcs if rc != 0]
-    return bad[0] if bad else 0
+class S5(Workload):
+    name = "s5"
+    metric_id = "ICP iterations/sec, synthetic 10M-point cloud (BASELINE configs[4])"
+    workload = "synthetic 10M-point cloud point-to-point ICP, moving cloud sharded over the ranks (BASELINE configs[4])"
+    kernel = ("nn_match_sparse<1, ..., HIER> (rows of 128 points, 16 waves per block, three-level box hierarchy over the Morton view "
+              "of the model, rows taken heaviest first), ONE launch per pass")
+    scaling = "strong"
+    regime = "fixed"
+
+    def build(self):
+        import numpy as np
+        N = self.args.points
+        self.Wd = int(np.ceil(np.sqrt(N)))
+        D = self.pkg.datasets.synthetic_grid(self.Wd, np.float32)[:N]
+        self.Q = self.pkg.datasets.make_model_gpu(D, *self.pkg.datasets.P2P_GPU)
+        lo, cnt = self.pkg.shard_range(N, self.rank, self.world)
+        self.P = np.ascontiguousarray(D[lo:lo + cnt])
+        self.slice_D = np.ascontiguousarray(D[: min(N, 100_000)])
+        del D
+        self.n, self.m, self.n_global = cnt, N, N
+        self.data = "synthetic z = x^2 - y^2 grid, W = %d truncated to %d points; model = moved copy" % (self.Wd, N)
+        t0 = time.perf_counter()
+        self.ctx.set_model(self.Q)
+        self.ctx.set_moving(self.P)
+        self.setup_s = time.perf_counter() - t0
+
+    def alg_flop_pass(self):
+        return float(FLOP_PAIR) * self.n_global * self.m
+
+    def alg_bytes_pass(self):
+        return 12.0 * (self.n_global + self.m) + 4.0 * self.n_global
+
+    def cpu_baseline(self, budget_s=12.0):
+        """1e14 pairs per iteration are out of a CPU's reach; a 100 k-point slice is timed and the
+        iteration time scaled by (N / slice)^2 -- a brute-force scan costs the same per pair whatever the geometry"""
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        D = self.slice_D
+        s = D.shape[0]
+        M = self.Q[:s]
+        t0 = time.perf_counter()
+        orc.icp_p2p(D, M, 1, 0.0, fixed=True)
+        one = time.perf_counter() - t0
+        scale = (float(self.n_global) / s) * (float(self.m) / s)
+        out = {"value": 1.0 / (one * scale), "unit": "iterations/s", "cores": 1, "kind": "port", "extrapolated": True,
+               "sample": f"EXTRAPOLATED: one point-to-point iteration of a {s} x {s}-point slice of the same clouds ({one:.2f} s, "
+                         f"oracle/icp_oracle.c single thread) x (N / slice)^2 = {scale:.0f} -> {one * scale:.0f} s per iteration of the "
+                         f"{self.n_global} x {self.m} workload",
+               "slice_points": s, "slice_iteration_s": one, "host_cpus": os.cpu_count()}
+        cores = usable_cores()
+        if cores > 1:
+            orc.set_threads(cores)
+            try:
+                orc.icp_p2p(D, M, 1, 0.0, fixed=True)
+                t0 = time.perf_counter()
+                orc.icp_p2p(D, M, 3, 0.0, fixed=True)
+                dt2 = (time.perf_counter() - t0) / 3
+                out["all_cores"] = {"value": 1.0 / (dt2 * scale), "unit": "iterations/s", "cores": cores, "extrapolated": True,
+                                    "sample": f"EXTRAPOLATED the same way from {dt2:.2f} s per slice iteration with the matching loop over {cores} OpenMP threads"}
+            finally:
+                orc.set_threads(1)
+        return out
 
 
+class CpuF64(Workload):
+    name = "cpu_f64"
+    metric_id = "ICP iterations/sec, synthetic z=x^2-y^2 cloud, fp64 (src/ICP_CPU.c's run; BASELINE configs[0])"
+    dtype = "f64"
+    peak = FP64_PEAK_TFLOPS
+    elem = 8
+    max_iter, tol = 200, 1e-5     # src/ICP_CPU.c:267-269
+    kernel = ("nn_match_row64_f64<1, NW> (rows of 64 points, one per lane, 16 waves per block while every row has its own CU, chunk boxes "
+              "+ exact scalar (dx*dx + dy*dy) + dz*dz in double), resident: ONE launch per registration")
+
+    def build(self):
+        import numpy as np
+        W = self.args.width
+        self.P = self.pkg.datasets.synthetic_grid(W, np.float64)
+        self.Q = self.pkg.datasets.make_model_cpu(self.P)
+        self.n, self.m = self.P.shape[0], self.Q.shape[0]
+        self.n_global = self.n
+        self.data = f"synthetic z = x^2 - y^2 grid, WIDTH {W} ({W * W} points), model by src/ICP_CPU.c:100-149; float64"
+        self.workload = f"synthetic z=x^2-y^2 cloud ({W * W} points) point-to-point ICP in fp64, the run of src/ICP_CPU.c (BASELINE configs[0])"
+        self.ctx.set_model(self.Q)
+        self.ctx.set_moving(self.P)
+
+    def geometry(self, info):
+        return 64, (16 if info["blocks"] <= 256 else 8)    # (launch_row64_f64: 16 waves while every row has a CU of its own)
+
+    def check_converged(self, passes, err):
+        # (this pair is a radian apart and ends at E = 0.83 by the |dE| rule: src/ICP_CPU.c prints the same)
+        if not (2 <= passes <= self.max_iter):
+            raise SystemExit(f"[bench] the fp64 registration did not stop by its rule: {passes} passes")
+
+    def cpu_baseline(self, budget_s=10.0):
+        """the fp64 oracle (oracle/icp_oracle.c, orc_icp_p2p_f64 = src/ICP_CPU.c:217-271) to convergence on the same pair"""
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        t0 = time.perf_counter()
+        r = orc.icp_p2p(self.P, self.Q, self.max_iter, self.tol)
+        one = time.perf_counter() - t0
+        reps = max(1, min(400, int(budget_s / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        its = 0
+        for _ in range(reps):
+            its += orc.icp_p2p(self.P, self.Q, self.max_iter, self.tol)["passes"]
+        dt = time.perf_counter() - t0
+        out = {"value": its / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+               "sample": f"{reps} whole registrations of the same pair to convergence ({r['passes']} passes each, tol 1e-5), fp64 oracle single thread, {dt:.1f} s",
+               "iterations_per_registration": r["passes"], "final_rms_error": float(r["err"][-1]), "host_cpus": os.cpu_count()}
+        cores = usable_cores()
+        if cores > 1 and self.n >= 4096:
+            orc.set_threads(cores)
+            try:
+                orc.icp_p2p(self.P, self.Q, self.max_iter, self.tol)
+                t0 = time.perf_counter()
+                its2 = sum(orc.icp_p2p(self.P, self.Q, self.max_iter, self.tol)["passes"] for _ in range(3))
+                dt2 = time.perf_counter() - t0
+                out["all_cores"] = {"value": its2 / dt2, "unit": "iterations/s", "cores": cores,
+                                    "sample": f"3 registrations, matching loop over {cores} OpenMP threads, {dt2:.1f} s"}
+            finally:
+                orc.set_threads(1)
+        return out
+
+
+WORKLOADS = {"hall": Hall, "hall_plane": HallPlane, "bunny": Bunny, "s5": S5, "cpu_f64": CpuF64}
+DEFAULT_STEPS = {"hall": (2000, 200), "hall_plane": (1000, 100), "bunny": (420, 42), "s5": (30, 5), "cpu_f64": (2000, 200)}
+
+
+# ======================================================================================================================
+# the control plane of a multi-rank run
+# ======================================================================================================================
 class Ranks:
-    """the control plane of a multi-rank run: torch.distributed over gloo (barriers, the max over ranks, the 128-byte
-    communicator ids).  The data path never goes through it."""
+    """torch.distributed over gloo (barriers, the max over ranks, the 128-byte communicator ids).  The data path never
+    goes through it."""
 
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
@@ -168,382 +499,374 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return int(t.item())
 
+    def max_int(self, v):
+        if not self.dist:
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
+
     def close(self):
         if self.dist:
             self.dist.barrier()
             self.dist.destroy_process_group()
 
 
-STUCK = []   # helper threads that never came back (a communicator attempt that hangs)
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def guarded(fn, seconds):
-    """run fn() on a helper thread; (True, result) or (False, reason) when it raised or did not return in time -- the
-    stuck thread is abandoned (the process leaves through os._exit)"""
-    box = {}
-
-    def body():
-        try:
-            box["ok"] = fn()
-        except Exception as e:  # noqa: BLE001
-            box["err"] = f"{type(e).__name__}: {e}"
-    t = threading.Thread(target=body, daemon=True)
-    t.start()
-    t.join(seconds)
-    if t.is_alive():
-        STUCK.append(t)
-        return False, f"no answer within {seconds} s"
-    if "err" in box:
-        return False, box["err"]
-    return True, box.get("ok")
-
-
-# ---- the hall workload -----------------------------------------------------------------------------------------------
-def run_hall(args, rank, local_rank, world):
-    import numpy as np
+# ======================================================================================================================
+# --leg main: the measurement
+# ======================================================================================================================
+def timed_steps(wl, ranks, K, stride):
+    """EXACTLY K steps between barrier + synchronize on both sides; the max over ranks"""
     import torch
-    from __graft_entry__ import load_package
-    pkg = load_package()
-    ranks = Ranks(rank, world)
-    K, W = args.steps, args.warmup
-
-    g = os.path.join(ROOT, "tests", "golden")
-    ranges = np.fromfile(os.path.join(g, "hall_ranges_u32.bin"), dtype=np.uint32)
-    enc = json.load(open(os.path.join(g, "hall_meta.json")))["encoder_count0"]
-    alt, az = pkg.datasets.read_os1_intrinsics(os.path.join(g, "beam_intrinsics.csv"))
-    ctx = pkg.Context(local_rank)          # raises when the HIP library / a gfx950 device is missing
-    P, Q = pkg.datasets.hall_clouds(ctx, ranges, enc, alt, az)   # polar -> Cartesian by the device kernel
-    n, m = P.shape[0], Q.shape[0]
-    ctx.set_model(Q)
-    ctx.set_moving(P)
+    ctx = wl.ctx
 
     def sync():
         ranks.barrier()
-        torch.cuda.synchronize(local_rank)
+        torch.cuda.synchronize(wl.local_rank)
 
-    def run_steps(count, stats=None):
-        """`count` ICP iterations, executed as back-to-back REAL registrations of the hall pair: every registration
-        starts from the pristine moving cloud (reset inside the timed region), begins with a cold matching pass and
-        iterates until the reference's stop rule fires; the last one is cut when `count` is reached."""
-        left = count
-        while left > 0:
-            ctx.reset_moving()
-            ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=MAX_ITER, tol=TOL, fixed_iterations=False)
-            k, _ = ctx.loop_run(left)                 # (enqueue + complete) x k inside libicp_mi355x
-            left -= k
-            if stats is not None:
-                stats["registrations"] += 1
-                stats["iterations"] += k
+    stats = {"registrations": 0, "iterations": 0}
+    ctx.set_profiling(stride)     # (also restarts the stride: the first launch after this is a timed one)
+    sync()
+    t0 = time.perf_counter()
+    wl.run_steps(K, stats)
+    sync()
+    dt = ranks.max(time.perf_counter() - t0)
+    sec, cnt = ctx.loop_timing()
+    passes = ctx.loop_timing_passes()
+    ctx.set_profiling(0)
+    return dt, stats, sec, cnt, passes
 
-    def timed(count, stride):
-        stats = {"registrations": 0, "iterations": 0}
-        ctx.set_profiling(stride)     # (also restarts the stride: the first launch after this is a timed one)
-        sync()
-        t0 = time.perf_counter()
-        run_steps(count, stats)
-        sync()
-        dt = ranks.max(time.perf_counter() - t0)
-        sec, cnt = ctx.loop_timing()
-        passes = ctx.loop_timing_passes()
-        ctx.set_profiling(0)
-        return dt, stats, sec, cnt, passes
 
-    use_local = world > 1 or os.environ.get("ICP_BENCH_FORCE_DIST") == "1"
-    if use_local and ranks.dist:
-        pkg.distributed.attach_local_comm(ctx, ranks.dist)
-
-    # set-up, untimed: one complete registration (loads the code objects, sizes the work buffers) whose result is the
-    # bench's own sanity check -- every rank registers the same pair, so it must end like the single-GPU run does
-    ctx.reset_moving()
-    ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=MAX_ITER, tol=TOL, fixed_iterations=False)
-    done = False
-    while not done:
-        _, done = ctx.loop_run(1 << 20)
-    st = ctx.loop_state()
-    passes_full = int(st["passes"])
-    if not (2 <= passes_full <= MAX_ITER and float(st["err"][-1]) < 1e-3):
-        raise SystemExit(f"[bench] the hall registration did not converge: {passes_full} passes, rms error {st['err'][-1]}")
-
-    run_steps(W)
-    # HIP events around the loop's kernel inside the timed region: with a resident kernel a launch is a whole registration,
-    # so every 7th is timed when the region holds many of them (1-2 % of overhead).  A region of a few registrations is
-    # not bracketed at all -- the two event records and the wait for the kernel's end would be a tenth of what is being
-    # measured; the roofline leg then comes from the fixed block of 20 registrations run right after it
-    regs_expected = max(1, K // max(1, passes_full))
-    stride = 7 if regs_expected >= 70 else 0
-    dt, stats, sec1, cnt1, passes1 = timed(K, stride)
-    out = None
-    if rank == 0:
-        out = {
-            "metric": "ICP iterations/sec + NN HBM GB/s (% roofline), hall cloud",
-            "value": world * K / dt, "unit": "iterations/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "hall LiDAR scan fixture (tests/golden/hall_ranges_u32.bin, decoded from the reference's "
-                    "Donut_1024x16.csv; polar->Cartesian by the device kernel)",
-            "config": {"workload": "hall LiDAR scan point-to-point ICP (BASELINE configs[2])", "moving_points_per_gpu": n,
-                       "model_points": m, "global_moving_points": n * world,
-                       "regime": "back-to-back full registrations from the initial pose (cold first pass, tol 1e-6, stop rule on); "
-                                 "a step = one iteration of such a registration",
-                       "registrations_timed": stats["registrations"],
-                       "iterations_per_registration": stats["iterations"] / max(1, stats["registrations"]),
-                       "passes_of_a_full_registration": passes_full,
-                       "collective": ("sum of the loop's moment vector (19 doubles) per iteration over the node's ranks through shared "
-                                      "host memory (icp_comm_init_local), rank order, every rank keeps its resident kernel; the RCCL "
-                                      "route is measured beside it (`rccl`)") if use_local else "none"},
-            "final_rms_error": float(st["err"][-1]),
-        }
-
-    if use_local and ranks.dist:
-        ctx.comm_destroy()     # rank 0 measures its roofline leg alone: no communicator may wait for the others
-    if rank == 0:
-        info = ctx.nn_launch_info()
-        flops_pass = float(FLOP_PAIR) * n * m                 # the brute-force scan's arithmetic (SURVEY 8d)
-        alg_bytes_pass = 12.0 * n + 12.0 * m + 4.0 * n        # read P, read Q, write idx (fp32)
-        # (1) the loop's kernel, timed inside the timed region (events on the loop's own stream)
-        region = None
-        if cnt1 > 0:
-            region = {"launches_timed": cnt1, "avg_launch_us": 1e6 * sec1 / cnt1, "passes_per_launch": passes1 / cnt1,
-                      "timing_stride": stride}
-        # ... and over a fixed block of 20 registrations after it (K-independent: the figure of a short region is noisy)
+def roofline_leg(wl, K, passes_full, region, stride):
+    """rank 0, alone: kernel durations by HIP events, executed arithmetic by the kernel's own tallies"""
+    pkg, ctx = wl.pkg, wl.ctx
+    info = ctx.nn_launch_info()
+    n, m = wl.n, wl.m
+    per_pass = wl.name in ("s5", "bunny")     # one launch per matching pass; the others: ONE resident launch per registration
+    # (1) the kernel's launches of a fixed block of registrations right after the timed region (K-independent); where the
+    #     timed region itself was bracketed by events (every launch of s5, every 7th registration of a long hall run) that
+    #     figure comes first
+    block = None
+    if wl.regime != "fixed":
         ctx.set_profiling(1)
-        for _ in range(20):
-            run_steps(passes_full)
+        for _ in range(wl.block_regs):
+            wl.registration()
         sec2, cnt2 = ctx.loop_timing()
         passes2 = ctx.loop_timing_passes()
         ctx.set_profiling(0)
-        block = {"launches_timed": cnt2, "avg_launch_us": 1e6 * sec2 / max(1, cnt2), "passes_per_launch": passes2 / max(1, cnt2)}
-        prim, prim_src = (region, "timed region") if region else (block, "block of 20 registrations after the timed region")
-        t_launch = 1e-6 * prim["avg_launch_us"]
-        ppl = max(1.0, prim["passes_per_launch"])
-        # (2) what the kernel EXECUTES: one full registration with the instrumented instantiation
-        ctx.set_work_counting(True)
-        ctx.reset_moving()
-        ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=MAX_ITER, tol=TOL, fixed_iterations=False)
-        done = False
-        while not done:
-            _, done = ctx.loop_run(1 << 20)
-        work = ctx.get_work_counters()
-        ctx.set_work_counting(False)
-        blocks = info["blocks"]
-        passes_counted = work["block_passes"] / max(1, blocks)
-        row64 = info["threads"] == 512          # rows of 64 points: 8 waves per block, one point per lane
-        pts_hit, nwaves = (64, 8) if row64 else (128, 16)
-        flop_reg, flop_parts = executed_flop(work, pts_hit, nwaves)
-        flop_launch = flop_reg * (ppl / max(1.0, passes_counted))      # scaled to the passes an average timed launch ran
-        pairs_full = work["hits_full"] * pts_hit * 8
-        # (3) the stand-alone matching kernel by the reference's method: min (and mean) of 10 launches after 2 warm-ups
+        block = {"launches_timed": cnt2, "avg_launch_us": 1e6 * sec2 / max(1, cnt2), "passes_per_launch": passes2 / max(1, cnt2),
+                 "registrations": wl.block_regs}
+    prim, prim_src = (region, "timed region") if region else (block, f"block of {wl.block_regs} registrations after the timed region")
+    t_launch = 1e-6 * prim["avg_launch_us"]
+    ppl = max(1.0, prim["passes_per_launch"])
+    # (2) what the kernel EXECUTES: the same registration once more with the instrumented instantiation (every launch timed,
+    #     so that the loop's own counters say how many launches and matching passes it was)
+    ctx.set_work_counting(True)
+    ctx.set_profiling(1)
+    wl.registration(K if wl.regime == "fixed" else None)
+    launches_reg = ctx.loop_timing()[1]
+    passes_counted = float(max(1, ctx.loop_timing_passes()))
+    ctx.set_profiling(0)
+    work = ctx.get_work_counters()
+    ctx.set_work_counting(False)
+    pts_hit, nwaves = wl.geometry(info)
+    flop_reg, flop_parts = executed_flop(work, pts_hit, nwaves)
+    flop_pass = flop_reg / max(1.0, passes_counted)
+    flop_launch = flop_pass * ppl
+    pairs_full = work["hits_full"] * pts_hit * 8
+    alg_flop, alg_bytes = wl.alg_flop_pass(), wl.alg_bytes_pass()
+    share = float(wl.n) / float(wl.n_global)      # (s5, N > 1: rank 0 holds this share of the moving cloud)
+    achieved = flop_launch / t_launch / 1e12
+    roof = {
+        "kernel": wl.kernel + (", resident: ONE launch per REGISTRATION, every block on the machine (%.2f matching passes per timed launch); "
+                               "the duration INCLUDES the host round trips between the passes" % ppl if not per_pass
+                               else "; one launch per matching pass (plain launches while they are timed)"),
+        "bound": "valu",
+        "bound_detail": ("%s vector roof %.1f TFLOP/s (FMA-counted).  The kernels issue %s only -- (dx*dx + dy*dy) + dz*dz must round "
+                         "every operation separately, the contract forbids FMA (which caps executed arithmetic at half that roof) and an MFMA "
+                         "cannot evaluate a per-pair subtraction.  Brute-force NN is %.0f flop/B on this cloud (ridge ~20): not HBM-bound."
+                         % (wl.dtype, wl.peak, "packed VALU ops (v_pk_add/mul_f32)" if wl.dtype == "f32" else "scalar fp64 VALU ops",
+                            alg_flop / alg_bytes)),
+        "achieved": achieved, "peak": wl.peak, "unit": "TFLOP/s", "frac": achieved / wl.peak,
+        "traffic": None, "traffic_source": None,
+        "what_frac_counts": "EXECUTED flop (kernel-side tallies of one whole registration, icp_get_work_counters) per matching pass x passes per "
+                            "timed launch / average launch time; the kernel returns the brute-force answer bit for bit but proves for most pairs "
+                            "that they cannot win",
+        "avg_launch_us": prim["avg_launch_us"], "launches_timed": prim["launches_timed"], "passes_per_launch": ppl,
+        "avg_pass_us": prim["avg_launch_us"] / ppl, "timed_in": prim_src, "timing_stride": stride,
+        "timed_region": region, "post_region_block": block,
+        "executed": {"flop_per_launch": flop_launch, "flop_per_pass": flop_pass,
+                     "flop_by_part_one_registration": flop_parts, "work_counters_one_registration": work,
+                     "passes_counted": passes_counted, "launches_of_that_registration": launches_reg,
+                     "moving_points_per_wave": pts_hit, "waves_per_block": nwaves,
+                     "pairs_evaluated_in_full_fraction": pairs_full / max(1.0, passes_counted * n * m)},
+        "time_to_solution": {"brute_force_flop_per_pass": alg_flop * share,
+                             "brute_force_equivalent_TFLOPs": alg_flop * share * ppl / t_launch / 1e12,
+                             "note": "the arithmetic the answer stands for (8 flop x N x M per pass) over the measured time: a speed-up "
+                                     "figure, not a roofline fraction"},
+        "launch": info,
+        "hbm": {"algorithmic_bytes_per_pass": alg_bytes * share, "achieved_GBps": alg_bytes * share * ppl / t_launch / 1e9,
+                "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes * share * ppl / t_launch / 1e9 / HBM_PEAK_GBPS},
+    }
+    # HBM traffic: PMC counters need rocprofv3 (separate --pmc passes), so the figure comes from this round's committed
+    # profile of the config's kernel; left null when that profile is missing
+    for cand in (os.path.join(ROOT, "profiles", "r3", f"pmc_hbm_traffic_{wl.name}.json"),):
+        if wl.world == 1 and os.path.exists(cand):
+            rec = json.load(open(cand))
+            k = next((v for kk, v in rec.items() if "nn_match_" in kk and isinstance(v, dict)), None)
+            if k:
+                roof["traffic"] = k["hbm_bytes_corrected"]
+                roof["traffic_source"] = ("%s (build %s): %s, FETCH_SIZE %.0f B raw (x2: gfx950 correction) + WRITE_SIZE %.0f B per launch"
+                                          % (os.path.relpath(cand, ROOT), rec.get("_build", "unknown"), rec.get("_what", "one launch"),
+                                             k["fetch_bytes_raw"], k["write_bytes"]))
+    if wl.dtype == "f32" and wl.name in ("hall", "hall_plane", "bunny"):
+        # the stand-alone matching kernel by the reference's method: min (and mean) of 10 launches after 2 warm-ups
         seeded = ctx.nn_match_bench_launches(10, 2, 0)
+        roof["matching_only"] = {"what": "stand-alone seeded launches of the same search without its fused front end and tail (no transform, no moment "
+                                         "rows), events around every launch, 2 warm-ups: the reference's method (src/CUDA/Matching_opt.cu:213-226)",
+                                 "min_launch_us": 1e3 * float(seeded.min()), "avg_launch_us": 1e3 * float(seeded.mean()), "launches": 10}
         dense = ctx.nn_match_bench_launches(10, 2, 2)
         dinfo = ctx.nn_launch_info_ex(dense=True)
         dense_flop = float(FLOP_PAIR) * dinfo["n_pad"] * dinfo["m_pad"]
         t_dense = 1e-3 * float(dense.mean())
-        # HBM traffic: PMC counters need rocprofv3 (separate --pmc passes), so the figure comes from this round's committed
-        # profile of the stand-alone kernel; left null when that profile is missing
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r2", "pmc_hbm_traffic_sparse.json")
-        if world == 1 and os.path.exists(pmc):
-            rec = json.load(open(pmc))
-            k = next((v for kk, v in rec.items() if "nn_match_" in kk), None)
-            if k:
-                traffic = k["hbm_bytes_corrected"]
-                traffic_src = ("profiles/r2/pmc_hbm_traffic_sparse.json (%s): ONE stand-alone seeded pass, FETCH_SIZE %.0f B raw (x2: gfx950 "
-                               "correction) + WRITE_SIZE %.0f B; a resident launch keeps its chunk boxes in registers, so its later passes "
-                               "read less" % (rec.get("_build", "build unknown"), k["fetch_bytes_raw"], k["write_bytes"]))
-        out["roofline"] = {
-            "kernel": ("nn_match_row64<1> (rows of 64 points, 8 waves per block)" if row64 else "nn_match_sparse<1> (rows of 128 points, 16 waves per block)") +
-                      ", resident: ONE launch per REGISTRATION, every block on the machine (%.2f matching passes per "
-                      "timed launch); every pass = mailbox message from the host (command, R, t) -> [transform + error of the previous "
-                      "pass] -> lane-parallel chunk-box search -> hit processing (packed fp32, exact arithmetic) -> LDS key merge -> "
-                      "moment row to the host.  The duration INCLUDES the host round trips between the passes." % ppl,
-            "bound": "valu",
-            "bound_detail": "fp32 vector roof 157.3 TFLOP/s (FMA-counted; the same figure as fp32 MFMA on gfx950).  The kernel issues packed "
-                            "VALU ops only (v_pk_add/mul_f32, no MFMA: (dx*dx + dy*dy) + dz*dz must round every operation separately, and "
-                            "the contract forbids FMA, which caps executed arithmetic at half that roof).  Brute-force NN is 4681 "
-                            "flop/B on this cloud (ridge ~20): not HBM-bound.",
-            "achieved": flop_launch / t_launch / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop_launch / t_launch / 1e12 / FP32_PEAK_TFLOPS,
-            "traffic": traffic, "traffic_source": traffic_src,
-            "what_frac_counts": "EXECUTED fp32 flop (kernel-side tallies of one full registration, icp_get_work_counters) / launch time; the "
-                                "kernel returns the brute-force answer bit for bit but proves for ~98 % of the pairs that they cannot win, "
-                                "so it is bound by a chain of dependent latencies, not by arithmetic",
-            "avg_launch_us": prim["avg_launch_us"], "launches_timed": prim["launches_timed"], "passes_per_launch": ppl,
-            "avg_pass_us": prim["avg_launch_us"] / ppl, "timed_in": prim_src,
-            "timed_region": region, "post_region_block": block,
-            "executed": {"flop_per_launch": flop_launch, "flop_per_pass": flop_reg / max(1.0, passes_counted),
-                         "flop_by_part_one_registration": flop_parts, "work_counters_one_registration": work,
-                         "passes_counted": passes_counted,
-                         "pairs_evaluated_in_full_fraction": pairs_full / max(1.0, passes_counted * n * m)},
-            "time_to_solution": {"brute_force_flop_per_pass": flops_pass,
-                                 "brute_force_equivalent_TFLOPs": flops_pass * ppl / t_launch / 1e12,
-                                 "note": "the arithmetic the answer stands for (8 flop x N x M per pass) over the measured time: a speed-up "
-                                         "figure, not a roofline fraction",
-                                 "speedup_vs_dense_kernel_per_pass": t_dense / (t_launch / ppl)},
-            "matching_only": {"what": "stand-alone seeded launches of the same kernel without its fused front end and tail (no transform, no moment rows), events around "
-                                      "every launch, 2 warm-ups: the reference's method (src/CUDA/Matching_opt.cu:213-226)",
-                              "min_launch_us": 1e3 * float(seeded.min()), "avg_launch_us": 1e3 * float(seeded.mean()), "launches": 10},
-            "dense_kernel": {"what": "nn_match_f32_v2<2,8,0,0>: the LDS-tiled packed kernel that EXECUTES every pair (no boxes, no early-out) on "
-                                     "the same resident clouds; executed flop = 8 x n_pad x m_pad",
-                             "min_launch_us": 1e3 * float(dense.min()), "avg_launch_us": 1e3 * float(dense.mean()), "launches": 10,
-                             "flop_per_launch": dense_flop, "achieved": dense_flop / t_dense / 1e12,
-                             "frac": dense_flop / t_dense / 1e12 / FP32_PEAK_TFLOPS, "launch": dinfo},
-            "launch": info,
-            "hbm": {"algorithmic_bytes_per_pass": alg_bytes_pass, "achieved_GBps": alg_bytes_pass * ppl / t_launch / 1e9,
-                    "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes_pass * ppl / t_launch / 1e9 / HBM_PEAK_GBPS},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, Q)
-    # ---- the same K steps with the iteration's collective done by RCCL (library-issued ncclAllReduce) -----------------
-    if use_local:
-        ranks.barrier()
-        ok, why = guarded(lambda: pkg.distributed.attach_native_comm(ctx, ranks.dist) if ranks.dist
-                          else ctx.comm_init(ctx.comm_unique_id(), 0, 1), 90)
-        all_ok = ranks.min_int(1 if ok else 0) == 1
-        rccl = {"route": "icp_comm_init: ONE ncclAllReduce(sum, 32 doubles, in place) per iteration, issued by libicp_mi355x "
-                         "right behind the finalize kernel on the loop's stream; one kernel launch per pass (no resident kernel)",
-                "ranks": world}
-        if all_ok:
-            run_steps(min(W, 50))
-            dt_r, stats_r, _, _, _ = timed(K, 0)
-            rccl.update({"value": world * K / dt_r, "unit": "iterations/s", "us_per_iteration": 1e6 * dt_r / K,
-                         "registrations_timed": stats_r["registrations"]})
-            ctx.comm_destroy()
-        else:
-            rccl["error"] = why if not ok else "another rank could not create its communicator"
-            if ok:
-                ctx.comm_destroy()
-        if out is not None:
-            out["rccl"] = rccl
-
-    ranks.barrier()
-    return out, ctx, ranks
+        roof["dense_kernel"] = {"what": "the LDS-tiled packed kernel that EXECUTES every pair (no boxes, no early-out) on the same resident clouds; "
+                                        "executed flop = 8 x n_pad x m_pad",
+                                "min_launch_us": 1e3 * float(dense.min()), "avg_launch_us": 1e3 * float(dense.mean()), "launches": 10,
+                                "flop_per_launch": dense_flop, "achieved": dense_flop / t_dense / 1e12,
+                                "frac": dense_flop / t_dense / 1e12 / FP32_PEAK_TFLOPS, "launch": dinfo}
+        roof["time_to_solution"]["speedup_vs_dense_kernel_per_pass"] = t_dense / (t_launch / ppl)
+    return roof
 
 
-# ---- configs[4]: the synthetic 10 M-point cloud, moving cloud sharded over the ranks ------------------------------------
-def run_s5(args, rank, local_rank, world):
-    import numpy as np
-    import torch
+def leg_main(args, rank, local_rank, world):
+    import torch  # noqa: F401  (device synchronisation in the timed region)
     from __graft_entry__ import load_package
     pkg = load_package()
     ranks = Ranks(rank, world)
-    N = args.points
-    Wd = int(np.ceil(np.sqrt(N)))
-    D = pkg.datasets.synthetic_grid(Wd, np.float32)[:N]
-    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
-    lo, cnt = pkg.shard_range(N, rank, world)
-    P = np.ascontiguousarray(D[lo:lo + cnt])
-    del D
-    ctx = pkg.Context(local_rank)
-    t0 = time.perf_counter()
-    ctx.set_model(M)
-    ctx.set_moving(P)
-    setup_s = time.perf_counter() - t0
+    K, W = args.steps, args.warmup
+    wl = WORKLOADS[args.config](pkg, args, rank, local_rank, world)
+    ctx = wl.ctx
+    use_dist = world > 1 or os.environ.get("ICP_BENCH_FORCE_DIST") == "1"
     if ranks.dist:
         pkg.distributed.attach_local_comm(ctx, ranks.dist)
 
-    def sync():
-        ranks.barrier()
-        torch.cuda.synchronize(local_rank)
-
-    def run(iters):
-        ctx.reset_moving()
-        ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=iters, tol=1e-6, fixed_iterations=True)
-        k, done = 0, False
-        while not done:
-            kk, done = ctx.loop_run(1 << 20)
-            k += kk
-        return k
-
-    if args.warmup > 0:
-        run(args.warmup)
-    ctx.set_profiling(1)
-    sync()
-    t0 = time.perf_counter()
-    k = run(args.steps)
-    sync()
-    dt = ranks.max(time.perf_counter() - t0)
-    sec, cnt_l = ctx.loop_timing()
+    passes_full = wl.sanity()
+    first_us = None
+    if wl.name == "bunny":    # (a context's very first registration ran above: what it cost per iteration is a figure of its own)
+        t0 = time.perf_counter()
+        k2 = wl.registration()
+        first_us = 1e6 * (time.perf_counter() - t0) / max(1, k2)
+    if W > 0:
+        wl.run_steps(W)
+    # HIP events around the loop's kernel inside the timed region: s5 -- every launch is a pass of milliseconds; a resident
+    # kernel is a whole registration, so every 7th is timed when the region holds many of them (1-2 % of overhead) and a
+    # region of a few registrations is not bracketed at all (the two event records and the wait for the kernel's end would
+    # be a tenth of what is being measured); Bunny.csv's launches are armed ahead of their transform, which a timed launch
+    # cannot be: its kernel block follows the region
+    regs_expected = max(1, K // max(1, passes_full))
+    if wl.regime == "fixed":
+        stride = 1
+    elif wl.name == "bunny":
+        stride = 0
+    else:
+        stride = 7 if regs_expected >= 70 else 0
+    dt, stats, sec1, cnt1, passes1 = timed_steps(wl, ranks, K, stride)
     st = ctx.loop_state()
     out = None
     if rank == 0:
+        n_rep = world if wl.scaling == "weak" else 1
         out = {
-            "metric": "ICP iterations/sec, synthetic 10M-point cloud (BASELINE configs[4])",
-            "value": args.steps / dt, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic z = x^2 - y^2 grid, W = %d truncated to %d points; model = moved copy" % (Wd, N),
-            "config": {"workload": "synthetic 10M-point cloud point-to-point ICP, moving cloud sharded over the ranks (BASELINE configs[4])",
-                       "model_points": N, "moving_points_per_gpu": cnt, "global_moving_points": N,
-                       "regime": "one registration of `steps` fixed iterations from the initial pose (cold first pass)",
-                       "iterations_run": k, "set_up_ms_rank0": 1e3 * setup_s,
-                       "collective": "sum of 32 doubles per iteration through shared host memory (icp_comm_init_local)" if world > 1 else "none"},
-            "pairs_per_s_algorithmic": float(N) * float(N) * args.steps / dt,
-            "matching_kernel": {"launches_timed": cnt_l, "avg_launch_ms": 1e3 * sec / max(1, cnt_l)},
-            "rms_error_series_head": [float(e) for e in st["err"][:6]], "final_rms_error": float(st["err"][-1]),
+            "metric": wl.metric_id, "value": n_rep * K / dt, "unit": "iterations/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K,
+            "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": wl.dtype, "data": wl.data,
+            "config": {"workload": wl.workload, "moving_points_per_gpu": wl.n, "model_points": wl.m,
+                       "global_moving_points": wl.n_global if wl.scaling == "strong" else wl.n * world,
+                       "regime": ("one registration of `steps` fixed iterations from the initial pose (cold first pass)" if wl.regime == "fixed" else
+                                  "back-to-back full registrations from the initial pose (cold first pass, tol %g, stop rule on); "
+                                  "a step = one iteration of such a registration" % wl.tol),
+                       "registrations_timed": stats["registrations"],
+                       "iterations_per_registration": stats["iterations"] / max(1, stats["registrations"]),
+                       "passes_of_a_full_registration": passes_full,
+                       "collective": ("sum of the loop's moment vector (32 doubles, the 19 / 28 the metric uses travel) per iteration over the node's "
+                                      "ranks through shared host memory (icp_comm_init_local), rank order; the RCCL route is measured beside it (`rccl`)")
+                                     if ranks.dist else "none"},
+            "final_rms_error": float(st["err"][-1]),
         }
+        if wl.name == "s5":
+            out["config"]["set_up_ms_rank0"] = 1e3 * wl.setup_s
+            out["pairs_per_s_algorithmic"] = float(wl.n_global) * float(wl.m) * K / dt
+            out["rms_error_series_head"] = [float(e) for e in st["err"][:6]]
+        if first_us is not None:
+            out["config"]["second_registration_of_the_context_us_per_iteration"] = first_us
+        if wl.name == "hall_plane":
+            out["config"]["normals_on_device_ms"] = 1e3 * wl.normals_s
     if ranks.dist:
-        ctx.comm_destroy()
-    return out, ctx, ranks
+        ctx.comm_destroy()     # rank 0 measures its roofline leg alone: no communicator may wait for the others
+    if rank == 0:
+        region = None
+        if cnt1 > 0:
+            region = {"launches_timed": cnt1, "avg_launch_us": 1e6 * sec1 / cnt1, "passes_per_launch": passes1 / cnt1}
+        out["roofline"] = roofline_leg(wl, K, passes_full, region, stride)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline()
+    # the RCCL leg runs in a process of its own (the supervisor starts it): agree on its port here
+    port = 0
+    if use_dist and args.config in ("hall", "s5") and not args.no_rccl:
+        port = ranks.max_int(free_port() if rank == 0 else 0)
+    ranks.barrier()
+    ctx.close()
+    ranks.close()
+    return out, {"rccl_port": port}
 
 
-def run_bunny(args, rank, local_rank, world):
-    """BASELINE configs[1]: Bunny.csv (35 947 points) against its moved copy, point-to-point, the whole cloud on every rank
-    (replicas: a cloud of this size does not shard usefully).  A step is one ICP iteration of real registrations from the
-    initial pose (tolerance 1e-6, cold first pass and launches included), as in the hall configuration."""
-    import numpy as np
-    import torch
+# ======================================================================================================================
+# --leg rccl: the same K steps with the iteration's collective done by RCCL (library-issued ncclAllReduce)
+# ======================================================================================================================
+def leg_rccl(args, rank, local_rank, world):
+    import torch  # noqa: F401
     from __graft_entry__ import load_package
     pkg = load_package()
     ranks = Ranks(rank, world)
-    B = np.fromfile(os.path.join(ROOT, "tests", "golden", "bunny_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
-    M = pkg.datasets.make_model_gpu(B, *pkg.datasets.BUNNY)
-    ctx = pkg.Context(local_rank)
-    ctx.set_model(M)
-    ctx.set_moving(B)
+    K, W = args.steps, args.warmup
+    wl = WORKLOADS[args.config](pkg, args, rank, local_rank, world)
+    ctx = wl.ctx
+    rccl = {"route": "icp_comm_init: ONE ncclAllReduce(sum, 32 doubles, in place) per iteration, issued by libicp_mi355x right behind the "
+                     "finalize kernel on the loop's stream; one kernel launch per pass (no resident kernel)",
+            "ranks": world}
+    ok, why = True, ""
+    try:
+        if ranks.dist:
+            pkg.distributed.attach_native_comm(ctx, ranks.dist)
+        else:
+            ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    except Exception as e:  # noqa: BLE001
+        ok, why = False, f"{type(e).__name__}: {e}"
+    all_ok = ranks.min_int(1 if ok else 0) == 1
+    if all_ok:
+        wl.sanity()
+        if W > 0:
+            wl.run_steps(min(W, 50))
+        dt, stats, _, _, _ = timed_steps(wl, ranks, K, 0)
+        st = ctx.loop_state()
+        n_rep = world if wl.scaling == "weak" else 1
+        rccl.update({"value": n_rep * K / dt, "unit": "iterations/s", "us_per_iteration": 1e6 * dt / K,
+                     "registrations_timed": stats["registrations"], "final_rms_error": float(st["err"][-1])})
+    else:
+        rccl["error"] = why if not ok else "another rank could not create its communicator"
+    if ok:
+        ctx.comm_destroy()
+    ranks.barrier()
+    ctx.close()
+    ranks.close()
+    return (rccl if rank == 0 else None), {}
 
-    def registration():
-        ctx.reset_moving()
-        ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=100, tol=1e-6)
-        k, done = 0, False
-        while not done:
-            kk, done = ctx.loop_run(1 << 20)
-            k += kk
-        return k
 
-    def sync():
-        ranks.barrier()
-        torch.cuda.synchronize(local_rank)
+# ======================================================================================================================
+# the supervisor: no GPU call in this process
+# ======================================================================================================================
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE: N supervisors, one rank each; rank 0's line is relayed"""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    return bad[0] if bad else 0
 
-    first = time.perf_counter()
-    k_first = registration()                     # a context's first registration: its first pass has no counts to share the rows by
-    first = time.perf_counter() - first
-    done_it = 0
-    while done_it < args.warmup:
-        done_it += registration()
-    sync()
-    t0 = time.perf_counter()
-    steps = regs = 0
-    while steps < args.steps:
-        steps += registration()
-        regs += 1
-    sync()
-    dt = ranks.max(time.perf_counter() - t0)
-    st = ctx.loop_state()
-    info = ctx.nn_launch_info()
-    out = None
+
+def run_leg(leg, argv, env, timeout):
+    """one leg in a fresh child process; (rc or None when it had to be killed, its stdout, the side record it left)"""
+    fd, side = tempfile.mkstemp(prefix="icp_bench_", suffix=".json")
+    os.close(fd)
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--leg", leg, "--side-file", side]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+        rc = p.returncode
+    except subprocess.TimeoutExpired:
+        p.kill()                      # (the exact process this supervisor started)
+        out, _ = p.communicate()
+        rc = None
+    rec = {}
+    try:
+        txt = open(side).read()
+        rec = json.loads(txt) if txt.strip() else {}
+    except (OSError, ValueError):
+        pass
+    try:
+        os.unlink(side)
+    except OSError:
+        pass
+    return rc, out.decode(errors="replace"), rec
+
+
+def last_json_line(text):
+    for ln in reversed(text.splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def supervise(args, argv):
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    env = dict(os.environ)
+    t_main = float(os.environ.get("ICP_BENCH_TIMEOUT", "2400"))
+    t_rccl = float(os.environ.get("ICP_BENCH_RCCL_TIMEOUT", "300"))
+    rc, text, side = run_leg("main", argv, env, t_main)
+    line = last_json_line(text) if rank == 0 else None
+    if rc is None:
+        sys.stderr.write(f"[bench] rank {rank}: the measuring process gave no answer within {t_main:.0f} s and was killed\n")
+        return 3
+    if rc != 0:
+        return rc
+    exit_code = 0
+    port = int(side.get("rccl_port", 0) or 0)
+    if port:
+        env2 = dict(env, MASTER_PORT=str(port), MASTER_ADDR=env.get("MASTER_ADDR", "127.0.0.1"))
+        rc2, text2, _ = run_leg("rccl", argv, env2, t_rccl)
+        rccl = last_json_line(text2) if rank == 0 else None
+        rehearsal = os.environ.get("ICP_BENCH_ONE_DEVICE") == "1"
+        if rc2 is None:
+            rccl = {"ranks": world, "error": f"no answer within {t_rccl:.0f} s: the process was killed (a stuck communicator?)", "hung": True}
+            exit_code = 3
+        elif rc2 != 0:
+            rccl = {"ranks": world, "error": f"the RCCL leg ended with exit code {rc2}"}
+            exit_code = 4
+        elif rank == 0 and (rccl is None or "error" in rccl):
+            rccl = rccl or {"ranks": world, "error": "the RCCL leg printed no record"}
+            # (two ranks rehearsed on ONE device: RCCL refuses that, by design -- reported, not a failure of the run)
+            exit_code = 0 if rehearsal else 4
+        if line is not None:
+            line["rccl"] = rccl
     if rank == 0:
-        out = {
-            "metric": "ICP iterations/sec, Bunny.csv 35 947-point cloud (BASELINE configs[1])",
-            "value": world * steps / dt, "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "tests/golden/bunny_xyz_f32.bin (the reference's Bunny.csv as float32) and its moved copy",
-            "config": {"workload": "Bunny.csv point-to-point ICP (BASELINE configs[1]), one replica per rank",
-                       "moving_points": int(B.shape[0]), "model_points": int(M.shape[0]), "registrations_timed": regs,
-                       "iterations_per_registration": steps / regs, "steps_requested": args.steps,
-                       "matching_blocks": info["blocks"], "threads_per_block": info["threads"],
-                       "first_registration_of_the_context_us_per_iteration": 1e6 * first / max(1, k_first)},
-            "final_rms_error": float(st["err"][-1]),
-        }
-    return out, ctx, ranks
+        if line is None:
+            sys.stderr.write("[bench] the measuring process printed no line\n")
+            return 5
+        print(json.dumps(line), flush=True)
+    return exit_code
 
 
 def main():
@@ -551,19 +874,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=("hall", "s5", "bunny"), default="hall")
+    ap.add_argument("--config", choices=CONFIGS, default="hall")
     ap.add_argument("--points", type=int, default=10_000_000, help="s5: size of the synthetic cloud")
+    ap.add_argument("--width", type=int, default=32, help="cpu_f64: WIDTH of the synthetic grid (src/ICP_CPU.c ships 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rccl", action="store_true", help="N > 1: skip the RCCL leg")
+    ap.add_argument("--leg", choices=("main", "rccl"), default=None, help="(internal) run this leg in this process")
+    ap.add_argument("--side-file", default=None, help="(internal)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"hall": 2000, "bunny": 420}.get(args.config, 30)
+        args.steps = DEFAULT_STEPS[args.config][0]
     if args.warmup is None:
-        args.warmup = {"hall": 200, "bunny": 42}.get(args.config, 5)
+        args.warmup = DEFAULT_STEPS[args.config][1]
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         raise SystemExit("--gpus >= 1, --steps >= 1, --warmup >= 0")
+    if args.leg is None:
+        argv = [a for a in sys.argv[1:]]
+        sys.exit(supervise(args, argv))
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(spawn_ranks(args.gpus))          # (nothing in this process has touched a GPU)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -573,24 +901,20 @@ def main():
     # device, so the `rccl` leg reports that); never used by the driver
     if os.environ.get("ICP_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
-
     # the contract is ONE JSON line on stdout and RCCL prints a version banner there when its first communicator is
     # created: fd 1 points at stderr until the result is printed
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    out, ctx, ranks = {"hall": run_hall, "s5": run_s5, "bunny": run_bunny}[args.config](args, rank, local_rank, world)
+    out, side = (leg_main if args.leg == "main" else leg_rccl)(args, rank, local_rank, world)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
-    if rank == 0:
+    if args.side_file:
+        with open(args.side_file, "w") as f:
+            json.dump(side, f)
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
-    ctx.close()
-    ranks.close()
-    sys.stdout.flush()
-    sys.stderr.flush()
-    if STUCK:
-        os._exit(0)    # a communicator attempt never returned: its helper thread would keep the interpreter from ending
 
 
 if __name__ == "__main__":

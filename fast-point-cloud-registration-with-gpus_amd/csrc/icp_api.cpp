@@ -1031,8 +1031,11 @@ static int prepare_row_order(icp_ctx* c)
 
 static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
 {
-    if (c->prec == ICP_F64)   // (fp64: no sorted views)
-        return icp::NNCullInputs{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
+    if (c->prec == ICP_F64) {   // (fp64: no sorted views)
+        icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
+        if (c->count_work) o.work = (unsigned long long*)c->work.p;
+        return o;
+    }
     icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
@@ -1334,7 +1337,7 @@ int icp_loop_enqueue(icp_ctx* c)
             ta.compact = use_compact_rows(c, pl, ta.metric, mom_rows) ? 1 : 0;
         }
         L.rows_compact = tail && ta.compact != 0;
-        if (tail && host_reduce) prepare_rows_format(c, L.rows_compact);
+        if (host_reduce) prepare_rows_format(c, L.rows_compact);   // (also the two-kernel form: launch_moments writes full rows)
         if (fused) {
             icp::NNFusedTransform ft{L.H.R, L.H.t, (const int32_t*)c->idx[L.applied_idx].p, c->P2.p, err_rows};
             HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, tail ? &ta : nullptr, c->stream));

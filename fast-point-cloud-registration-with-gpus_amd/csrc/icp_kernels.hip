@@ -2737,7 +2737,7 @@ __device__ __forceinline__ void tail_fill_one(double (*tr)[65], int lane, bool l
 
 // NW: waves per block -- 16 while that still gives every block its own CU (a far-apart pair is hundreds of hits per
 // block: the more waves share them the better), else 8 (two blocks per CU)
-template <int TAIL, int NW>
+template <int TAIL, int NW, bool DIAG = false /* icp_set_work_counting: tallies of the executed work (NNFuse::work) */>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(const double* __restrict__ P, int n_pad, const double* __restrict__ Q,
                                                                      int m_pad, int round_passes, double* __restrict__ part_d,
                                                                      int32_t* __restrict__ part_idx, RT<double> rt_arg, NNFuse fuse, NNTail tail)
@@ -2777,6 +2777,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(c
     js = sok ? js : 0;
     double sq[3] = {Qg[js], Qg[(size_t)m_pad + js], Qg[2 * (size_t)m_pad + js]};
     double x = P[pi], y = P[(size_t)n_pad + pi], z = P[2 * (size_t)n_pad + pi];
+    unsigned int wk_find = 0, wk_hit[2] = {0, 0}, wk_samp = 0;   // (work-counting instantiation only)
     // ---- the pass loop: one turn for an ordinary launch, one per ICP pass for a resident one (fuse.mailbox: a message of
     // TWO cache lines -- twelve doubles do not fit one -- in four 32-byte parts {3 doubles, cmd, tag}: NNMailbox64) ----
     for (int pass = 0;; ++pass) {
@@ -2900,9 +2901,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(c
         }
         __syncthreads();
         double sb = kInf;
-        for (int gp = w; gp < ng; gp += NW)
+        for (int gp = w; gp < ng; gp += NW) {
+            if constexpr (DIAG) ++wk_samp;
 #pragma unroll
             for (int k = 0; k < 8; ++k) sb = __builtin_fmin(sb, dist2<double>(x, y, z, sl[gp * 8 + k], sl[SMAX + gp * 8 + k], sl[2 * SMAX + gp * 8 + k]));
+        }
         if (real && sb < kInf) atomicMin(&smin[lane], (unsigned long long)__double_as_longlong(sb));
         __syncthreads();  // (also: the staging area is free again)
         const unsigned long long v = smin[lane];
@@ -2923,6 +2926,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(c
             const int c0 = rb + (r * NW + w) * 64;
             if (c0 >= c_hi) break;
             const int cidx = c0 + lane;
+            if constexpr (DIAG) wk_find += (unsigned int)max(0, min(64, c_hi - c0));
             const double* bp = boxes + (size_t)(cidx < c_hi ? cidx : c_lo) * 8;
             const double2 b01 = *reinterpret_cast<const double2*>(bp), b23 = *reinterpret_cast<const double2*>(bp + 2),
                           b45 = *reinterpret_cast<const double2*>(bp + 4);
@@ -2966,6 +2970,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(c
             const int cnt = mine < 8 ? mine : 8;
             for (int rr = 0; rr < cnt; ++rr) {
                 const double* sb = stage + rr * STG;
+                if constexpr (DIAG) ++wk_hit[0];
                 {   // the chunk's box against the lane's point (ties pass: the hits are unordered)
                     const double gx = __builtin_fmax(__builtin_fmax(sb[0] - x, x - sb[3]), 0.0);
                     const double gy = __builtin_fmax(__builtin_fmax(sb[1] - y, y - sb[4]), 0.0);
@@ -2973,6 +2978,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(c
                     const double L = ((gx * gx + gy * gy) + gz * gz) * 0.99999999;
                     if (__builtin_amdgcn_ballot_w64(L <= best) == 0ull) continue;
                 }
+                if constexpr (DIAG) ++wk_hit[1];
                 const int ch = __builtin_amdgcn_readfirstlane(hits[hb + rr * NW + w]);
                 double d[8];
                 double c0 = kInf;
@@ -3000,6 +3006,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(c
             const unsigned long long v = smin[lane];
             if (real && v < kInfBits && v < (unsigned long long)__double_as_longlong(best)) { best = __longlong_as_double((long long)(v + 1ull)); bj = -1; }
         }
+    }
+    if constexpr (DIAG) {
+        if (fuse.work != nullptr && lane == 0) {
+            if (wk_find) atomicAdd(&fuse.work[NN_WORK_FIND_BOXES], (unsigned long long)wk_find);
+            if (wk_hit[0]) atomicAdd(&fuse.work[NN_WORK_HITS_BOX], (unsigned long long)wk_hit[0]);
+            if (wk_hit[1]) { atomicAdd(&fuse.work[NN_WORK_HITS_XY], (unsigned long long)wk_hit[1]); atomicAdd(&fuse.work[NN_WORK_HITS_FULL], (unsigned long long)wk_hit[1]); }
+            if (wk_samp) atomicAdd(&fuse.work[NN_WORK_SAMPLE_GROUPS], (unsigned long long)wk_samp);
+            if (w == 0) atomicAdd(&fuse.work[NN_WORK_BLOCK_PASSES], 1ull);
+            if (w == 0 && apply) atomicAdd(&fuse.work[NN_WORK_BLOCK_TRANSFORMS], 1ull);
+        }
+        wk_find = wk_samp = 0; wk_hit[0] = wk_hit[1] = 0;
     }
     // every wave leaves its candidate; wave 0 takes the lexicographic (distance, index) minimum
     cand_d[w][lane] = bj >= 0 ? best : kInf;
@@ -4629,6 +4646,9 @@ static hipError_t launch_row64_f64(const NNPlan& pl, const void* P, const void* 
                                           {(const void*)nn_match_row64_f64<1, 8>, (const void*)nn_match_row64_f64<1, 16>},
                                           {(const void*)nn_match_row64_f64<2, 8>, (const void*)nn_match_row64_f64<2, 16>}};
     const void* fn = fns[tl][nw == 16 ? 1 : 0];
+    // icp_set_work_counting: the instrumented instantiation (point-to-point rows only: what the fp64 loop of src/ICP_CPU.c runs)
+    fuse.work = (opt->work != nullptr && tl == 1) ? opt->work : nullptr;
+    if (fuse.work != nullptr) fn = nw == 16 ? (const void*)nn_match_row64_f64<1, 16, true> : (const void*)nn_match_row64_f64<1, 8, true>;
     if (fuse.resident) {
         // every block must be on the machine at once: blocks <= CUs x resident blocks per CU (the occupancy query)
         if (!ta) return hipErrorInvalidValue;

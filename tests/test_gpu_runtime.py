@@ -172,6 +172,28 @@ def test_bench_with_the_drivers_arguments():
     assert d["final_rms_error"] < 1e-3
 
 
+@pytest.mark.parametrize("cfg,extra", [("hall_plane", ["--steps", "40", "--warmup", "10"]), ("bunny", ["--steps", "44", "--warmup", "0"]),
+                                       ("s5", ["--points", "600000", "--steps", "8", "--warmup", "2"]), ("cpu_f64", ["--steps", "120", "--warmup", "10"])])
+def test_bench_every_config_carries_roofline_and_cpu_baseline(cfg, extra):
+    """BASELINE configs[0], [1], [3], [4] through `bench.py --config ...`: a line with an EXECUTED-work roofline of the config's own
+    kernel (frac <= 1, recomputable from its parts) and a CPU baseline timed beside it"""
+    d = _bench(["--config", cfg] + extra)
+    assert d["value"] > 0 and d["unit"] == "iterations/s" and d["dtype"] == ("f64" if cfg == "cpu_f64" else "f32")
+    r = d["roofline"]
+    assert r["peak"] == (78.6 if cfg == "cpu_f64" else 157.3) and r["unit"] == "TFLOP/s" and r["bound"] == "valu"
+    assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    ex = r["executed"]
+    assert abs(r["achieved"] - ex["flop_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) < 1e-9 * max(1.0, r["achieved"])
+    assert abs(ex["flop_per_launch"] - ex["flop_per_pass"] * r["passes_per_launch"]) < 1e-6 * ex["flop_per_launch"]
+    assert abs(sum(ex["flop_by_part_one_registration"].values()) - ex["flop_per_pass"] * ex["passes_counted"]) < 1e-6 * ex["flop_per_pass"] * ex["passes_counted"]
+    assert ex["work_counters_one_registration"]["hits_full"] > 0 and 0 < ex["pairs_evaluated_in_full_fraction"] <= 1.0
+    assert r["launches_timed"] >= 1 and r["avg_launch_us"] > 0
+    c = d["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] == 1 and c["kind"] == "port" and c["sample"]
+    if cfg == "s5":
+        assert c["extrapolated"] is True and "EXTRAPOLATED" in c["sample"]
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher: the parent spawns the ranks (rehearsed with both on the one GPU)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
