@@ -260,3 +260,20 @@ def test_bench_rccl_leg_single_rank():
     """the library-issued ncclAllReduce route, exercised with the one rank this box has"""
     d = _bench(["--steps", "120", "--warmup", "20", "--no-cpu-baseline"], {"ICP_BENCH_FORCE_DIST": "1"})
     assert d["rccl"]["ranks"] == 1 and d["rccl"]["value"] > 0 and d["rccl"]["us_per_iteration"] > 0
+
+
+def test_bench_rccl_leg_on_the_sharded_config_single_rank():
+    """configs[4] is the config north_star shards: its line carries the library-issued ncclAllReduce route too"""
+    d = _bench(["--config", "s5", "--points", "600000", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], {"ICP_BENCH_FORCE_DIST": "1"})
+    assert d["rccl"]["ranks"] == 1 and d["rccl"]["value"] > 0 and d["rccl"]["us_per_iteration"] > 0
+    assert abs(d["rccl"]["final_rms_error"] - d["final_rms_error"]) < 1e-9      # the same registration through either route
+
+
+def test_bench_a_stuck_rccl_leg_is_visible():
+    """a communicator attempt that never answers: the process is killed at its time limit, the line is still printed (with the
+    reason) and the run ends NON-zero -- never rc 0 (round 2 left through os._exit(0))"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline"],
+                         env=dict(os.environ, ICP_BENCH_FORCE_DIST="1", ICP_BENCH_RCCL_TIMEOUT="0.2"), capture_output=True, text=True, timeout=420)
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["value"] > 0 and d["rccl"]["hung"] is True and "killed" in d["rccl"]["error"]
