@@ -187,6 +187,7 @@ def _hall_pair(pkg, ctx):
 
 class Hall(Workload):
     name = "hall"
+    pmc_kernel = "nn_match_row64<1, false"
     metric_id = "ICP iterations/sec + NN HBM GB/s (% roofline), hall cloud"
     data = ("hall LiDAR scan fixture (tests/golden/hall_ranges_u32.bin, decoded from the reference's Donut_1024x16.csv; "
             "polar->Cartesian by the device kernel)")
@@ -237,6 +238,7 @@ class Hall(Workload):
 
 class HallPlane(Hall):
     name = "hall_plane"
+    pmc_kernel = "nn_match_row64<2, false"
     metric_id = "ICP iterations/sec, hall cloud, point-to-plane (BASELINE configs[3])"
     workload = "hall LiDAR scan point-to-plane ICP, 6x6 solve on the host (BASELINE configs[3])"
     kernel = "nn_match_row64<2> (rows of 64 points, 8 waves per block, point-to-plane row tail: 21 + 6 sums)"
@@ -288,6 +290,7 @@ class HallPlane(Hall):
 
 class Bunny(Workload):
     name = "bunny"
+    pmc_kernel = "nn_match_sparse<1, false, true, false, 8>"
     metric_id = "ICP iterations/sec, Bunny.csv 35 947-point cloud (BASELINE configs[1])"
     data = "tests/golden/bunny_xyz_f32.bin (the reference's Bunny.csv as float32) and its moved copy"
     workload = "Bunny.csv point-to-point ICP (BASELINE configs[1]), one replica per rank"
@@ -336,6 +339,7 @@ class Bunny(Workload):
 
 class S5(Workload):
     name = "s5"
+    pmc_kernel = "nn_match_sparse<1, false, true, true, 16>"
     metric_id = "ICP iterations/sec, synthetic 10M-point cloud (BASELINE configs[4])"
     workload = "synthetic 10M-point cloud point-to-point ICP, moving cloud sharded over the ranks (BASELINE configs[4])"
     kernel = ("nn_match_sparse<1, ..., HIER> (rows of 128 points, 16 waves per block, three-level box hierarchy over the Morton view "
@@ -400,6 +404,7 @@ class S5(Workload):
 
 class CpuF64(Workload):
     name = "cpu_f64"
+    pmc_kernel = "nn_match_row64_f64<1, 16, false>"
     metric_id = "ICP iterations/sec, synthetic z=x^2-y^2 cloud, fp64 (src/ICP_CPU.c's run; BASELINE configs[0])"
     dtype = "f64"
     peak = FP64_PEAK_TFLOPS
@@ -621,12 +626,13 @@ def roofline_leg(wl, K, passes_full, region, stride):
     for cand in (os.path.join(ROOT, "profiles", "r3", f"pmc_hbm_traffic_{wl.name}.json"),):
         if wl.world == 1 and os.path.exists(cand):
             rec = json.load(open(cand))
-            k = next((v for kk, v in rec.items() if "nn_match_" in kk and isinstance(v, dict)), None)
+            kk, k = next(((kk, v) for kk, v in rec.items() if wl.pmc_kernel in kk and isinstance(v, dict)), (None, None))
             if k:
                 roof["traffic"] = k["hbm_bytes_corrected"]
-                roof["traffic_source"] = ("%s (build %s): %s, FETCH_SIZE %.0f B raw (x2: gfx950 correction) + WRITE_SIZE %.0f B per launch"
-                                          % (os.path.relpath(cand, ROOT), rec.get("_build", "unknown"), rec.get("_what", "one launch"),
-                                             k["fetch_bytes_raw"], k["write_bytes"]))
+                roof["traffic_source"] = ("%s (build %s): kernel %s, %s; FETCH_SIZE %.0f B raw (x2: gfx950 correction) + WRITE_SIZE %.0f B per launch, "
+                                          "%d launches; against %.0f algorithmic bytes per launch (%.2f passes)"
+                                          % (os.path.relpath(cand, ROOT), rec.get("_build", "unknown"), kk.replace("void icp::", ""), rec.get("_what", "one launch"),
+                                             k["fetch_bytes_raw"], k["write_bytes"], k["launches"], alg_bytes * share * ppl, ppl))
     if wl.dtype == "f32" and wl.name in ("hall", "hall_plane", "bunny"):
         # the stand-alone matching kernel by the reference's method: min (and mean) of 10 launches after 2 warm-ups
         seeded = ctx.nn_match_bench_launches(10, 2, 0)
@@ -664,8 +670,14 @@ def leg_main(args, rank, local_rank, world):
         t0 = time.perf_counter()
         k2 = wl.registration()
         first_us = 1e6 * (time.perf_counter() - t0) / max(1, k2)
+    warm = None
     if W > 0:
+        if wl.regime == "fixed":
+            ctx.set_profiling(1)
         wl.run_steps(W)
+        if wl.regime == "fixed":
+            warm = ctx.loop_timing()
+            ctx.set_profiling(0)
     # HIP events around the loop's kernel inside the timed region: s5 -- every launch is a pass of milliseconds; a resident
     # kernel is a whole registration, so every 7th is timed when the region holds many of them (1-2 % of overhead) and a
     # region of a few registrations is not bracketed at all (the two event records and the wait for the kernel's end would
@@ -715,6 +727,10 @@ def leg_main(args, rank, local_rank, world):
         if cnt1 > 0:
             region = {"launches_timed": cnt1, "avg_launch_us": 1e6 * sec1 / cnt1, "passes_per_launch": passes1 / cnt1}
         out["roofline"] = roofline_leg(wl, K, passes_full, region, stride)
+        if warm is not None and region is not None and warm[1] > 0:
+            # (the figure `rocprofv3 --kernel-trace --stats` of this process shows for the kernel: its warm-up launches are the
+            # heavy first passes of a registration, once more)
+            out["roofline"]["all_launches_incl_warmup"] = {"launches": warm[1] + cnt1, "avg_launch_us": 1e6 * (warm[0] + sec1) / (warm[1] + cnt1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
     # the RCCL leg runs in a process of its own (the supervisor starts it): agree on its port here
