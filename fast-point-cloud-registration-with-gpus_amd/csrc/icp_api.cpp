@@ -205,6 +205,8 @@ struct LoopState {
     bool armed_compact = false;
     std::chrono::steady_clock::time_point armed_at{};   // when the armed pass was launched (mailbox lease)
     icp::NNMailbox* live_mailbox = nullptr;             // a resident kernel is running and listens here
+    bool from_pristine = false;  // the loop started from the cloud icp_set_moving uploaded: it can be run again from the copy
+    long long steps = 0;         // completed (enqueue + complete) steps of this loop
 };
 
 // the calling thread's affinity, narrowed to the device's NUMA node for the duration of one entry point (see icp_create)
@@ -268,6 +270,7 @@ struct icp_ctx {
     bool mail_wide = true;             // ICP_MAILBOX_AVX=0: write the mailbox line word by word (payload, fence, tags) -- the path of a CPU without AVX
     double* mom_dev = nullptr;
     double* h_mom = nullptr;  // pinned: the reduced ICP_NMOM vector as the host solve reads it
+    unsigned int* h_nonfinite = nullptr;  // pinned, coherent: points with a NaN / infinite coordinate seen by the last upload
     // single-GPU fast path: the moments / transform kernels store their per-block partial rows straight
     // into mapped pinned host memory and the host adds them in block order -- no finalize launch, no
     // D2H blit.  (With an external moments buffer, i.e. the multi-GPU driver, the device finalize runs.)
@@ -294,6 +297,10 @@ struct icp_ctx {
     // the message of that pass of a registration -- a descheduled host thread, as the mailbox lease has to survive it
     int debug_stall_pass = -1;
     double debug_stall_s = 0.0;
+    int debug_lose_pass = -1;          // test hook (ICP_DEBUG_LOSE_MESSAGE=pass): the message of that pass is never posted, once
+    bool moving_untouched = false;     // c->P (or the pristine copy standing in for it) still holds what icp_set_moving uploaded
+    bool rows_timed_out = false;       // the last failure of icp_loop_complete was a pass that never delivered its rows
+    int recoveries = 0;                // registrations finished step-wise after such a time-out (icp_recoveries)
     int pin_mode = 1;                  // ICP_PIN: 0 never, 1 scoped (default), 2 narrowed once and kept
     bool have_local_cpus = false;
     cpu_set_t local_cpus;              // CPUs of the device's NUMA node (sysfs local_cpulist)
@@ -424,10 +431,19 @@ int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision,
     if (count <= 0) return ICP_OK;
     HIP_TRY(c->stage.ensure(3 * (size_t)count * es));
     HIP_TRY(hipMemcpyAsync(c->stage.p, aos, 3 * (size_t)count * es, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(icp::launch_aos_to_soa(precision, c->stage.p, count, pad, dst.p, c->stream));
+    *(volatile unsigned int*)c->h_nonfinite = 0u;
+    HIP_TRY(icp::launch_aos_to_soa(precision, c->stage.p, count, pad, dst.p, c->stream, c->h_nonfinite));
     // the staging buffer is reused by the next upload: order them on the stream, and make sure the
     // pageable host source has been consumed before returning
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // Non-finite coordinates are refused (include/icp_mi355x.h, "Non-finite input").  The reference has no defined answer
+    // for them: src/ICP_CPU.c:232's `c == 0 || d < best` leaves a NaN point at index 0, and its centroid sums (:342-366)
+    // then turn the whole transform into NaN -- nothing a caller could use, and the pruned search has no bound to go by.
+    if (const unsigned int bad = *(volatile unsigned int*)c->h_nonfinite) {
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "%u of the %d points have a NaN or infinite coordinate: non-finite input is refused", bad, count);
+        return fail(ICP_ERR_INVALID, msg);
+    }
     return ICP_OK;
 }
 
@@ -614,6 +630,7 @@ int icp_create(int device, icp_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mom, ICP_NMOM * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_nonfinite, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) {
         // mailbox: fine-grained device memory written through the PCIe BAR when the machine allows it (every block
         // polls its own memory), else pinned host memory polled by block 0 and relayed (ICP_MAILBOX=host forces that)
@@ -643,6 +660,7 @@ int icp_create(int device, icp_ctx** out)
         return fail(ICP_ERR_HIP, msg);
     }
     c->stream = c->own_stream;
+    if (const char* v = std::getenv("ICP_DEBUG_LOSE_MESSAGE")) c->debug_lose_pass = std::atoi(v);
     if (const char* v = std::getenv("ICP_DEBUG_STALL")) {
         int pass = -1;
         double sec = 0.0;
@@ -698,6 +716,7 @@ void icp_destroy(icp_ctx* c)
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
+    if (c->h_nonfinite) (void)hipHostFree(c->h_nonfinite);
     if (c->h_mail) { if (c->mail_in_bar) (void)hipFree(c->h_mail); else (void)hipHostFree(c->h_mail); }
     if (c->relay) (void)hipFree(c->relay);
     if (c->h_mom_partials) (void)hipHostFree(c->h_mom_partials);
@@ -869,8 +888,9 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
     c->have_normals = false;
     c->loop.active = false;
     c->idx_valid = false;
-    if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q)) return rc;
+    c->have_model = false;     // (until the upload has been accepted)
     c->have_scan_copy = false;
+    if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q)) return rc;
     if (precision == ICP_F32 && m > 0) {
         // scan copy for the early-out matching kernels: exact duplicates of a lower-index point (and the padding)
         // voided to +inf -- they can never be the lowest-index minimum (see NNCullInputs).  Flags, Morton order and
@@ -935,6 +955,7 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
     c->n = n;
     c->loop.active = false;
     c->idx_valid = false;
+    c->have_moving = false;    // (until the upload has been accepted)
     if (int rc = upload_cloud(c, xyz, n, icp::pad_moving(n), precision, c->P)) return rc;
     if (n > 0) {
         const size_t bytes = 3 * (size_t)icp::pad_moving(n) * icp::elem_size(precision);
@@ -959,6 +980,7 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
     }
     c->have_moving = true;
     c->moving_is_pristine = false;
+    c->moving_untouched = true;
     return ICP_OK;
 }
 
@@ -968,6 +990,7 @@ int icp_reset_moving(icp_ctx* c)
     if (!c->have_moving) return fail(ICP_ERR_STATE, "no moving cloud resident");
     if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
     c->moving_is_pristine = true;
+    c->moving_untouched = true;
     c->loop.active = false;
     c->idx_valid = false;
     return ICP_OK;
@@ -978,6 +1001,7 @@ int icp_set_model_normals(icp_ctx* c, const void* nxyz, int m)
     if (int rc = use(c)) return rc;
     if (!c->have_model) return fail(ICP_ERR_STATE, "set the model before its normals");
     if (m != c->m || (m > 0 && !nxyz)) return fail(ICP_ERR_INVALID, "normal count must equal the model size");
+    c->have_normals = false;
     if (int rc = upload_cloud(c, nxyz, m, icp::pad_model(m), c->prec, c->Nrm)) return rc;
     c->have_normals = true;
     return ICP_OK;
@@ -1279,6 +1303,8 @@ int icp_loop_begin(icp_ctx* c, const icp_params* prm)
     L = LoopState();
     if (int rc = L.H.begin(*prm)) return fail(rc, "bad loop parameters");
     L.active = true;
+    L.from_pristine = c->moving_untouched;
+    c->moving_untouched = false;   // (a loop moves the cloud)
     return ICP_OK;
 }
 
@@ -1512,6 +1538,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
                     for (int r = 0; r < L.mom_blocks; ++r) have += row_tag(r) == tag_value(L.wait_tag) ? 1 : 0;
                     std::snprintf(msg, sizeof msg, "a matching pass ended without producing its rows: row %d of %d carries tag %.0f, expected %.0f; %d rows arrived (armed / resident launch timed out?)",
                                   b, L.mom_blocks, row_tag(b), tag_value(L.wait_tag), have);
+                    c->rows_timed_out = true;
                     return fail(ICP_ERR_HIP, msg);
                 }
             start_sum();
@@ -1551,6 +1578,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
         c->tr_solve += std::chrono::duration<double>(tr3 - tr2).count();
         c->tr_n += 1;
     }
+    L.steps += 1;
     if (done) *done = L.H.done ? 1 : 0;
     return ICP_OK;
 }
@@ -1635,7 +1663,8 @@ void loop_release_armed(icp_ctx* c)
 {
     LoopState& L = c->loop;
     icp::NNMailbox* mb = mail_slot(c->h_mail, L.armed_slot);
-    post_message(mb, L.H.R, L.H.t, icp::ICP_CMD_TRANSFORM_MATCH, L.armed_tag, c->mail_wide);
+    if (c->debug_lose_pass >= 0 && L.H.applied == c->debug_lose_pass) c->debug_lose_pass = -1;   // (test hook: this message is lost)
+    else post_message(mb, L.H.R, L.H.t, icp::ICP_CMD_TRANSFORM_MATCH, L.armed_tag, c->mail_wide);
     L.applied_idx = L.armed_prev_cur;
     L.H.note_applied();
     L.mom_blocks = c->plan.blocks_x;
@@ -1677,7 +1706,11 @@ bool can_reside(icp_ctx* c)
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
     // (a plan with shared rows starts with armed launches, see share_wants_resident; ICP_RESIDENT=2: resident from the first pass)
-    return c->resident && (c->resident > 1 || pl.share_blocks == 0 || share_wants_resident(c)) && (c->prec == ICP_F32 || pl.version == 3) && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
+    // (ranks of one node communicator that share a DEVICE never reside: each fits the machine alone, the two together need
+    // not -- one rank's waiting blocks would hold the CUs the other's rows are waited for on, the circular wait of can_arm)
+    // ICP_SHARED_DEVICE_RESIDENT=1 (tests: two hall-sized ranks, 2 x 256 half-CU blocks, known to fit together) lifts it.
+    static const bool shared_ok = std::getenv("ICP_SHARED_DEVICE_RESIDENT") && std::getenv("ICP_SHARED_DEVICE_RESIDENT")[0] == '1';
+    return c->resident && (!c->shares_device || shared_ok) && (c->resident > 1 || pl.share_blocks == 0 || share_wants_resident(c)) && (c->prec == ICP_F32 || pl.version == 3) && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
            icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done;
 }
 
@@ -1768,7 +1801,8 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
             c->idx_valid = true;
             ++matched;
         }
-        send(cmd, base + (double)sent);
+        if (c->debug_lose_pass >= 0 && L.H.applied == c->debug_lose_pass + (apply ? 1 : 0)) c->debug_lose_pass = -1;   // (test hook: this message is lost)
+        else send(cmd, base + (double)sent);
         if (c->trace_passes && sent > 0)
             std::fprintf(stderr, "[icp trace]   host turnaround (last row seen -> next message out): %.2f us\n",
                          1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - c->tr_rows_done).count());
@@ -1833,11 +1867,69 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
 
 }  // namespace
 
+// A pass that never delivered its rows (a message that no block saw, blocks another process kept off the machine) ends the
+// resident / armed conversation -- but not necessarily the registration: when the loop started from the uploaded cloud
+// (icp_set_moving / icp_reset_moving) the copy is still there, and the same registration is run again with plain launches,
+// one per pass, nothing resident and nothing armed.  Every loop form produces the same bits, so the caller gets what an
+// undisturbed run would have returned; only when that fails too (a device that is really gone) does the error surface.
+static int loop_run_inner(icp_ctx* c, int max_steps, int* k_out, int* d_out);
+
+static int redo_stepwise(icp_ctx* c, const icp_params& prm, long long target_steps, int* d_out)
+{
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return ICP_ERR_HIP; }
+    const int keep_resident = c->resident;
+    const bool keep_arm = c->arm;
+    c->resident = 0;
+    c->arm = false;
+    c->moving_is_pristine = true;
+    c->moving_untouched = true;
+    int d = 0;
+    int rc = icp_loop_begin(c, &prm);
+    while (rc == ICP_OK && !d && c->loop.steps < target_steps) {
+        rc = icp_loop_enqueue(c);
+        if (rc == ICP_OK) rc = icp_loop_complete(c, &d);
+    }
+    c->resident = keep_resident;
+    c->arm = keep_arm;
+    *d_out = d;
+    return rc;
+}
+
 int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
 {
     if (max_steps < 0) return fail(ICP_ERR_INVALID, "max_steps < 0");
     if (!c) return fail(ICP_ERR_INVALID, "null context");
     ScopedPin pin(c);
+    const bool can_redo = c->loop.active && c->loop.from_pristine && !c->comm && !c->lcomm;   // (ranks of a communicator must move together)
+    const icp_params prm = c->loop.H.prm;
+    const long long steps_before = c->loop.steps;
+    c->rows_timed_out = false;
+    int k = 0, d = 0;
+    int rc = loop_run_inner(c, max_steps, &k, &d);
+    if (rc == ICP_ERR_HIP && c->rows_timed_out && can_redo) {
+        const std::string first = g_last_error;
+        if (c->trace) std::fprintf(stderr, "[icp trace] %s -- running the registration again step-wise\n", first.c_str());
+        c->loop.active = false;
+        c->loop.pending = false;
+        c->idx_valid = false;
+        rc = redo_stepwise(c, prm, steps_before + (long long)max_steps, &d);
+        if (rc == ICP_OK) {
+            c->recoveries += 1;
+            k = (int)std::max<long long>(0, c->loop.steps - steps_before);
+        } else {
+            g_last_error = first + " [the step-wise re-run failed as well: " + g_last_error + "]";
+        }
+    }
+    if (rc != ICP_OK) return rc;
+    if (steps_done) *steps_done = k;
+    if (done) *done = d;
+    return ICP_OK;
+}
+
+int icp_recoveries(icp_ctx* c) { return c ? c->recoveries : ICP_ERR_INVALID; }
+
+static int loop_run_inner(icp_ctx* c, int max_steps, int* k_out, int* d_out)
+{
     int d = c->loop.active && c->loop.H.done ? 1 : 0, k = 0;
     while (!d && k < max_steps) {
         if (can_reside(c)) {
@@ -1849,7 +1941,17 @@ int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
             if (int rc = icp_loop_enqueue(c)) return rc;
         if (k + 1 < max_steps && can_arm(c))
             if (int rc = loop_arm(c)) return rc;
-        if (int rc = icp_loop_complete(c, &d)) { loop_withdraw_armed(c); return rc; }
+        if (int rc = icp_loop_complete(c, &d)) {
+            loop_withdraw_armed(c);
+            // (as after a failed resident pass: nothing half-transformed is offered to the caller)
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipGetLastError();
+            c->moving_is_pristine = true;
+            c->idx_valid = false;
+            c->loop.active = false;
+            c->loop.pending = false;
+            return rc;
+        }
         if (c->loop.armed) {
             // (a host that comes back too late may not publish any more: the waiting kernel may have given up -- it is
             // withdrawn, which is consistent either way, and the pass is launched afresh)
@@ -1863,8 +1965,8 @@ int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
         }
         ++k;
     }
-    if (steps_done) *steps_done = k;
-    if (done) *done = d;
+    *k_out = k;
+    *d_out = d;
     return ICP_OK;
 }
 

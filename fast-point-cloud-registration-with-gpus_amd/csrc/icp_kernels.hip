@@ -109,15 +109,21 @@ __device__ __forceinline__ void block_sum_store(const double (&acc)[NACC], doubl
 // ------------------------------------------------------------------------------------------------
 // layout conversion
 // ------------------------------------------------------------------------------------------------
+// `nonfinite` (pinned host memory, or NULL): counts the points with a NaN or an infinite coordinate -- icp_set_* refuse such a
+// cloud (include/icp_mi355x.h).  Written only when there is something to count.
 template <typename F>
-__global__ void aos_to_soa_kernel(const F* __restrict__ aos, int n, int n_pad, F* __restrict__ soa)
+__global__ void aos_to_soa_kernel(const F* __restrict__ aos, int n, int n_pad, F* __restrict__ soa, unsigned int* nonfinite)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
     const int s = i < n ? i : n - 1;  // padding replicates the last real point
-    soa[i] = aos[3 * (size_t)s + 0];
-    soa[(size_t)n_pad + i] = aos[3 * (size_t)s + 1];
-    soa[2 * (size_t)n_pad + i] = aos[3 * (size_t)s + 2];
+    const F x = aos[3 * (size_t)s + 0], y = aos[3 * (size_t)s + 1], z = aos[3 * (size_t)s + 2];
+    soa[i] = x;
+    soa[(size_t)n_pad + i] = y;
+    soa[2 * (size_t)n_pad + i] = z;
+    // (x - x is 0 for every finite x, NaN for NaN and for +-inf)
+    if (nonfinite != nullptr && i < n && !((x - x) == F(0) && (y - y) == F(0) && (z - z) == F(0)))
+        __hip_atomic_fetch_add(nonfinite, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <typename F>
@@ -4740,16 +4746,16 @@ hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_
     return hipGetLastError();
 }
 
-hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st)
+hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st, unsigned int* nonfinite)
 {
     if (n <= 0) return hipSuccess;
     const int blocks = (n_pad + 255) / 256;
     if (precision == ICP_F64)
         hipLaunchKernelGGL((aos_to_soa_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)aos, n, n_pad,
-                           (double*)soa);
+                           (double*)soa, nonfinite);
     else
         hipLaunchKernelGGL((aos_to_soa_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)aos, n, n_pad,
-                           (float*)soa);
+                           (float*)soa, nonfinite);
     return hipGetLastError();
 }
 

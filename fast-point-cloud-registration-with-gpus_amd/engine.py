@@ -256,6 +256,10 @@ class Context:
         capi.check(self._lib.icp_loop_run(self._h, int(max_steps), C.byref(k), C.byref(d)), "icp_loop_run")
         return k.value, bool(d.value)
 
+    def recoveries(self):
+        """registrations this context finished step-wise after a resident / armed pass never delivered its rows"""
+        return int(self._lib.icp_recoveries(self._h))
+
     def loop_state(self):
         it, ps = C.c_int(0), C.c_int(0)
         err = np.zeros(self._max_iter + 1, dtype=np.float64)

@@ -15,6 +15,11 @@
  *     distance (dx*dx + dy*dy) + dz*dz with every operation rounded separately (no FMA), the
  *     LOWEST model index wins ties, every idx[i] is always written.
  *   - rotation matrices are row-major 3x3 (R maps moving -> model), transforms row-major 4x4.
+ *   - non-finite input: a cloud (or normal set) with a NaN or an infinite coordinate is REFUSED -- icp_set_model,
+ *     icp_set_moving, icp_set_model_normals and everything built on them (icp_nn_match_*, icp_point_to_*) return
+ *     ICP_ERR_INVALID and the context keeps no such cloud.  The reference has no usable answer for such input:
+ *     src/ICP_CPU.c:232 (`c == 0 || d < best`) leaves a NaN point at index 0, after which its centroid sums
+ *     (:342-366) make the whole transform NaN.
  *   - a context is bound to one HIP device; calls on one context are not re-entrant, distinct
  *     contexts are independent.  Every device entry point fails with ICP_ERR_NO_DEVICE when no
  *     gfx950 device is usable -- there is no CPU fallback.
@@ -183,6 +188,13 @@ int icp_loop_complete(icp_ctx* ctx, int* done);
 /* up to max_steps x (enqueue + complete) without returning to the caller in between (single GPU, or a
  * communicator attached with icp_comm_init); stops early when the loop ends */
 int icp_loop_run(icp_ctx* ctx, int max_steps, int* steps_done, int* done);
+/* A pass of icp_loop_run's resident / armed conversation that never delivers its rows (a lost message, blocks that another
+ * process kept off the machine) does not end the registration when the loop started from the cloud icp_set_moving uploaded
+ * (or icp_reset_moving restored) and no communicator is attached: the kernel is withdrawn and the same registration is run
+ * again from the copy with plain launches, one per pass -- every loop form yields the same bits.  ICP_ERR_HIP is returned
+ * only if that fails as well.  icp_recoveries: how often this context has done so (the reference's loops,
+ * src/ICP_point_to_point.cu:308-421, are plain launches throughout and have nothing to recover from). */
+int icp_recoveries(icp_ctx* ctx);
 /* current state: iterations so far, error series (count doubles), composed transform */
 int icp_loop_state(icp_ctx* ctx, int* iterations, int* passes, double* err, int err_cap, double* T16);
 /* summed hipEvent time and count of the matching-kernel launches timed since icp_set_profiling was last called

@@ -657,10 +657,9 @@ def test_largest_clouds_that_stay_resident(ctx, pkg, orc, width):
     assert ctx.nn_launch_info()["threads"] == 512
 
 
-def test_two_ranks_one_node_local_communicator(pkg, orc, golden):
-    """two processes, each with a shard of the hall scan and its own resident kernel (both on cuda:0 here), meet once per
-    iteration in shared host memory (icp_comm_init_local): both ranks end with the same bits, and with the run of one
-    rank holding the whole cloud up to the association of the fp64 sums"""
+def _two_ranks_on_one_device(pkg, golden, metric, dtype, env=None, max_iter=100, tol=1e-6):
+    """two processes on cuda:0, each with a shard of the hall scan, meeting once per iteration in shared host memory
+    (icp_comm_init_local); returns what each rank ended with"""
     import subprocess, sys, json
     code = (
         "import sys, os, json, numpy as np\n"
@@ -668,32 +667,106 @@ def test_two_ranks_one_node_local_communicator(pkg, orc, golden):
         "from __graft_entry__ import load_package\n"
         "import oracle_lib\n"
         "pkg = load_package(); orc = oracle_lib.Oracle()\n"
-        "rank, world, idh = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]\n"
+        "rank, world, idh, metric, dt = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), np.dtype(sys.argv[5])\n"
         f"P, Q = orc.hall_clouds({golden!r})\n"
+        "P, Q = P.astype(dt), Q.astype(dt)\n"
         "Ps, begin = pkg.distributed.shard(P, rank, world)\n"
         "with pkg.Context(0) as ctx:\n"
         "    ctx.set_model(Q); ctx.set_moving(Ps)\n"
+        "    nrm = ctx.estimate_normals() if metric == pkg.ICP_POINT_TO_PLANE else None\n"
         "    ctx.comm_init_local(bytes.fromhex(idh), rank, world)\n"
-        "    ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=100, tol=1e-6)\n"
+        f"    ctx.loop_begin(metric, max_iter={max_iter}, tol={tol})\n"
         "    done = False\n"
         "    while not done:\n"
         "        _, done = ctx.loop_run(1 << 20)\n"
         "    st = ctx.loop_state(); idx = ctx.loop_indices()\n"
         "    ctx.comm_destroy()\n"
-        "print(json.dumps(dict(it=st['iterations'], T=st['T'].tolist(), err=st['err'].tolist(), begin=int(begin), idx=idx.tolist())))\n")
+        "print(json.dumps(dict(it=st['iterations'], T=st['T'].tolist(), err=st['err'].tolist(), begin=int(begin), idx=idx.tolist(),\n"
+        "                      nrm=None if nrm is None else nrm.tolist())))\n")
     idh = pkg.Context.comm_random_id().hex()
-    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", idh], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", idh, str(metric), np.dtype(dtype).name], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=dict(os.environ, **(env or {}))) for r in range(2)]
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
     got = [json.loads(o.strip().splitlines()[-1]) for o, _ in outs]
-    assert got[0]["it"] == got[1]["it"] and got[0]["T"] == got[1]["T"] and got[0]["err"] == got[1]["err"]
+    assert got[0]["it"] == got[1]["it"] and got[0]["T"] == got[1]["T"] and got[0]["err"] == got[1]["err"]   # both ranks: the same bits
+    return got
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_two_ranks_one_node_local_communicator(pkg, orc, golden, resident):
+    """two ranks with a shard of the hall scan each, both on cuda:0: both end with the same bits, and with the run of one rank
+    holding the whole cloud up to the association of the fp64 sums.  Ranks that share a DEVICE run one launch per pass by
+    default (two resident kernels need not fit the machine together: the circular wait of icp_api.cpp, can_reside);
+    ICP_SHARED_DEVICE_RESIDENT=1 -- two hall-sized shards do fit -- keeps each rank's resident kernel, the form two ranks on
+    two devices run"""
+    got = _two_ranks_on_one_device(pkg, golden, pkg.ICP_POINT_TO_POINT, np.float32, {"ICP_SHARED_DEVICE_RESIDENT": "1"} if resident else None)
     P, Q = orc.hall_clouds(golden)
     want = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
     assert_same_run(got[0]["it"], np.array(got[0]["err"]), np.array(got[0]["T"]), want, 1e-6, fp32=True)
     if got[0]["it"] == want["iterations"]:
         assert np.array_equal(np.concatenate([got[0]["idx"], got[1]["idx"]]), want["idx"])
+
+
+def test_two_ranks_fp64_against_the_cpu_path(pkg, orc, golden):
+    """ICP_F64 sharded over two ranks (src/ICP_CPU.c:217-271 is the comparator: tol 1e-5, MAX_ITER 200).  Alone, each rank's
+    fp64 kernel would be resident with one 16-wave block on every CU it uses -- two of those on one device is the case
+    the advisor named: by default neither resides, and the registration completes"""
+    got = _two_ranks_on_one_device(pkg, golden, pkg.ICP_POINT_TO_POINT, np.float64, max_iter=200, tol=1e-5)
+    P, Q = orc.hall_clouds(golden)
+    want = orc.icp_p2p(P.astype(np.float64), Q.astype(np.float64), 200, 1e-5)
+    assert got[0]["it"] == want["iterations"]
+    assert np.abs(np.array(got[0]["err"]) - want["err"]).max() < 1e-9
+    assert rel(np.array(got[0]["T"]), want["T"]) < 1e-9
+    assert np.array_equal(np.concatenate([got[0]["idx"], got[1]["idx"]]), want["idx"])
+
+
+def test_two_ranks_point_to_plane(pkg, orc, golden):
+    """the 28-sum point-to-plane vector through the node communicator (src/ICP_point_to_plane.cu:517-631), two ranks, against
+    the oracle run on the whole cloud with the normals the device estimated"""
+    got = _two_ranks_on_one_device(pkg, golden, pkg.ICP_POINT_TO_PLANE, np.float32, max_iter=50, tol=1e-6)
+    P, Q = orc.hall_clouds(golden)
+    assert got[0]["nrm"] == got[1]["nrm"]
+    nrm = np.array(got[0]["nrm"], dtype=np.float32)
+    want = orc.icp_p2plane_f32x(P, Q, nrm, 50, 1e-6)
+    n = min(len(got[0]["err"]), len(want["err"]))
+    assert np.abs(np.array(got[0]["err"])[:n] - want["err"][:n]).max() < TOL_E
+    if got[0]["it"] == want["iterations"]:
+        assert rel(np.array(got[0]["T"]), want["T"]) < TOL_T
+        assert np.array_equal(np.concatenate([got[0]["idx"], got[1]["idx"]]), want["idx"])
+    else:
+        k = min(got[0]["it"], want["iterations"]) + 1
+        dE = abs(want["err"][k] - want["err"][k - 1])
+        assert abs(got[0]["it"] - want["iterations"]) == 1 and (abs(dE - 1e-6) < 5e-7 or abs(want["err"][k] - 1e-6) < 5e-7)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_non_finite_input_is_refused(ctx, pkg, orc, dtype):
+    """include/icp_mi355x.h, "non-finite input": a cloud with a NaN or an infinite coordinate is refused with ICP_ERR_INVALID at
+    every entry point that takes a cloud, the context keeps no such cloud, and stays usable.  (The reference has no usable
+    answer there: src/ICP_CPU.c:232 leaves a NaN point at index 0 and its centroid sums then poison the whole transform.)"""
+    D = pkg.datasets.synthetic_grid(32, dtype)
+    M = pkg.datasets.make_model_cpu(D) if dtype == np.float64 else pkg.datasets.make_model_standard(D)
+    for bad in (np.nan, np.inf, -np.inf):
+        Db, Mb = D.copy(), M.copy()
+        Db[7, 1] = bad
+        Mb[1000, 2] = bad
+        for call in (lambda: ctx.Matching(Db, M), lambda: ctx.Matching(D, Mb), lambda: ctx.point_to_point(Db, M, max_iter=3),
+                     lambda: ctx.point_to_point(D, Mb, max_iter=3), lambda: ctx.set_model(Mb), lambda: ctx.set_moving(Db)):
+            with pytest.raises(pkg.IcpError) as e:
+                call()
+            assert e.value.code == -1 and "non-finite" in str(e.value)
+    ctx.set_model(M)
+    with pytest.raises(pkg.IcpError):
+        ctx.set_moving(Db)
+    with pytest.raises(pkg.IcpError) as e:      # the refused cloud is not resident
+        ctx.nn_match_resident()
+    assert e.value.code == -7
+    with pytest.raises(pkg.IcpError) as e:
+        ctx.set_model_normals(np.full_like(M, np.nan))
+    assert e.value.code == -1
+    assert np.array_equal(ctx.Matching(D, M), orc.nn(D, M))
 
 
 @pytest.mark.parametrize("force", ["1", "0"])

@@ -97,6 +97,38 @@ def test_late_host_withdraws_and_resumes(form, stall):
         assert got[k] == ref[k], k
 
 
+LOST_CODE = """
+import oracle_lib
+orc = oracle_lib.Oracle()
+P, Q = orc.hall_clouds(os.path.join(%r, 'tests', 'golden'))
+with pkg.Context(0) as ctx:
+    r = ctx.point_to_point(P, Q, max_iter=100, tol=1e-6)
+    moved = ctx.get_moving()
+    rec = ctx.recoveries()
+    r2 = ctx.point_to_point(P, Q, max_iter=100, tol=1e-6)       # the context goes on as before
+    rec2 = ctx.recoveries()
+print(json.dumps(dict(it=r.iterations, T=r.T.tolist(), err=r.err.tolist(), sec=r.seconds_total, rec=rec, rec2=rec2, sec2=r2.seconds_total, T2=r2.T.tolist(),
+                      idx=int(np.bitwise_xor.reduce(r.idx * np.arange(1, r.idx.size + 1, dtype=np.int64))),
+                      moved=float(np.abs(moved).sum()))))
+""" % ROOT
+
+
+@pytest.mark.parametrize("form", ["resident", "armed"])
+def test_a_pass_that_never_delivers_is_finished_step_wise(form):
+    """ICP_DEBUG_LOSE_MESSAGE: the message of one pass is never posted -- what a block that never sees its message, or blocks
+    kept off the machine, look like from the host.  Round 2 returned ICP_ERR_HIP there.  Now the waiting kernel is withdrawn
+    (its own wall-clock budget ends it) and the registration is run again from the uploaded cloud with plain launches: the
+    caller gets the bits of an undisturbed run, icp_recoveries counts it, and the context keeps working at full speed."""
+    env = {"ICP_RESIDENT": "0"} if form == "armed" else {}
+    ref = _child(LOST_CODE, env)
+    got = _child(LOST_CODE, dict(env, ICP_DEBUG_LOSE_MESSAGE="3"))
+    assert ref["rec"] == 0 and got["rec"] == 1 and got["rec2"] == 1
+    assert got["sec"] > 1.5                                          # (the pass really went missing: the row poll's 2 s)
+    assert got["sec2"] < 0.1 and got["T2"] == ref["T"]
+    for k in ("it", "T", "err", "idx", "moved"):
+        assert got[k] == ref[k], k
+
+
 # ---------------------------------------------------------------------------------------------------
 # executed-work counters (the roofline of the pruned search is about EXECUTED arithmetic)
 # ---------------------------------------------------------------------------------------------------
