@@ -298,6 +298,7 @@ struct icp_ctx {
     int debug_stall_pass = -1;
     double debug_stall_s = 0.0;
     int debug_lose_pass = -1;          // test hook (ICP_DEBUG_LOSE_MESSAGE=pass): the message of that pass is never posted, once
+    int moving_group = 0;              // group size the moving cloud's order was judged on (0: not judged)
     bool moving_untouched = false;     // c->P (or the pristine copy standing in for it) still holds what icp_set_moving uploaded
     bool rows_timed_out = false;       // the last failure of icp_loop_complete was a pass that never delivered its rows
     int recoveries = 0;                // registrations finished step-wise after such a time-out (icp_recoveries)
@@ -326,6 +327,8 @@ struct icp_ctx {
     LoopState loop;
 };
 
+extern "C++" __attribute__((visibility("hidden"))) int decide_moving_order(icp_ctx* c, const void* P_soa, int grp);   // (below: it needs the prep helpers)
+
 namespace {
 
 ScopedPin::ScopedPin(const icp_ctx* c)
@@ -352,6 +355,10 @@ int ensure_work_buffers(icp_ctx* c)
     const icp::NNPlan before = c->plan;
     c->plan = icp::nn_plan(c->n, c->m, c->prec, c->num_cus);
     const icp::NNPlan& pl = c->plan;
+    // the moving cloud's order was judged when it was uploaded, possibly before the model was known: now that the plan is
+    // fixed, judge it again if the kernel works on groups of another size than the one assumed then
+    if (c->prec == ICP_F32 && c->have_moving && c->n > 128 && pl.sparse && c->moving_group != 0 && c->moving_group != (pl.row == 64 ? 64 : 128) && c->P0.p)
+        if (int rc = decide_moving_order(c, c->P0.p, pl.row == 64 ? 64 : 128)) return rc;
     if (before.n_pad != pl.n_pad || before.m_pad != pl.m_pad) c->resident_refused = false;  // another geometry: ask again
     if (before.n_pad != pl.n_pad || before.blocks_x != pl.blocks_x) c->rows_format = -1;     // (rows that were not in use keep old tags: wiped before the next launch)
     const size_t es = icp::elem_size(c->prec);
@@ -963,24 +970,33 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
         HIP_TRY(hipMemcpyAsync(c->P0.p, c->P.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     }
     c->moving_sorted = false;
+    c->moving_group = 0;
     if (precision == ICP_F32 && n > 128) {
-        const int n_pad = icp::pad_moving(n);
-        icp::PrepBuffers pb{};
-        if (int rc = prep_buffers(c, n, pb)) return rc;
-        icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
-        // (judged on the groups the matching kernel will work on: rows of 64 points for a cloud that cannot fill the machine
-        // with rows of 128 -- icp_kernels.hip, nn_plan)
-        const int grp = (n_pad / 128 <= c->num_cus) ? 64 : 128;
-        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->P.p, n, n_pad, grp, 0, (int32_t*)c->prep_perm.p, small->totals, c->stream));
-        if (int rc = morton_decision(c, n, grp, 0, &c->moving_sorted, nullptr)) return rc;
-        if (c->moving_sorted) {
-            HIP_TRY(c->Pperm.ensure((size_t)n_pad * sizeof(int32_t)));
-            HIP_TRY(icp::launch_slot_map((const int32_t*)c->prep_perm.p, n, n_pad, (int32_t*)c->Pperm.p, c->stream));
-        }
+        // judged on the groups the matching kernel will work on (rows of 64 or of 128 points: nn_plan's rule, overrides
+        // included); with no model resident yet the plan assumes one of the moving cloud's size -- ensure_work_buffers looks again
+        const icp::NNPlan guess = icp::nn_plan(n, c->have_model && c->m > 0 ? c->m : n, precision, c->num_cus);
+        if (int rc = decide_moving_order(c, c->P.p, (guess.sparse && guess.row == 64) ? 64 : 128)) return rc;
     }
     c->have_moving = true;
     c->moving_is_pristine = false;
     c->moving_untouched = true;
+    return ICP_OK;
+}
+
+// Morton order or the given one for the moving cloud's slots ("spatial order"): decided on groups of `grp`
+extern "C++" int decide_moving_order(icp_ctx* c, const void* P_soa, int grp)
+{
+    const int n = c->n, n_pad = icp::pad_moving(n);
+    icp::PrepBuffers pb{};
+    if (int rc = prep_buffers(c, n, pb)) return rc;
+    icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
+    HIP_TRY(icp::launch_morton_order(pb, (const float*)P_soa, n, n_pad, grp, 0, (int32_t*)c->prep_perm.p, small->totals, c->stream));
+    if (int rc = morton_decision(c, n, grp, 0, &c->moving_sorted, nullptr)) return rc;
+    if (c->moving_sorted) {
+        HIP_TRY(c->Pperm.ensure((size_t)n_pad * sizeof(int32_t)));
+        HIP_TRY(icp::launch_slot_map((const int32_t*)c->prep_perm.p, n, n_pad, (int32_t*)c->Pperm.p, c->stream));
+    }
+    c->moving_group = grp;
     return ICP_OK;
 }
 

@@ -4523,9 +4523,12 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
                     const unsigned long long k = (*opt->share_cold_seq)++;
                     fuse.share_prev = cold + ((k + 1) % 2) * R;
                     fuse.share_cur2 = cold + (k % 2) * R;
-                    // (zeroed by block 0 as it starts, long before any block has a list to count: where every launch is a first pass --
-                    // resident kernels, one per registration -- nothing else would, and the counts of all registrations would pile up)
-                    fuse.share_zero2 = fuse.share_cur2;
+                    // The array this launch adds to is zeroed on the stream, ahead of the launch: where every launch is a first pass
+                    // (resident kernels, one per registration) no ordinary pass in between would do it, and the counts of all
+                    // registrations would pile up.  (Not by a block of the launch itself: nothing orders block 0's stores before
+                    // another block's adds, and lost counts would make the roles -- and the timings -- differ from run to run.)
+                    if (hipMemsetAsync(fuse.share_cur2, 0, R * sizeof(unsigned int), st) != hipSuccess) return hipErrorInvalidValue;
+                    fuse.share_zero2 = nullptr;
                 } else {
                     fuse.share_zero2 = cold + (*opt->share_cold_seq % 2) * R;
                 }
