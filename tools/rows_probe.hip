@@ -35,6 +35,49 @@ __global__ void answer(const unsigned int* mb, double* rows, double* errs, int s
     }
 }
 
+// Device-side combine (round 3): the blocks of a group leave their rows in DEVICE memory (agent-scope stores,
+// drained), draw a ticket on the group's counter, and the last arriver adds the group's rows in FIXED member order (the sums do
+// not depend on who came last) and sends ONE row to the host.  groups = 8: group g = the blocks b with b % 8 == g (one XCD's
+// blocks when workgroups are dealt to the XCDs round-robin) or b / (blocks / 8) (contiguous).  The host ingests 8 rows.
+__global__ void answer_combine(const unsigned int* mb, double* dev_rows, unsigned int* tickets, double* host_rows, int groups, int by_xcd, int rounds)
+{
+    const int lane = threadIdx.x;
+    const int per = gridDim.x / groups;
+    const int g = by_xcd ? (int)blockIdx.x % groups : (int)blockIdx.x / per;
+    const int member = by_xcd ? (int)blockIdx.x / groups : (int)blockIdx.x % per;
+    double* row = dev_rows + (size_t)blockIdx.x * 16;
+    for (int i = 1; i <= rounds; ++i) {
+        unsigned int word = 0;
+        const long long give_up = (long long)wall_clock64() + 200000000ll;
+        for (unsigned int spins = 1;; ++spins) {
+            word = __hip_atomic_load(mb + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned int)__builtin_amdgcn_readlane((int)word, 7) == (unsigned int)i && (unsigned int)__builtin_amdgcn_readlane((int)word, 14) == (unsigned int)i) break;
+            if ((spins & 63u) == 0u && (long long)wall_clock64() > give_up) return;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (lane < 16) __hip_atomic_store(&row[lane], (double)(blockIdx.x + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(&tickets[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (ticket != (unsigned int)(i * per - 1)) continue;     // (the counter runs on: round i ends at i * per)
+        // the group's last arriver: lane l adds slot l % 16 of the members l / 16, l / 16 + 4, ... in that order; then the four
+        // partial sums of a slot are added in lane order -- the same order whoever closes the group
+        double sum = 0.0;
+        for (int m = lane >> 4; m < per; m += 4) {
+            const int b = by_xcd ? m * groups + g : g * per + m;
+            sum += __hip_atomic_load(&dev_rows[(size_t)b * 16 + (lane & 15)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sum += __shfl_down(sum, 32, 64);
+        sum += __shfl_down(sum, 16, 64);
+        double* out = host_rows + (size_t)g * 16;
+        if (lane >= 1 && lane < 16) __hip_atomic_store(&out[lane], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&out[0], (double)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        (void)member;
+    }
+}
+
 __attribute__((target("avx"))) static void post(unsigned int* mb, unsigned int tag)
 {
     alignas(32) unsigned int line[16] = {0};
@@ -107,10 +150,64 @@ static int run(unsigned int* mb, int blocks, int stride, int tag_slot, int nslot
     return 0;
 }
 
-int main()
+static int run_combine(unsigned int* mb, int blocks, int groups, int by_xcd, const char* name)
+{
+    const int rounds = 3000;
+    double *host_rows = nullptr, *dev_rows = nullptr;
+    unsigned int* tickets = nullptr;
+    CK(hipHostMalloc((void**)&host_rows, (size_t)groups * 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    CK(hipMalloc((void**)&dev_rows, (size_t)blocks * 16 * sizeof(double)));
+    CK(hipMalloc((void**)&tickets, 64 * sizeof(unsigned int)));
+    CK(hipMemset(tickets, 0, 64 * sizeof(unsigned int)));
+    std::memset(host_rows, 0, (size_t)groups * 16 * sizeof(double));
+    std::memset(mb, 0, 64); _mm_sfence();
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipLaunchKernelGGL(answer_combine, dim3(blocks), dim3(64), 0, st, mb, dev_rows, tickets, host_rows, groups, by_xcd, rounds);
+    CK(hipGetLastError());
+    std::vector<double> rt;
+    double sink = 0, want = 0;
+    for (int b = 0; b < blocks; ++b) want += (double)(b + 1);
+    for (int i = 1; i <= rounds; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        post(mb, (unsigned int)i);
+        double mom[16] = {0};
+        for (int g = 0; g < groups; ++g) {
+            const volatile double* tg = host_rows + (size_t)g * 16;
+            while (*tg != (double)i)
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) { std::printf("%s: timeout round %d group %d\n", name, i, g); return 1; }
+            const double* row = host_rows + (size_t)g * 16;
+            for (int k = 1; k < 16; ++k) mom[k] += row[k];
+        }
+        const double t1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (mom[1] != want) { std::printf("%s: wrong sum %g, expected %g (round %d)\n", name, mom[1], want, i); return 1; }
+        sink += mom[1];
+        if (i > rounds / 3) rt.push_back(1e6 * t1);
+    }
+    CK(hipStreamSynchronize(st));
+    std::sort(rt.begin(), rt.end());
+    std::printf("%-46s blocks %4d: all sums on the host after %5.2f us (median; p90 %5.2f)  [%g]\n", name, blocks, rt[rt.size() / 2], rt[rt.size() * 9 / 10], sink > 0 ? 0.0 : 1.0);
+    CK(hipStreamDestroy(st)); CK(hipHostFree(host_rows)); CK(hipFree(dev_rows)); CK(hipFree(tickets));
+    return 0;
+}
+
+int main(int argc, char** argv)
 {
     unsigned int* mb = nullptr;
     CK(hipExtMallocWithFlags((void**)&mb, 256, hipDeviceMallocFinegrained));
+    if (argc > 1 && std::strcmp(argv[1], "combine") == 0) {
+        // the device-side combine against the host's own ingest of every row (the shipped form: compact rows, sweep)
+        for (int rep = 0; rep < 2; ++rep)
+            for (int blocks : {128, 256}) {
+                g_mode = 2;
+                run(mb, blocks, 16, 0, 16, 0, "rows of 16 to the host, sweep (shipped form)");
+                run_combine(mb, blocks, 8, 1, "combine on the device: 8 groups, b % 8 (per XCD)");
+                run_combine(mb, blocks, 8, 0, "combine on the device: 8 groups, contiguous");
+                run_combine(mb, blocks, 16, 1, "combine on the device: 16 groups, b % 16");
+                run_combine(mb, blocks, 4, 1, "combine on the device: 4 groups, b % 4");
+                run_combine(mb, blocks, 1, 0, "combine on the device: 1 group");
+            }
+        return 0;
+    }
     for (g_mode = 1; g_mode <= 2; ++g_mode)
         for (int blocks : {128, 256}) {
             run(mb, blocks, 16, 0, 16, 0, g_mode == 1 ? "rows of 16, next 4 tag lines prefetched" : "rows of 16, sweep over missing tags then add");
