@@ -298,6 +298,7 @@ struct icp_ctx {
     int debug_stall_pass = -1;
     double debug_stall_s = 0.0;
     int debug_lose_pass = -1;          // test hook (ICP_DEBUG_LOSE_MESSAGE=pass): the message of that pass is never posted, once
+    float sample_spacing2 = 0.f;       // large models: squared spacing of the samples of a sample round (0: unknown / not searched hierarchically)
     int moving_group = 0;              // group size the moving cloud's order was judged on (0: not judged)
     bool moving_untouched = false;     // c->P (or the pristine copy standing in for it) still holds what icp_set_moving uploaded
     bool rows_timed_out = false;       // the last failure of icp_loop_complete was a pass that never delivered its rows
@@ -927,6 +928,28 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         HIP_TRY(c->Qsamp.ensure(icp::model_samples_bytes(m_pad)));
         HIP_TRY(icp::launch_model_samples(view, m_pad, (float*)c->Qsamp.p, c->stream));
         c->have_scan_copy = true;
+        // A model searched through the box hierarchy: how far apart the (at most 2048) samples of a sample round lie -- the
+        // model's extent from its top-level boxes, its area from the extents (a surface in that box), spacing^2 = area / samples.
+        // A seeded pass whose bounds are well above that takes the sample round too (icp_kernels.hip, resample_bound).
+        c->sample_spacing2 = 0.f;
+        if (group2 > 0) {
+            const int n2 = ((m_pad >> 3) + 63) >> 6, n3 = (n2 + 63) >> 6;
+            std::vector<float> top((size_t)n3 * 8);
+            HIP_TRY(hipMemcpyAsync(top.data(), (const float*)c->Qbox.p + (size_t)m_pad + (size_t)n2 * 8, top.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int b = 0; b < n3; ++b)
+                for (int a = 0; a < 3; ++a) {
+                    const float l = top[(size_t)b * 8 + a], h = top[(size_t)b * 8 + 3 + a];
+                    if (l <= h) { lo[a] = std::min(lo[a], l); hi[a] = std::max(hi[a], h); }
+                }
+            if (lo[0] <= hi[0]) {
+                const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+                const double area = std::sqrt(ex * ey * ex * ey + ey * ez * ey * ez + ex * ez * ex * ez);
+                const int samples = std::min(m_pad / 8, 2048);
+                c->sample_spacing2 = (float)(area / (double)std::max(1, samples));
+            }
+        }
     }
     if (precision == ICP_F64 && m > 0) {
         // fp64 on the sparse structure: the scan copy (exact duplicates of a lower-index point and the padding voided to
@@ -1078,6 +1101,7 @@ static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
     }
     icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
+    o.sample_spacing2 = c->sample_spacing2;
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
     if (c->count_work) o.work = (unsigned long long*)c->work.p;
     if (c->plan.order && c->row_order != nullptr) { o.row_order = c->row_order; o.row_hits = (unsigned int*)c->row_hits.p; }

@@ -398,12 +398,11 @@ __device__ __forceinline__ bool box_may_improve(float lox, float loy, float loz,
     bool needb = false;
 #pragma unroll
     for (int u = 0; u < TP; ++u) {
-        const f2 ax = f2{lox, lox} - px[u], bxx = px[u] - f2{hix, hix};
-        const f2 ay = f2{loy, loy} - py[u], byy = py[u] - f2{hiy, hiy};
-        const f2 az = f2{loz, loz} - pz[u], bzz = pz[u] - f2{hiz, hiz};
-        f2 gx = f2{__builtin_fmaxf(__builtin_fmaxf(ax.x, bxx.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ax.y, bxx.y), 0.f)};
-        f2 gy = f2{__builtin_fmaxf(__builtin_fmaxf(ay.x, byy.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ay.y, byy.y), 0.f)};
-        f2 gz = f2{__builtin_fmaxf(__builtin_fmaxf(az.x, bzz.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(az.y, bzz.y), 0.f)};
+        // g = p - clamp(p, lo, hi): one v_med3 per coordinate and point, one packed subtraction per axis -- |g| is max(lo - p,
+        // p - hi, 0) bit for bit (a difference and its negation round alike), in 9 instructions instead of 12
+        const f2 gx = px[u] - f2{__builtin_amdgcn_fmed3f(px[u].x, lox, hix), __builtin_amdgcn_fmed3f(px[u].y, lox, hix)};
+        const f2 gy = py[u] - f2{__builtin_amdgcn_fmed3f(py[u].x, loy, hiy), __builtin_amdgcn_fmed3f(py[u].y, loy, hiy)};
+        const f2 gz = pz[u] - f2{__builtin_amdgcn_fmed3f(pz[u].x, loz, hiz), __builtin_amdgcn_fmed3f(pz[u].y, loz, hiz)};
         f2 L = (gx * gx + gy * gy) + gz * gz;
         L = L * f2{0.99999905f, 0.99999905f};  // 1 - 2^-20
         if constexpr (LE) needb |= (L.x <= best[2 * u]) | (L.y <= best[2 * u + 1]);
@@ -484,6 +483,7 @@ struct NNFuse {
     const float* Q_gather;   // the unmodified model (Q passed to a CULL kernel has its exact duplicates voided)
     const float* boxes;      // CULL kernels: per 8-point chunk of the scan copy {lo.xyz, hi.xyz, -, -} (or NULL)
     int sample_groups;       // sparse kernel: at most this many groups of 8 samples are used by the cold start (<= 256)
+    float resample_bound;    // hierarchical search: a SEEDED pass whose largest bound exceeds this takes the sample round too (0: never)
     const int32_t* q_perm;   // sparse kernel: the scan copy is spatially sorted; q_perm[sorted j] = model index (NULL: identity)
     const int32_t* p_perm;   // sparse kernel: slot -> moving point handled there (spatially sorted groups; NULL: identity)
     int store_first;         // resident launch reading a pristine copy: pass 0 stores the cloud to P_out even without a transform
@@ -1558,7 +1558,18 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
         // padding lanes never ask for a chunk (their result, "nothing found", is never read)
         best[t] = real[t] ? best[t] : -1.f;
     }
-    if (!have_seeds && fuse.samples != nullptr) {
+    // Seeded, but poorly (hierarchical search): early in a registration of two clouds that are far apart the previous match is a
+    // loose bound -- the 10 M-point pair, pass 2: the matches lie 0.23 away, the true neighbours 0.16, and what a row lists is the
+    // model within sqrt(bound) of its box; it grows with (bound - true distance^2).  A sample of the thinned-out model that lies
+    // within a sample spacing of the foot point brings the bound to within spacing^2 of the truth, for the price of ~16 hits per
+    // wave.  So a seeded pass whose largest bound is well above the sample spacing squared takes the cold start's sample round
+    // first.  The bound is the same in every wave (they hold the same points): the same decision everywhere.
+    bool resample = false;
+    if constexpr (HIER) {
+        if (have_seeds && fuse.samples != nullptr && fuse.resample_bound > 0.f)
+            resample = wave_minmax<true>(__builtin_fmaxf(best[0], best[1])) > fuse.resample_bound;
+    }
+    if ((!have_seeds || resample) && fuse.samples != nullptr) {
         // Cold start: no previous match to seed the bounds, so the block measures its points against a thinned-out
         // model first -- one point per chunk, at most 2048 of them, staged in LDS (over the hit list and the merge
         // scratch, both idle until later), a share per wave -- and every wave starts from the block-wide minimum
@@ -1580,7 +1591,18 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
         for (;;) {   // (one body for both rounds: inlined twice it spilled registers in the sorted-view variant)
             // one round over <= gcap groups spread evenly over the model
             const int gs = (ns8 + gcap - 1) / gcap;            // group stride: <= gcap groups are staged
-            const int ng = (ns8 + gs - 1) / gs;
+            int ng = (ns8 + gs - 1) / gs;
+            if constexpr (HIER) {
+                // a large model: the round's samples one by one, evenly spread (a group of 8 CONSECUTIVE samples is eight
+                // neighbouring chunks -- 256 places, not 2048; with single samples the nearest one lies within
+                // ~0.4 x sqrt(area / 2048) of a point's foot on the model, which is what makes the round worth taking
+                // in a seeded pass too, see `resample`)
+                // (the hierarchy's size class has >= 2^13 chunks; forced onto a small model -- the tests do -- the samples repeat)
+                const int ns = m_pad >> 3, cnt = min(gcap * 8, max(8, ns & ~7)), stride = max(1, ns / cnt);
+                ng = cnt >> 3;
+                for (int a = 0; a < 3; ++a)
+                    for (int i = threadIdx.x; i < cnt; i += NWS * 64) sl[a * SMAX + i] = fuse.samples[(size_t)a * ns_pad + (size_t)i * stride];
+            } else
             for (int v = threadIdx.x; v < ng * 6; v += NWS * 64) {
                 const int gp = v / 6, r = v % 6, a = r >> 1, hh = r & 1;
                 *reinterpret_cast<float4*>(sl + a * SMAX + gp * 8 + hh * 4) =
@@ -1677,6 +1699,20 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     auto scan_batch = [&](const int hb, const int h1) {
             const int mine = (h1 - hb - w + NWS - 1) / NWS;     // this wave's hits in the batch
             const int cnt = mine < HB ? mine : HB;
+            // A list of several batches per wave (a pair that is far apart: thousands of hits per row): the hits are dealt
+            // round-robin, so the chunk that holds a point's nearest neighbour is worked on by ONE wave, and until the round's
+            // exchange the other fifteen go on testing their hits against a bound that no longer holds.  So the waves leave the
+            // minima they have reached in smin[] as they go (LDS atomic min, no barrier) and pick up what the others have left:
+            // every value ever stored there is a distance some wave has MEASURED for that point, i.e. a valid bound whenever it
+            // is read; taken over bumped by an ulp with "no candidate of my own", exactly as at the round's exchange.
+            const bool share_minima = h1 > NWS * HB;
+            if (share_minima && hb != 0) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned int v = smin[lane + t * 64];
+                    if (real[t] && v < 0x7f800000u && v < __float_as_uint(best[t])) { best[t] = __uint_as_float(v + 1u); bj[t] = -1; }
+                }
+            }
             for (int rr = 0; rr < cnt; ++rr) {
                 int stage_reached;
                 if constexpr (PERM) {
@@ -1690,6 +1726,10 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
                     wk_hit[1] += stage_reached >= 1 ? 1u : 0u;
                     wk_hit[2] += stage_reached >= 2 ? 1u : 0u;
                 }
+            }
+            if (share_minima && hb + NWS * HB < h1) {   // (the last batch: the round's exchange, or the merge, follows)
+                if (real[0] && bj[0] >= 0) atomicMin(&smin[lane], __float_as_uint(best[0]));
+                if (real[1] && bj[1] >= 0) atomicMin(&smin[lane + 64], __float_as_uint(best[1]));
             }
             lds_same_wave_order();
     };
@@ -2494,9 +2534,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64(const
             if (rr < cnt) {
                 const float4 b0 = *reinterpret_cast<const float4*>(stage + rr * STG);          // lo.xyz hi.x
                 const float2 b1 = *reinterpret_cast<const float2*>(stage + rr * STG + 4);      // hi.yz
-                const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - x, x - b0.w), 0.f);
-                const float gy = __builtin_fmaxf(__builtin_fmaxf(b0.y - y, y - b1.x), 0.f);
-                const float gz = __builtin_fmaxf(__builtin_fmaxf(b0.z - z, z - b1.y), 0.f);
+                // (g = p - clamp(p, lo, hi), as box_may_improve: a v_med3 and a subtraction per axis)
+                const float gx = x - __builtin_amdgcn_fmed3f(x, b0.x, b0.w);
+                const float gy = y - __builtin_amdgcn_fmed3f(y, b0.y, b1.x);
+                const float gz = z - __builtin_amdgcn_fmed3f(z, b0.z, b1.y);
                 const float L = ((gx * gx + gy * gy) + gz * gz) * 0.99999905f;   // 1 - 2^-20, as box_may_improve
                 if (__builtin_amdgcn_ballot_w64(L <= best) != 0ull) alive |= 1u << rr;   // (ties pass: the hits are unordered)
             }
@@ -4128,6 +4169,13 @@ template <> struct NNCfg<double> { static constexpr int T = 2; static constexpr 
 
 // tuning knobs (read once): ICP_NN_T = points per lane {1,2,4,8}, ICP_NN_SPLITS = forced segment
 // count, ICP_NN_BLOCKS_PER_CU = occupancy target used to derive the segment count.
+static float env_float(const char* name, float dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return (float)atof(v);
+}
+
 static int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
@@ -4426,6 +4474,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         // pass on the hall scan, where a few blocks take the full round without gaining from it; 2048 on large models
         static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 0);
         fuse.sample_groups = env_sgroups > 0 ? env_sgroups : (pl.m_pad <= 32768 ? 64 : 256);
+        fuse.resample_bound = (opt->sample_spacing2 > 0.f && pl.hier) ? opt->sample_spacing2 * env_float("ICP_NN_RESAMPLE", 2.0f) : 0.f;
         static const int env_passes = env_int("ICP_NN_PASSES", 0);
         // seeded: few hits, long rounds; cold: short rounds so that the exchanged minima start pruning early
         static const int env_waves = env_int("ICP_NN_WAVES", 0);
