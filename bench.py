@@ -295,7 +295,8 @@ class Bunny(Workload):
     data = "tests/golden/bunny_xyz_f32.bin (the reference's Bunny.csv as float32) and its moved copy"
     workload = "Bunny.csv point-to-point ICP (BASELINE configs[1]), one replica per rank"
     kernel = ("nn_match_sparse<1, ..., NWS = 8> (rows of 128 points, 8-wave blocks, shared rows: a grid of 2 x CUs blocks, the spare "
-              "ones dealt to the heaviest rows; Morton-ordered views of both clouds)")
+              "ones dealt to the heaviest rows; Morton-ordered views of both clouds; a context's first registration runs one armed "
+              "launch per pass, every later one is a single launch whose blocks keep the roles the counts of the registration before give them)")
     block_regs = 6
 
     def build(self):
@@ -555,7 +556,6 @@ def roofline_leg(wl, K, passes_full, region, stride):
     pkg, ctx = wl.pkg, wl.ctx
     info = ctx.nn_launch_info()
     n, m = wl.n, wl.m
-    per_pass = wl.name in ("s5", "bunny")     # one launch per matching pass; the others: ONE resident launch per registration
     # (1) the kernel's launches of a fixed block of registrations right after the timed region (K-independent); where the
     #     timed region itself was bracketed by events (every launch of s5, every 7th registration of a long hall run) that
     #     figure comes first
@@ -572,6 +572,7 @@ def roofline_leg(wl, K, passes_full, region, stride):
     prim, prim_src = (region, "timed region") if region else (block, f"block of {wl.block_regs} registrations after the timed region")
     t_launch = 1e-6 * prim["avg_launch_us"]
     ppl = max(1.0, prim["passes_per_launch"])
+    per_pass = ppl < 1.5      # one launch per matching pass (s5); the others: ONE resident launch per registration
     # (2) what the kernel EXECUTES: the same registration once more with the instrumented instantiation (every launch timed,
     #     so that the loop's own counters say how many launches and matching passes it was)
     ctx.set_work_counting(True)
@@ -681,13 +682,10 @@ def leg_main(args, rank, local_rank, world):
     # HIP events around the loop's kernel inside the timed region: s5 -- every launch is a pass of milliseconds; a resident
     # kernel is a whole registration, so every 7th is timed when the region holds many of them (1-2 % of overhead) and a
     # region of a few registrations is not bracketed at all (the two event records and the wait for the kernel's end would
-    # be a tenth of what is being measured); Bunny.csv's launches are armed ahead of their transform, which a timed launch
-    # cannot be: its kernel block follows the region
+    # be a tenth of what is being measured)
     regs_expected = max(1, K // max(1, passes_full))
     if wl.regime == "fixed":
         stride = 1
-    elif wl.name == "bunny":
-        stride = 0
     else:
         stride = 7 if regs_expected >= 70 else 0
     dt, stats, sec1, cnt1, passes1 = timed_steps(wl, ranks, K, stride)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "icp_nn_launch_info_ex": (_i, [_vp, _i, _pi, _pi, _pi, _pi, _pi]),
     "icp_set_work_counting": (_i, [_vp, _i]),
     "icp_recoveries": (_i, [_vp]),
+    "icp_set_exclusive": (_i, [_vp, _i]),
     "icp_get_work_counters": (_i, [_vp, C.POINTER(C.c_uint64), _i]),
     "icp_estimate_normals": (_i, [_vp, _vp, _vp]),
     "icp_point_to_point": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(icp_params), C.POINTER(icp_result)]),

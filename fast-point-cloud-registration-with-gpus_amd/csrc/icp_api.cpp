@@ -245,6 +245,8 @@ struct icp_ctx {
     DevBuf row_hits, order_keys[2], order_vals[2], order_tmp;   // ordered rows (NNPlan::order): hits per row, and the sort that turns them into the next launch's order
     const int32_t* row_order = nullptr;          // ... the order the next launch follows (device; NULL: index order)
     DevBuf seed_pub;                            // ... resident launches: blocks_x x 384 floats, the matches of split rows for their other blocks
+    bool exclusive = false;                     // icp_set_exclusive: the caller owns the device -- rows of 64 points run as 16-wave blocks, one to a CU
+    bool share_auto = true;                     // ... ICP_SHARE_AUTO=0: never resident of its own accord (see share_wants_resident)
     int share_resident_after = -1;              // ... ICP_SHARE_RESIDENT_AFTER=n: a registration runs armed launches for n passes, then one resident kernel (< 0, the default: armed throughout)
     bool model_sorted = false, moving_sorted = false;
     // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
@@ -678,6 +680,7 @@ int icp_create(int device, icp_ctx** out)
     if (const char* v = std::getenv("ICP_ARMED")) c->arm = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1);
     if (const char* v = std::getenv("ICP_SHARE_RESIDENT_AFTER")) c->share_resident_after = std::atoi(v);
+    if (const char* v = std::getenv("ICP_SHARE_AUTO")) c->share_auto = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_TRACE")) { c->trace = v[0] == '1' || v[0] == '2'; c->trace_passes = v[0] == '2'; }
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
@@ -857,6 +860,15 @@ int icp_set_profiling(icp_ctx* c, int enable)
     // the stride counts from here: the first launch after this call is a timed one
     c->nn_launch_count = 0;
     c->resident_launch_count = 0;
+    return ICP_OK;
+}
+
+int icp_set_exclusive(icp_ctx* c, int on)
+{
+    if (int rc = use(c)) return rc;
+    if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
+    if (c->exclusive != (on != 0)) c->resident_refused = false;   // (another kernel variant: the occupancy question is asked again)
+    c->exclusive = on != 0;
     return ICP_OK;
 }
 
@@ -1102,6 +1114,7 @@ static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
     icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
     o.sample_spacing2 = c->sample_spacing2;
+    o.waves64 = c->exclusive ? 16 : 0;
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
     if (c->count_work) o.work = (unsigned long long*)c->work.p;
     if (c->plan.order && c->row_order != nullptr) { o.row_order = c->row_order; o.row_hits = (unsigned int*)c->row_hits.p; }
@@ -1640,8 +1653,13 @@ namespace {
 // of 42 us instead of 24), which is why armed is the default.
 bool share_wants_resident(const icp_ctx* c)
 {
-    return c->plan.share_blocks > 0 && c->resident == 1 && !c->resident_refused && c->share_resident_after >= 0 &&
-           c->loop.H.applied + 1 >= c->share_resident_after;
+    if (!(c->plan.share_blocks > 0 && c->resident == 1 && !c->resident_refused)) return false;
+    // Round 3 default: a context's FIRST registration of a geometry has no counts to deal the roles by -- it runs armed launches,
+    // which adapt within one pass; from the second registration on the counts of the one before are there, and the whole
+    // registration is ONE resident kernel with shared rows (Bunny.csv, registrations repeated in one context: 32.9 -> 30.7 us per
+    // iteration, profiles/r2/r2_03_bunny_shared_rows.txt).  ICP_SHARE_AUTO=0: armed throughout, as in round 2.
+    if (c->share_auto && c->share_cold_seq >= 1 && c->loop.H.applied == 0 && !c->loop.matched) return true;
+    return c->share_resident_after >= 0 && c->loop.H.applied + 1 >= c->share_resident_after;
 }
 
 bool can_arm(icp_ctx* c)

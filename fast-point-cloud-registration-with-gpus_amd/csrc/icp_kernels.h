@@ -113,6 +113,7 @@ struct NNCullInputs {
     const int32_t* seed_idx;
     const void* boxes;  // per 8-point chunk of Q_scan: {lo.xyz, hi.xyz, 0, 0} floats (launch_model_boxes), or NULL
     const void* samples = nullptr;  // one point per chunk of Q_scan (launch_model_samples): the sparse kernel's cold start
+    int waves64 = 0;                // rows of 64 points: 16 = sixteen waves per block where every row has a CU to itself (icp_set_exclusive)
     float sample_spacing2 = 0.f;    // ... the squared spacing of the (<= 2048) samples a round uses, from the model's extent (0: unknown)
     // sparse kernel only: when the model's own order has no locality its scan copy is kept in Morton order instead
     // (boxes and samples then describe THAT copy) with q_perm[sorted j] = model index; likewise the moving points are

@@ -4480,7 +4480,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         static const int env_waves = env_int("ICP_NN_WAVES", 0);
         int cus64 = 0, dev64 = 0;
         if (pl.row == 64 && (hipGetDevice(&dev64) != hipSuccess || hipDeviceGetAttribute(&cus64, hipDeviceAttributeMultiprocessorCount, dev64) != hipSuccess)) cus64 = 256;
-        const int nw64 = (pl.row == 64 && env_waves == 16 && pl.blocks_x <= cus64) ? 16 : R64_NW;
+        const int nw64 = (pl.row == 64 && (env_waves == 16 || opt->waves64 == 16) && pl.blocks_x <= cus64) ? 16 : R64_NW;
         const int max_passes = pl.row == 64 ? SP_HCAP / (nw64 * 64) : pl.hier ? SP_MAX_PASSES : SP_HCAP_FLAT / (((pl.nw == 8 && ta) ? 8 : SP_NW) * 64);
         int passes = env_passes > 0 ? env_passes : ((fuse.seed_idx || fuse.samples) ? max_passes : 1);
         if (passes > max_passes) passes = max_passes;

@@ -79,6 +79,10 @@ class Context:
     def set_stream(self, hip_stream):
         capi.check(self._lib.icp_set_stream(self._h, C.c_void_p(hip_stream or 0)), "icp_set_stream")
 
+    def set_exclusive(self, on=True):
+        """the caller owns the device: hall-sized clouds run 16-wave blocks, one to a CU (same bits, ~4 % faster)"""
+        capi.check(self._lib.icp_set_exclusive(self._h, 1 if on else 0), "icp_set_exclusive")
+
     def set_profiling(self, every_nth=1):
         """time every n-th matching launch of the loop with HIP events (0 / False = off)"""
         capi.check(self._lib.icp_set_profiling(self._h, int(every_nth)), "icp_set_profiling")

@@ -154,6 +154,12 @@ int icp_nn_launch_info_ex(icp_ctx* ctx, int dense, int* splits, int* blocks, int
  *   5 cold-start sample groups scanned (128 x 8 pairs each)   6 (block, pass) pairs   7 ... that applied a transform
  * Timing with counting on is not representative (atomics, extra registers): count in a separate run. */
 #define ICP_WORK_SLOTS 12 /* 8..11: speculative lists entered / that covered the pass / their hits / hits of ordinarily built lists */
+/* The caller owns the device (no other context of this or any other process keeps kernels resident on it): clouds of up to
+ * 16 384 moving points (one row of 64 per CU) then run their rows as 16-wave blocks, one to a CU, instead of 8-wave blocks that
+ * leave room for a second resident context -- hall pair 9.5 -> 9.15 us per iteration (profiles/r2/r2_02_waves_8_vs_16.txt).
+ * The results are the same bits.  Off by default: the library cannot see who else is on the device.  (The reference's
+ * programs own their GPU implicitly, src/ICP_point_to_point.cu:90.) */
+int icp_set_exclusive(icp_ctx* ctx, int on);
 int icp_set_work_counting(icp_ctx* ctx, int enable);
 int icp_get_work_counters(icp_ctx* ctx, uint64_t* out_slots, int reset);
 

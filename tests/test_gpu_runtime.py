@@ -129,6 +129,24 @@ def test_a_pass_that_never_delivers_is_finished_step_wise(form):
         assert got[k] == ref[k], k
 
 
+def test_exclusive_device_gives_the_same_bits(pkg, orc, golden):
+    """icp_set_exclusive(ctx, 1): the caller owns the device, the hall pair's rows of 64 points run as 16-wave blocks (one to a CU,
+    no room left for a second resident context).  Same search, same arithmetic: the same bits, point-to-point and point-to-plane"""
+    P, Q = orc.hall_clouds(golden)
+    with pkg.Context(0) as ctx:
+        a = ctx.point_to_point(P, Q, max_iter=100, tol=1e-6)
+        ctx.set_exclusive(True)
+        b = ctx.point_to_point(P, Q, max_iter=100, tol=1e-6)
+        ctx.set_model(Q); ctx.set_moving(P); ctx.estimate_normals()
+        pb = ctx.point_to_plane(P, Q, max_iter=50, tol=1e-6)
+        ctx.set_exclusive(False)
+        c = ctx.point_to_point(P, Q, max_iter=100, tol=1e-6)
+        pc = ctx.point_to_plane(P, Q, max_iter=50, tol=1e-6)
+    for r in (b, c):
+        assert r.iterations == a.iterations and np.array_equal(r.T, a.T) and np.array_equal(r.err, a.err) and np.array_equal(r.idx, a.idx)
+    assert pb.iterations == pc.iterations and np.array_equal(pb.T, pc.T) and np.array_equal(pb.idx, pc.idx)
+
+
 # ---------------------------------------------------------------------------------------------------
 # executed-work counters (the roofline of the pruned search is about EXECUTED arithmetic)
 # ---------------------------------------------------------------------------------------------------
