@@ -187,17 +187,26 @@ def _hall_pair(pkg, ctx):
 
 class Hall(Workload):
     name = "hall"
-    pmc_kernel = "nn_match_row64<1, false"
+
+    def geometry(self, info):
+        pts, nw = super().geometry(info)
+        return pts, (16 if (self.exclusive and pts == 64 and info["blocks"] <= 256) else nw)
+    pmc_kernel = "nn_match_row64<1, false, false"
     metric_id = "ICP iterations/sec + NN HBM GB/s (% roofline), hall cloud"
     data = ("hall LiDAR scan fixture (tests/golden/hall_ranges_u32.bin, decoded from the reference's Donut_1024x16.csv; "
             "polar->Cartesian by the device kernel)")
     workload = "hall LiDAR scan point-to-point ICP (BASELINE configs[2])"
-    kernel = "nn_match_row64<1> (rows of 64 points, 8 waves per block, point-to-point row tail)"
+    kernel = "nn_match_row64<1> (rows of 64 points, one per lane; 16 waves per block with the device to itself, else 8; point-to-point row tail)"
 
     def build(self):
         self.P, self.Q = _hall_pair(self.pkg, self.ctx)
         self.n, self.m = self.P.shape[0], self.Q.shape[0]
         self.n_global = self.n * self.world
+        # one process per GPU and nothing else on it: the bench owns its device and says so (icp_set_exclusive: the rows of 64
+        # points run as 16-wave blocks, one to a CU; same bits).  Not in the one-device rehearsal, where two ranks share a GPU.
+        self.exclusive = os.environ.get("ICP_BENCH_ONE_DEVICE") != "1" and os.environ.get("ICP_BENCH_EXCLUSIVE", "1") != "0"
+        if self.exclusive:
+            self.ctx.set_exclusive(True)
         self.ctx.set_model(self.Q)
         self.ctx.set_moving(self.P)
 
@@ -241,7 +250,7 @@ class HallPlane(Hall):
     pmc_kernel = "nn_match_row64<2, false"
     metric_id = "ICP iterations/sec, hall cloud, point-to-plane (BASELINE configs[3])"
     workload = "hall LiDAR scan point-to-plane ICP, 6x6 solve on the host (BASELINE configs[3])"
-    kernel = "nn_match_row64<2> (rows of 64 points, 8 waves per block, point-to-plane row tail: 21 + 6 sums)"
+    kernel = "nn_match_row64<2> (rows of 64 points, one per lane; 16 waves per block with the device to itself, else 8; point-to-plane row tail: 21 + 6 sums)"
     max_iter, tol = 50, 1e-6      # src/ICP_point_to_plane.cu
 
     def build(self):
@@ -718,6 +727,8 @@ def leg_main(args, rank, local_rank, world):
             out["config"]["second_registration_of_the_context_us_per_iteration"] = first_us
         if wl.name == "hall_plane":
             out["config"]["normals_on_device_ms"] = 1e3 * wl.normals_s
+        if getattr(wl, "exclusive", False):
+            out["config"]["exclusive_device"] = "icp_set_exclusive(ctx, 1): this process owns its GPU (16-wave blocks, one row of 64 points per CU)"
     if ranks.dist:
         ctx.comm_destroy()     # rank 0 measures its roofline leg alone: no communicator may wait for the others
     if rank == 0:
