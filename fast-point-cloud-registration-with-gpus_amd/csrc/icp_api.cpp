@@ -252,6 +252,7 @@ struct icp_ctx {
     // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
     DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
     struct PrepSmall { float box[4]; double totals[4]; int voided; int pad_; };
+    DevBuf fin_scratch;      // finalize in two stages (many rows): 256 x ICP_NMOM doubles
     DevBuf work;             // icp_set_work_counting: NN_WORK_SLOTS counters of the work the sparse kernel executes
     bool count_work = false;
     DevBuf phase_log;        // ICP_NN_PHASES diagnostic
@@ -325,7 +326,13 @@ struct icp_ctx {
     // it from another XCD keeps reading its stale line (seen as 24 of 128 blocks never receiving the message)
     icp::NNMailbox* relay = nullptr;
     uint64_t mail_seq = 0;
-    bool host_reduce() const { return !comm && mom_dev == (double*)mom_own.p && h_mom_partials != nullptr; }
+    // Who adds up the moment rows: the host, as their tags arrive in pinned memory (no synchronisation, and what armed and
+    // resident launches need) -- or, for clouds of more than kHostRowsMax rows, the device (two-stage finalize, 256 bytes come
+    // back): 78 125 rows of the 10 M-point cloud are 20 MB over PCIe and a pass through them on one core per iteration,
+    // 0.7 ms of 13 (profiles/r3: the library-issued RCCL route, which reduces on the device, was FASTER than the default).
+    static constexpr int kHostRowsMax = 16384;
+    bool host_reduce() const { return !comm && mom_dev == (double*)mom_own.p && h_mom_partials != nullptr && (plan.blocks_x <= host_rows_max || plan.n == 0); }
+    int host_rows_max = kHostRowsMax;   // (ICP_HOST_ROWS_MAX: A/B runs)
     icp::NNPlan plan{};
     LoopState loop;
 };
@@ -681,6 +688,7 @@ int icp_create(int device, icp_ctx** out)
     if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1);
     if (const char* v = std::getenv("ICP_SHARE_RESIDENT_AFTER")) c->share_resident_after = std::atoi(v);
     if (const char* v = std::getenv("ICP_SHARE_AUTO")) c->share_auto = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_HOST_ROWS_MAX")) c->host_rows_max = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("ICP_TRACE")) { c->trace = v[0] == '1' || v[0] == '2'; c->trace_passes = v[0] == '2'; }
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
@@ -723,7 +731,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->work, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->work, &c->fin_scratch, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -1438,8 +1446,9 @@ int icp_loop_enqueue(icp_ctx* c)
         }
     }
     if (!host_reduce) {
+        if (L.mom_blocks > 2048) HIP_TRY(c->fin_scratch.ensure(256 * ICP_NMOM * sizeof(double)));
         HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
-                                     (const double*)c->err_partials.p, L.err_blocks, L.rows_have_err ? 1 : 0, c->stream));
+                                     (const double*)c->err_partials.p, L.err_blocks, L.rows_have_err ? 1 : 0, c->stream, (double*)c->fin_scratch.p));
         if (c->comm) {  // the iteration's one collective: 32 doubles, in place, on the loop's stream
             std::string err;
             if (int rc = icp::comm_allreduce_sum_f64(c->comm, c->mom_dev, ICP_NMOM, c->stream, err)) return fail(rc, err);
@@ -1613,7 +1622,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
         c->prof_nn_launches += 1;
         c->prof_nn_passes += 1;
     }
-    if (c->lcomm && L.host_reduce) {  // the node's ranks exchange their sums (rank order: identical on every rank)
+    if (c->lcomm) {  // the node's ranks exchange their sums (rank order: identical on every rank)
         std::string err;
         // (only the entries the metric uses travel: 19 doubles = 3 cache lines per slot instead of 5)
         const int used = L.H.prm.metric == ICP_POINT_TO_PLANE ? ICP_MOM_B + 6 : ICP_MOM_SQQ + 1;

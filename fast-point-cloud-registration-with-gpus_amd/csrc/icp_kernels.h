@@ -278,7 +278,7 @@ hipError_t launch_transform_error(int precision, void* P_soa, int n, int n_pad, 
                                   int* blocks, hipStream_t st);
 // deterministic fixed-order reduction of the per-block partials into the ICP_NMOM-vector
 hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_blocks, const double* err_partials,
-                           int err_blocks, int rows_have_err /* slot 0 of the rows carries error shares */, hipStream_t st);
+                           int err_blocks, int rows_have_err /* slot 0 of the rows carries error shares */, hipStream_t st, double* scratch = nullptr /* >= 256 x ICP_NMOM doubles: many rows are added in two stages */);
 
 hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st, unsigned int* nonfinite = nullptr);
 hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, void* aos, hipStream_t st);

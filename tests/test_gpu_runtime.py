@@ -265,15 +265,23 @@ def test_bench_sharded_cloud_two_ranks_on_one_device():
     """`bench.py --config s5 --gpus 2` (the moving cloud sharded over the ranks, large-model kernels, rows taken heaviest first),
     rehearsed with both ranks on the one GPU: the library sees that two ranks of its node communicator share a device and arms
     no pass ahead of its transform -- the waiting blocks of one rank would keep the other's pass off the CUs, and with the
-    exchange between the ranks that is a circular wait (a pass missing its last rows, found with exactly this command)"""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env["ICP_BENCH_ONE_DEVICE"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "s5", "--points", "600000", "--gpus", "2", "--steps", "12", "--warmup", "2",
-                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=420)
-    assert out.returncode == 0, out.stderr[-3000:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_moving_points"] == 600000
-    assert d["rms_error_series_head"][1] > d["final_rms_error"] > 0
+    exchange between the ranks that is a circular wait (a pass missing its last rows, found with exactly this command).
+    Run twice: with the rows added up by the host as they arrive, and (ICP_HOST_ROWS_MAX: a cloud of more than 16 384 rows by
+    default) by the device's two-stage finalize with 256 bytes coming back -- the same registration either way."""
+    errs = []
+    for rows_max in (None, "1024"):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env["ICP_BENCH_ONE_DEVICE"] = "1"
+        if rows_max:
+            env["ICP_HOST_ROWS_MAX"] = rows_max
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "s5", "--points", "600000", "--gpus", "2", "--steps", "12", "--warmup", "2",
+                              "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=420)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+        assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_moving_points"] == 600000
+        assert d["rms_error_series_head"][1] > d["final_rms_error"] > 0
+        errs.append(d["final_rms_error"])
+    assert abs(errs[0] - errs[1]) < 1e-12 * errs[0], errs
 
 
 def test_bench_under_torch_distributed_run():
