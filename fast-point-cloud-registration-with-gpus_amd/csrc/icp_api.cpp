@@ -73,6 +73,24 @@ static inline void bar_fence()
 // and carries the tag in its last word, then one fence pushes the line out.  rt may be NULL (commands that carry no
 // transform); seq = 0 clears the mailbox (no tag ever equals 0).
 #if defined(__x86_64__)
+// The compact rows of a pass added up, rows in block order: four 4-double accumulators take a row's sixteen slots at once.
+// Every slot is still the sum of its 256 values in block order, starting from zero -- the bits of the scalar loop -- but the
+// sixteen chains advance together instead of one after the other (hall: 256 rows, once per pass, on the path between the last
+// row's arrival and the next message).  Slot 0 carries the row's tag in its low mantissa bits: masked off as it is loaded.
+__attribute__((target("avx"))) static void add_compact_rows_avx(const double* rows, int count, unsigned long long tag_mask, double (&out)[16])
+{
+    const __m256d keep = _mm256_castsi256_pd(_mm256_set_epi64x(-1ll, -1ll, -1ll, (long long)~tag_mask));
+    __m256d a0 = _mm256_setzero_pd(), a1 = a0, a2 = a0, a3 = a0;
+    for (int b = 0; b < count; ++b) {
+        const double* r = rows + (size_t)b * 16;
+        a0 = _mm256_add_pd(a0, _mm256_and_pd(_mm256_loadu_pd(r), keep));
+        a1 = _mm256_add_pd(a1, _mm256_loadu_pd(r + 4));
+        a2 = _mm256_add_pd(a2, _mm256_loadu_pd(r + 8));
+        a3 = _mm256_add_pd(a3, _mm256_loadu_pd(r + 12));
+    }
+    _mm256_storeu_pd(out, a0); _mm256_storeu_pd(out + 4, a1); _mm256_storeu_pd(out + 8, a2); _mm256_storeu_pd(out + 12, a3);
+}
+
 __attribute__((target("avx"))) static void store_line_avx(uint32_t* dst, const uint32_t* line)
 {
     _mm256_store_si256(reinterpret_cast<__m256i*>(dst), _mm256_load_si256(reinterpret_cast<const __m256i*>(line)));
@@ -303,6 +321,7 @@ struct icp_ctx {
     int debug_lose_pass = -1;          // test hook (ICP_DEBUG_LOSE_MESSAGE=pass): the message of that pass is never posted, once
     float sample_spacing2 = 0.f;       // large models: squared spacing of the samples of a sample round (0: unknown / not searched hierarchically)
     int moving_group = 0;              // group size the moving cloud's order was judged on (0: not judged)
+    std::chrono::steady_clock::time_point posted_at{};   // resident loop: when the pending pass's message went out (the row poll's time-out counts from here)
     bool moving_untouched = false;     // c->P (or the pristine copy standing in for it) still holds what icp_set_moving uploaded
     bool rows_timed_out = false;       // the last failure of icp_loop_complete was a pass that never delivered its rows
     int recoveries = 0;                // registrations finished step-wise after such a time-out (icp_recoveries)
@@ -1369,9 +1388,16 @@ int icp_loop_begin(icp_ctx* c, const icp_params* prm)
     return ICP_OK;
 }
 
+static int loop_enqueue_body(icp_ctx* c);
+
 int icp_loop_enqueue(icp_ctx* c)
 {
     if (int rc = use(c)) return rc;
+    return loop_enqueue_body(c);
+}
+
+static int loop_enqueue_body(icp_ctx* c)
+{
     LoopState& L = c->loop;
     if (!L.active || L.H.done || L.pending) return fail(ICP_ERR_STATE, "enqueue: loop not ready");
     if (int rc = materialize_moving(c)) return rc;
@@ -1477,13 +1503,24 @@ int icp_loop_set_moments_dev(icp_ctx* c, void* dev_ptr)
     return ICP_OK;
 }
 
+static int loop_complete_body(icp_ctx* c, int* done);
+
 int icp_loop_complete(icp_ctx* c, int* done)
 {
     if (int rc = use(c)) return rc;
     ScopedPin pin(c);
+    return loop_complete_body(c, done);
+}
+
+// (icp_loop_run's forms call this once per pass: the device was selected and the thread placed when the call came in --
+// a hipSetDevice and a sched_getcpu per pass are a measurable part of a 9 us iteration)
+static int loop_complete_body(icp_ctx* c, int* done)
+{
     LoopState& L = c->loop;
     if (!L.active || !L.pending) return fail(ICP_ERR_STATE, "complete without enqueue");
-    const auto tr0 = std::chrono::steady_clock::now();
+    // (clock reads cost ~25 ns apiece and there were seven per pass: the ones that only feed ICP_TRACE are taken when it is on)
+    const bool tracing = c->trace || c->trace_passes;
+    const auto tr0 = tracing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point{};
     auto tr1 = tr0;
     if (L.host_reduce) {
         // the kernels wrote their partial rows into mapped pinned memory.  Instead of a stream
@@ -1528,7 +1565,9 @@ int icp_loop_complete(icp_ctx* c, int* done)
         bool polled = false;
         if (L.mom_blocks > 0 && !L.timed_nn && c->poll && L.err_blocks == 0) {
             const double want = tag_value(L.wait_tag);
-            const auto t0 = std::chrono::steady_clock::now();
+            // (the poll's start: what the 2 s time-out counts from; the host got here right after posting the message, whose
+            // time the resident loop has just read -- an armed or plain pass reads the clock itself)
+            const auto t0 = L.live_mailbox != nullptr && !tracing ? c->posted_at : std::chrono::steady_clock::now();
             int b = 0;
             unsigned spins = 0;
             start_sum();
@@ -1539,13 +1578,18 @@ int icp_loop_complete(icp_ctx* c, int* done)
                 // row's second line as soon as its tag is seen, and add the rows up in block order once all are there
                 // (tools/rows_probe.hip: 256 rows 6.6 -> 5.8 us; the order of the additions, and with it every bit of
                 // the sums, is the same as before).
+                // (round 3 tried a LIST of the rows still missing instead of the flags -- a sweep then costs what is missing, not the
+                // row count: no difference on the hall loop, 8.99-9.07 against 8.92-9.04 us per iteration on one box; the tags are
+                // compared as the integers they are)
                 unsigned char seen[1024];
                 std::memset(seen, 0, (size_t)L.mom_blocks);
                 int left = L.mom_blocks;
                 bool first = true;
+                const unsigned long long want_bits = (unsigned long long)want;
+                const volatile unsigned long long* tags = reinterpret_cast<const volatile unsigned long long*>(c->h_mom_partials);
                 while (left > 0) {
                     for (int r = 0; r < L.mom_blocks; ++r) {
-                        if (seen[r] || row_tag(r) != want) continue;
+                        if (seen[r] || (tags[(size_t)r * stride] & kTagMask) != want_bits) continue;
                         seen[r] = 1;
                         --left;
                         __builtin_prefetch(reinterpret_cast<const char*>(c->h_mom_partials + (size_t)r * stride) + 64);
@@ -1558,6 +1602,15 @@ int icp_loop_complete(icp_ctx* c, int* done)
                 }
                 if (left == 0) {
                     std::atomic_thread_fence(std::memory_order_acquire);
+                    static const bool have_avx = __builtin_cpu_supports("avx");
+                    static_assert(icp::NN_CROW == 16, "add_compact_rows_avx takes rows of sixteen doubles");
+                    if (have_avx && c->mail_wide) {   // (ICP_MAILBOX_AVX=0 keeps the scalar loop: the same bits, for the A/B)
+                        double sum[16];
+                        add_compact_rows_avx(c->h_mom_partials, L.mom_blocks, kTagMask, sum);
+                        mom[ICP_MOM_ERR] += sum[0];
+                        for (int k = 1; k < icp::NN_CROW; ++k) mom[ICP_MOM_SP - 1 + k] += sum[k];
+                        b = L.mom_blocks;
+                    } else
                     for (b = 0; b < L.mom_blocks; ++b) add_row(b);
                 }
             } else
@@ -1583,7 +1636,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
                 std::fprintf(stderr, "\n");
             }
         }
-        tr1 = std::chrono::steady_clock::now();
+        if (tracing) tr1 = std::chrono::steady_clock::now();
         if (!polled) {
             // a resident kernel would go on waiting for its next message: withdraw it (under the tag it will wait for)
             if (L.live_mailbox) {
@@ -1611,7 +1664,7 @@ int icp_loop_complete(icp_ctx* c, int* done)
         HIP_TRY(hipStreamSynchronize(c->stream));
         tr1 = std::chrono::steady_clock::now();
     }
-    const auto tr2 = std::chrono::steady_clock::now();
+    const auto tr2 = tracing ? std::chrono::steady_clock::now() : tr1;
     L.pending = false;
     if (L.timed_nn) {
         float ms = 0.f;
@@ -1883,8 +1936,9 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
         L.pending = true;
         ++sent;
         if (c->trace) c->tr_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
-        const auto tc0 = std::chrono::steady_clock::now();
-        rc = icp_loop_complete(c, &d);
+        c->posted_at = tr0;
+        const auto tc0 = c->trace_passes ? std::chrono::steady_clock::now() : tr0;
+        rc = loop_complete_body(c, &d);
         if (c->trace_passes)
             std::fprintf(stderr, "[icp trace] resident pass %d cmd %d: %.2f us from message to reduced rows + solve (row 0 after %.2f us, all rows after %.2f us)\n", sent - 1, cmd,
                          1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count(), 1e6 * c->tr_first_row, 1e6 * c->tr_last_row);
@@ -1953,8 +2007,8 @@ static int redo_stepwise(icp_ctx* c, const icp_params& prm, long long target_ste
     int d = 0;
     int rc = icp_loop_begin(c, &prm);
     while (rc == ICP_OK && !d && c->loop.steps < target_steps) {
-        rc = icp_loop_enqueue(c);
-        if (rc == ICP_OK) rc = icp_loop_complete(c, &d);
+        rc = loop_enqueue_body(c);
+        if (rc == ICP_OK) rc = loop_complete_body(c, &d);
     }
     c->resident = keep_resident;
     c->arm = keep_arm;
@@ -1965,7 +2019,7 @@ static int redo_stepwise(icp_ctx* c, const icp_params& prm, long long target_ste
 int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
 {
     if (max_steps < 0) return fail(ICP_ERR_INVALID, "max_steps < 0");
-    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    if (int rc = use(c)) return rc;
     ScopedPin pin(c);
     const bool can_redo = c->loop.active && c->loop.from_pristine && !c->comm && !c->lcomm;   // (ranks of a communicator must move together)
     const icp_params prm = c->loop.H.prm;
@@ -2005,10 +2059,10 @@ static int loop_run_inner(icp_ctx* c, int max_steps, int* k_out, int* d_out)
             if (!fell_back) continue;
         }
         if (!c->loop.pending)
-            if (int rc = icp_loop_enqueue(c)) return rc;
+            if (int rc = loop_enqueue_body(c)) return rc;
         if (k + 1 < max_steps && can_arm(c))
             if (int rc = loop_arm(c)) return rc;
-        if (int rc = icp_loop_complete(c, &d)) {
+        if (int rc = loop_complete_body(c, &d)) {
             loop_withdraw_armed(c);
             // (as after a failed resident pass: nothing half-transformed is offered to the caller)
             (void)hipStreamSynchronize(c->stream);
