@@ -91,6 +91,20 @@ __attribute__((target("avx"))) static void add_compact_rows_avx(const double* ro
     _mm256_storeu_pd(out, a0); _mm256_storeu_pd(out + 4, a1); _mm256_storeu_pd(out + 8, a2); _mm256_storeu_pd(out + 12, a3);
 }
 
+// the same for rows in the full format (ICP_NMOM = 32 doubles, the last one the row's tag: not a moment -- left out)
+__attribute__((target("avx"))) static void add_full_rows_avx(const double* rows, int count, double (&out)[32])
+{
+    const __m256d keep = _mm256_castsi256_pd(_mm256_set_epi64x(0ll, -1ll, -1ll, -1ll));
+    __m256d a[8];
+    for (int v = 0; v < 8; ++v) a[v] = _mm256_setzero_pd();
+    for (int b = 0; b < count; ++b) {
+        const double* r = rows + (size_t)b * 32;
+        for (int v = 0; v < 7; ++v) a[v] = _mm256_add_pd(a[v], _mm256_loadu_pd(r + 4 * v));
+        a[7] = _mm256_add_pd(a[7], _mm256_and_pd(_mm256_loadu_pd(r + 28), keep));
+    }
+    for (int v = 0; v < 8; ++v) _mm256_storeu_pd(out + 4 * v, a[v]);
+}
+
 __attribute__((target("avx"))) static void store_line_avx(uint32_t* dst, const uint32_t* line)
 {
     _mm256_store_si256(reinterpret_cast<__m256i*>(dst), _mm256_load_si256(reinterpret_cast<const __m256i*>(line)));
@@ -1572,7 +1586,8 @@ static int loop_complete_body(icp_ctx* c, int* done)
             unsigned spins = 0;
             start_sum();
             static const bool sweep_ok = !(std::getenv("ICP_ROW_SWEEP") && std::getenv("ICP_ROW_SWEEP")[0] == '0');   // (A/B runs)
-            if (compact && sweep_ok && L.mom_blocks <= 1024) {
+            static_assert(ICP_NMOM == 32, "add_full_rows_avx takes rows of 32 doubles");
+            if (sweep_ok && L.mom_blocks <= 1024) {
                 // Compact rows: SWEEP over the rows whose tag is still missing -- the cache misses of different rows overlap,
                 // where polling row b to completion before looking at row b + 1 takes them one after the other -- fetch a
                 // row's second line as soon as its tag is seen, and add the rows up in block order once all are there
@@ -1581,18 +1596,22 @@ static int loop_complete_body(icp_ctx* c, int* done)
                 // (round 3 tried a LIST of the rows still missing instead of the flags -- a sweep then costs what is missing, not the
                 // row count: no difference on the hall loop, 8.99-9.07 against 8.92-9.04 us per iteration on one box; the tags are
                 // compared as the integers they are)
+                // Round 3: rows in the full format (point-to-plane, fp64) are swept and added the same way; their tag is a double
+                // of its own in the row's last slot, compared by its bits.
                 unsigned char seen[1024];
                 std::memset(seen, 0, (size_t)L.mom_blocks);
                 int left = L.mom_blocks;
                 bool first = true;
-                const unsigned long long want_bits = (unsigned long long)want;
-                const volatile unsigned long long* tags = reinterpret_cast<const volatile unsigned long long*>(c->h_mom_partials);
+                unsigned long long want_bits = (unsigned long long)want, tag_bits_mask = kTagMask;
+                if (!compact) { std::memcpy(&want_bits, &want, sizeof want_bits); tag_bits_mask = ~0ull; }
+                const volatile unsigned long long* tags = reinterpret_cast<const volatile unsigned long long*>(c->h_mom_partials) + tag_slot;
                 while (left > 0) {
                     for (int r = 0; r < L.mom_blocks; ++r) {
-                        if (seen[r] || (tags[(size_t)r * stride] & kTagMask) != want_bits) continue;
+                        if (seen[r] || (tags[(size_t)r * stride] & tag_bits_mask) != want_bits) continue;
                         seen[r] = 1;
                         --left;
-                        __builtin_prefetch(reinterpret_cast<const char*>(c->h_mom_partials + (size_t)r * stride) + 64);
+                        if (compact) __builtin_prefetch(reinterpret_cast<const char*>(c->h_mom_partials + (size_t)r * stride) + 64);
+                        else for (int l = 0; l < 3; ++l) __builtin_prefetch(reinterpret_cast<const char*>(c->h_mom_partials + (size_t)r * stride) + 64 * l);   // (the tag sits in the row's fourth line)
                         if (first && c->trace_passes) c->tr_first_row = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                         first = false;
                     }
@@ -1604,11 +1623,16 @@ static int loop_complete_body(icp_ctx* c, int* done)
                     std::atomic_thread_fence(std::memory_order_acquire);
                     static const bool have_avx = __builtin_cpu_supports("avx");
                     static_assert(icp::NN_CROW == 16, "add_compact_rows_avx takes rows of sixteen doubles");
-                    if (have_avx && c->mail_wide) {   // (ICP_MAILBOX_AVX=0 keeps the scalar loop: the same bits, for the A/B)
+                    if (have_avx && c->mail_wide && compact) {   // (ICP_MAILBOX_AVX=0 keeps the scalar loop: the same bits, for the A/B)
                         double sum[16];
                         add_compact_rows_avx(c->h_mom_partials, L.mom_blocks, kTagMask, sum);
                         mom[ICP_MOM_ERR] += sum[0];
                         for (int k = 1; k < icp::NN_CROW; ++k) mom[ICP_MOM_SP - 1 + k] += sum[k];
+                        b = L.mom_blocks;
+                    } else if (have_avx && c->mail_wide) {
+                        double sum[32];
+                        add_full_rows_avx(c->h_mom_partials, L.mom_blocks, sum);
+                        for (int k = 0; k < ICP_NMOM - 1; ++k) mom[k] += sum[k];
                         b = L.mom_blocks;
                     } else
                     for (b = 0; b < L.mom_blocks; ++b) add_row(b);
