@@ -2265,7 +2265,7 @@ __device__ __forceinline__ void scan8_min1(const float4 qx0, const float4 qx1, c
 // a CU of its own) halves the hits per wave once more, but such a block fills its CU: nothing else that must be resident --
 // another context's registration, another rank rehearsed on the same device -- fits beside it.
 template <int TAIL, bool DIAG, bool PERM, int NW = R64_NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64(const float* __restrict__ P, int n_pad, const float* __restrict__ Q,
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void nn_match_row64(const float* __restrict__ P, int n_pad, const float* __restrict__ Q,
                                                                  int m_pad, int round_passes, float* __restrict__ part_d,
                                                                  int32_t* __restrict__ part_idx, RT<float> rt_arg, NNFuse fuse, NNTail tail)
 {

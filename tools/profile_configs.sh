@@ -30,7 +30,7 @@ for c in $CFGS; do
 import json
 p = "$O/${T}_pmc_hbm_traffic_$c.json"
 try:
-    d = json.load(open(p)); d["_build"] = "$B"; d["_what"] = "average over the launches of `bench.py --leg main --config $c $PARGS`"
+    d = json.load(open(p)); d["_build"] = "$B"; d["_what"] = "average over the launches of bench.py --leg main --config $c $PARGS"
     json.dump(d, open(p, "w"), indent=1)
 except Exception as e:
     print("pmc json:", e)
