@@ -741,6 +741,23 @@ def test_two_ranks_point_to_plane(pkg, orc, golden):
         assert abs(got[0]["it"] - want["iterations"]) == 1 and (abs(dE - 1e-6) < 5e-7 or abs(want["err"][k] - 1e-6) < 5e-7)
 
 
+def test_rows_added_on_the_device_give_the_same_registration(pkg, orc, monkeypatch):
+    """a cloud of more than ICP_HOST_ROWS_MAX rows (16 384 by default: 2 M points) has its moment rows added on the device -- 256
+    blocks add contiguous ranges of rows in fixed order, one block adds those, 32 doubles come back -- instead of by the host as
+    they arrive: another association of the same fp64 sums.  Forced here on a 36 864-point grid (288 rows, limit 64)"""
+    D = pkg.datasets.synthetic_grid(192, np.float32)
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    with pkg.Context(0) as c:
+        ref = c.point_to_point(D, M, max_iter=12, tol=1e-6, fixed_iterations=True)
+    monkeypatch.setenv("ICP_HOST_ROWS_MAX", "64")
+    with pkg.Context(0) as c:
+        got = c.point_to_point(D, M, max_iter=12, tol=1e-6, fixed_iterations=True)
+    assert got.passes == ref.passes and np.array_equal(got.idx, ref.idx)
+    assert rel(got.T, ref.T) < 1e-12 and np.abs(got.err - ref.err).max() < 1e-12
+    want = orc.icp_p2p_f32x(D, M, 12, 1e-6, fixed=True)
+    assert np.array_equal(got.idx, want["idx"]) and rel(got.T, want["T"]) < TOL_T
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_non_finite_input_is_refused(ctx, pkg, orc, dtype):
     """include/icp_mi355x.h, "non-finite input": a cloud with a NaN or an infinite coordinate is refused with ICP_ERR_INVALID at
