@@ -231,6 +231,7 @@ struct LoopState {
     // armed launch: the matching pass AFTER the pending one is already enqueued and waits for its (R, t)
     bool armed = false;
     bool slot_written = false;   // the pending (or last completed) pass was an armed launch that left points and matches in slot order
+    bool slot_flip = false;      // ... in this plane of the slot-order points (the next such launch reads it and writes the other)
     double armed_tag = 0.0;
     int armed_slot = 0;
     int armed_prev_cur = 0;
@@ -270,10 +271,13 @@ struct icp_ctx {
     DevBuf Qss;   // Morton-ordered scan copy (sparse kernel), when the model's own order has no locality
     DevBuf Qperm; // ... and its permutation: sorted position -> model index
     DevBuf Pperm; // slot -> moving point (Morton order of the initial positions), when the cloud's own order has no locality
-    DevBuf slot_state; // armed launches: moving points + matched model points in slot order (6 x n_pad floats)
+    DevBuf slot_state; // fused launches of the sparse kernels: moving points (two planes) + matched model points in slot order (9 x n_pad floats)
     DevBuf share_counts;                        // shared rows (NNPlan::share_blocks): 5 x blocks_x hit counters (3 in rotation from launch to launch, 2 for first passes)
     mutable unsigned long long share_seq = 0;   // ... the launches so far (advanced by the launcher)
     mutable unsigned long long share_cold_seq = 0;   // ... and those that were the first pass of a registration
+    DevBuf order_roles, order_totals;  // ... the roles of the launch's blocks (split rows: icp_kernels.h, NN_ORDER_*), the sum of the counters
+    unsigned long long order_seq = 0;
+    int split_min = -1;                // the smallest part of a split row, in hits of the launch before (ICP_NN_SPLIT_MIN; 0: no row is split; -1: 512 per wave of a block)
     DevBuf row_hits, order_keys[2], order_vals[2], order_tmp;   // ordered rows (NNPlan::order): hits per row, and the sort that turns them into the next launch's order
     const int32_t* row_order = nullptr;          // ... the order the next launch follows (device; NULL: index order)
     DevBuf seed_pub;                            // ... resident launches: blocks_x x 384 floats, the matches of split rows for their other blocks
@@ -450,6 +454,12 @@ int ensure_work_buffers(icp_ctx* c)
             HIP_TRY(hipMemsetAsync(c->row_hits.p, 0, c->row_hits.cap, c->stream));   // "nothing known": index order
         }
         for (int k = 0; k < 2; ++k) { HIP_TRY(c->order_keys[k].ensure(rb)); HIP_TRY(c->order_vals[k].ensure(rb)); }
+        HIP_TRY(c->order_roles.ensure(((size_t)pl.blocks_x + icp::NN_ORDER_EXTRA) * sizeof(int32_t)));
+        if (c->order_totals.cap == 0) {
+            HIP_TRY(c->order_totals.ensure(2 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(c->order_totals.p, 0, c->order_totals.cap, c->stream));
+            c->order_seq = 0;
+        }
         HIP_TRY(c->order_tmp.ensure(icp::row_order_temp_bytes(pl.blocks_x)));
     }
     // one error row per matching block row (fused transform) or per transform block
@@ -721,6 +731,7 @@ int icp_create(int device, icp_ctx** out)
     if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1);
     if (const char* v = std::getenv("ICP_SHARE_RESIDENT_AFTER")) c->share_resident_after = std::atoi(v);
     if (const char* v = std::getenv("ICP_SHARE_AUTO")) c->share_auto = !(v[0] == '0');
+    if (const char* v = std::getenv("ICP_NN_SPLIT_MIN")) c->split_min = std::max(0, std::atoi(v));   // (A/B runs and tests)
     if (const char* v = std::getenv("ICP_HOST_ROWS_MAX")) c->host_rows_max = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("ICP_TRACE")) { c->trace = v[0] == '1' || v[0] == '2'; c->trace_passes = v[0] == '2'; }
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
@@ -764,7 +775,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->work, &c->fin_scratch, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->work, &c->fin_scratch, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->order_roles, &c->order_totals, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -1141,6 +1152,13 @@ static int prepare_row_order(icp_ctx* c)
     for (int k = 0; k < 2; ++k) { b.keys[k] = (unsigned int*)c->order_keys[k].p; b.vals[k] = (int32_t*)c->order_vals[k].p; }
     b.temp = c->order_tmp.p;
     b.temp_bytes = c->order_tmp.cap;
+    b.roles = (int32_t*)c->order_roles.p;
+    b.totals = (unsigned long long*)c->order_totals.p;
+    b.seq = c->order_seq++;
+    // (8192 hits for a 16-wave block, and in proportion for smaller ones; the target itself: a quarter of a block slot's mean load)
+    const int nw = c->plan.nw > 0 ? c->plan.nw : 16;
+    b.min_part = c->split_min >= 0 ? c->split_min : 512 * nw;
+    b.total_div = 4 * c->num_cus * (16 / nw);
     HIP_TRY(icp::launch_row_order(b, (unsigned int*)c->row_hits.p, c->plan.blocks_x, &c->row_order, c->stream));
     return ICP_OK;
 }
@@ -1439,6 +1457,7 @@ static int loop_enqueue_body(icp_ctx* c)
         L.H.note_applied();
     }
     L.timed_nn = false;
+    bool slots_written = false;
     if (!final_only) {
         // the previous pass's matches seed the early-out bound (any valid index would do)
         if (c->fused_tail && icp::nn_can_fuse_tail(pl)) { if (int rc = prepare_row_order(c)) return rc; } else c->row_order = nullptr;
@@ -1462,13 +1481,24 @@ static int loop_enqueue_body(icp_ctx* c)
             ta.rows = mom_rows;
             ta.tag = (double)take_tags(c, 1);
             ta.compact = use_compact_rows(c, pl, ta.metric, mom_rows) ? 1 : 0;
+            ta.rows_on_device = host_reduce ? 0 : 1;
         }
         L.rows_compact = tail && ta.compact != 0;
         if (host_reduce) prepare_rows_format(c, L.rows_compact);   // (also the two-kernel form: launch_moments writes full rows)
+        bool slots = false;
         if (fused) {
             icp::NNFusedTransform ft{L.H.R, L.H.t, (const int32_t*)c->idx[L.applied_idx].p, c->P2.p, err_rows};
+            // every fused pass of the sparse kernels leaves its points and matches in slot order; the next one starts from them
+            // (one level of coalesced loads instead of slot -> point -> seed -> model point), as the armed launches do
+            if (tail && pl.sparse && pl.row != 64 && pl.splits == 1 && c->slot_state.ensure(9 * (size_t)pl.n_pad * sizeof(float)) == hipSuccess) {
+                ft.slot_state = c->slot_state.p;
+                ft.slot_valid = L.slot_written;
+                ft.slot_flip = L.slot_flip;
+                slots = true;
+            }
             HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, tail ? &ta : nullptr, c->stream));
             std::swap(c->P, c->P2);  // the moved cloud is the current one from here on
+            slots_written = slots;
             L.err_blocks = pl.blocks_x;
         } else {
             HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, nullptr, &cull, tail ? &ta : nullptr, c->stream));
@@ -1497,7 +1527,8 @@ static int loop_enqueue_body(icp_ctx* c)
     L.host_reduce = host_reduce;
     L.wait_tag = (double)c->tag_seq;
     L.pending = true;
-    L.slot_written = false;   // (a plain launch: nothing in slot order)
+    L.slot_written = slots_written;   // (a fused pass of the sparse kernels left its points and matches in slot order)
+    if (slots_written) L.slot_flip = !L.slot_flip;
     if (c->trace) c->tr_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
     return ICP_OK;
 }
@@ -1786,9 +1817,10 @@ int loop_arm(icp_ctx* c)
     icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[prev_cur].p, c->P2.p, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, tag};
     // every armed pass leaves its points and matches in slot order; the next one starts from them (one level of
     // coalesced loads instead of slot -> point -> seed -> model point) if the pass before it was such a pass
-    if (pl.splits == 1 && c->slot_state.ensure(6 * (size_t)pl.n_pad * sizeof(float)) == hipSuccess) {
+    if (pl.splits == 1 && c->slot_state.ensure(9 * (size_t)pl.n_pad * sizeof(float)) == hipSuccess) {
         ft.slot_state = c->slot_state.p;
         ft.slot_valid = L.slot_written;
+        ft.slot_flip = L.slot_flip;
     }
     if (c->profile_stride > 0) c->nn_launch_count++;
     HIP_TRY(icp::launch_nn(pl, c->P.p, c->Q.p, c->part_d.p, (int32_t*)c->part_idx.p, &ft, &cull, &ta, c->stream));
@@ -1821,6 +1853,7 @@ void loop_release_armed(icp_ctx* c)
     L.pending = true;
     L.armed = false;
     L.slot_written = c->plan.splits == 1 && c->slot_state.p != nullptr;
+    if (L.slot_written) L.slot_flip = !L.slot_flip;
 }
 
 // the loop ended (or failed): the waiting kernel exits without touching anything; undo the bookkeeping

@@ -31,7 +31,8 @@ struct NNPlan {
     int sparse;         // the geometry is the sparse kernel's (16-wave blocks of 128 moving points; needs chunk boxes)
     int hier;           // sparse kernel: two-level search (boxes of 64 chunks first) -- large models
     int row;            // sparse geometry: moving points per block row -- 128 (nn_match_sparse, 16 waves) or 64 (nn_match_row64, 8 waves)
-    int nw;             // rows of 128: waves per block -- 16, or 8 (two blocks per CU: clouds whose rows outnumber the CUs; launches with a fused tail)
+    int nw;             // rows of 128: waves per block -- 16, or 8 (two blocks per CU: clouds whose rows outnumber the CUs; launches with a fused tail),
+                        // or 4 (four per CU: the hierarchical search of clouds with rows for several rounds of blocks)
     int share_blocks;   // rows of 128, 8 waves, one launch per pass: blocks of a launch (> blocks_x: the spare ones go to the heavy rows), or 0
     int order;          // rows of 128, many more rows than the machine holds at once: the blocks of a launch take the rows heaviest first
                         // (by the hits of the launch before) -- see launch_row_order
@@ -98,8 +99,9 @@ struct NNFusedTransform {
     double want = 0.0;                   // sequence number of the (first) message
     bool resident = false;               // the kernel stays for the whole registration: pass p is message want + p
     bool store_first = false;            // resident: the input is not P_out (pristine copy): store the cloud in pass 0 as well
-    void* slot_state = nullptr;          // armed launches: 6 x n_pad floats, points and matched model points in slot order (or NULL)
+    void* slot_state = nullptr;          // fused launches of the sparse kernels: 9 x n_pad floats -- points (two planes) and matched model points in slot order (or NULL)
     bool slot_valid = false;             // ... the previous pass wrote them
+    bool slot_flip = false;              // ... which of the two planes of points this launch reads (it writes the other): 9 x n_pad floats in all
 };
 bool nn_can_fuse_transform(const NNPlan& pl);
 
@@ -191,15 +193,31 @@ unsigned int share_rows_plan(const unsigned int* hits, int rows, int blocks, int
 // one row lists 468 000 chunks and takes 8.3 ms; it started at 5.9 ms of a 14.2 ms pass whose blocks add up to 10.0 ms per
 // CU).  So the rows are taken heaviest first: every block adds the hits of its lists to its row's counter, and before the
 // next launch the counters are sorted (stable, descending; 20 bits) into the order its blocks follow.  Any order is exact.
+// SPLIT ROWS.  With the rows in that order and everything else faster, a late pass of the same registration lasts exactly as
+// long as its heaviest row (pass 24: 8.2 ms for the row that lists 476 000 chunks, 6.0 ms of work per CU in the whole
+// launch).  So the launch gets NN_ORDER_EXTRA blocks beyond its rows, and the rows whose counters exceed a target
+// T = max(total / (4 x the blocks the machine holds at once), min) are dealt 2, 4, .. 64 of them: block b finds its role
+// -- row, part, parts -- in roles[b]
+// (launch_row_order writes them: the split rows first, then the others, heaviest first; -1 = no role).  The parts of a row
+// interleave the model's super boxes (part p takes those whose number is p modulo parts), fold their minima into the row's
+// 64-bit keys and the last to arrive closes the row -- the protocol of the segment blocks.  Any assignment is exact.
+constexpr int NN_ORDER_EXTRA = 4096;   // blocks of an ordered launch beyond its rows
+constexpr int NN_ORDER_HEAD = 1024;    // rows (the heaviest) that may be split
+constexpr int NN_ROLE_ROW_BITS = 21, NN_ROLE_PART_BITS = 6;   // role = row | part << 21 | log2(parts) << 27
 struct RowOrderBuffers {
     unsigned int* keys[2];   // >= rows each
     int32_t* vals[2];        // >= rows each; the order ends up in vals[1]
     void* temp;              // rocPRIM scratch, row_order_temp_bytes(rows)
     size_t temp_bytes;
+    int32_t* roles;          // >= rows + NN_ORDER_EXTRA
+    unsigned long long* totals;   // 2, zero before the first launch (the sum of the counters, alternating)
+    unsigned long long seq;  // launches so far (the caller counts)
+    int min_part;            // no part is meant to be smaller than this many hits (0: no row is split)
+    int total_div;           // the target: the sum of the counters over this (4 x the blocks the machine holds at once)
 };
 size_t row_order_temp_bytes(int rows);
-// reads AND zeroes hits[rows] (the next launch counts afresh); *order_out = the sorted rows (device pointer)
-hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int rows, const int32_t** order_out, hipStream_t st);
+// reads AND zeroes hits[rows] (the next launch counts afresh); *roles_out = the roles of rows + NN_ORDER_EXTRA blocks (device pointer)
+hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int rows, const int32_t** roles_out, hipStream_t st);
 
 // device-side preparation of the sparse kernel's views (icp_set_model / icp_set_moving): scratch owned by the caller
 struct PrepBuffers {
@@ -250,6 +268,7 @@ struct NNTailArgs {
     // sparse kernels, point-to-point, rows read by the host: rows of NN_CROW doubles {error share + tag, sum p, sum q,
     // sum q p^T} -- see NNTail in icp_kernels.hip
     int compact = 0;
+    int rows_on_device = 0;     // the rows stay in device memory for a later kernel (finalize): no drain, no tag to wait for
 };
 constexpr int NN_CROW = 16;            // doubles per compact row
 constexpr int NN_CROW_TAG_BITS = 16;   // low mantissa bits of slot 0 that carry the row's tag (mod 2^16)

@@ -439,6 +439,7 @@ struct NNTail {
     // squares whose last 16 bits (2^-36 of its value) nothing can resolve: slot 0 is written last, after the others have
     // drained, exactly as the separate tag word was.
     int compact;
+    int rows_on_device;        // the rows are read by a later kernel, not by a polling host: plain stores, nothing to drain
     unsigned int tag_lo;       // low 32 bits of `tag` as an integer (a double -> integer conversion on the device expands to f64 fma code)
     int row;                   // the row this block closes, or -1: blockIdx.x (shared rows: a block's row is not its index)
     int idx_through;           // the correspondences leave as agent-scope (write-through) stores: a resident launch whose rows are closed now by one
@@ -498,6 +499,9 @@ struct NNFuse {
                              // (6 arrays of n_pad floats: p.xyz, q.xyz), written by every such pass for the next one -- its front
                              // end is then one level of coalesced loads instead of slot -> point -> seed -> model point; or NULL
     int slot_valid;          // ... the previous pass wrote them: read them
+    int slot_flip;           // ... the points have two planes (a row may be searched by several blocks, only one of which stores the
+                             // moved points -- never over what the others still read): read plane slot_flip, write the other.
+                             // Layout: [points, plane 0: 3 x n_pad][matches: 3 x n_pad][points, plane 1: 3 x n_pad]
     long long* tlog;         // diagnostic (ICP_NN_PHASES): per-wave s_memrealtime stamps, 10 slots per wave, or NULL
     long long tlog_cap;      // slots available
     int tlog_pass;           // resident launch: stamp this pass only (-1: every pass, the last one survives)
@@ -1130,6 +1134,19 @@ __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, co
     // sake of 19 doubles; the other outputs of the pass are for later kernels and become visible at kernel end.)
     const bool compact = TAIL == 1 && tail.compact != 0;
     if (compact) row = tail.rows + (size_t)rowi * NN_CROW;
+    if (tail.rows_on_device != 0) {
+        // (round 3: rows that a later kernel adds up -- finalize, clouds of many rows or a device communicator -- need neither
+        // write-through stores nor the wait for them nor a tag: the kernel boundary orders them)
+        if (lane < NACC) {
+            double sum = tp[lane];
+#pragma unroll
+            for (int q = 1; q < PARTS; ++q) sum += tp[q * NACC + lane];
+            row[1 + lane] = sum;
+        }
+        if (lane == 0) { row[ICP_MOM_ERR] = err_row; row[ICP_NMOM - 1] = tail.tag; }
+        ICP_PHASE(8)
+        return;
+    }
     if (lane < NACC) {
         double sum = tp[lane];
 #pragma unroll
@@ -1152,7 +1169,7 @@ __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, co
 // the chunks of the surviving ones after them -- compiled apart for the same reason (the extra level costs a small
 // model more than it saves)
 template <int TAIL, bool DIAG, bool PERM, bool HIER = false, int NWS = SP_NW>
-__global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(const float* __restrict__ P, int n_pad,
+__global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(const float* __restrict__ P, int n_pad,
                                                               const float* __restrict__ Q, int m_pad, int seg_len,
                                                               int round_passes, float* __restrict__ part_d,
                                                               int32_t* __restrict__ part_idx, RT<float> rt_arg, NNFuse fuse,
@@ -1163,10 +1180,11 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     // before there is a list) and the tail's transpose buffer (after it), and behind both the 128 merge keys.  16 waves:
     // 2048 samples, 32 KB in all.  8 waves (two blocks share a CU's 160 KB): 1024 samples, so that the keys follow the
     // hit list directly -- 17 KB.
-    constexpr int SMAX = NWS == 8 ? 1024 : 2048;
+    constexpr int SMAX = NWS != 16 ? 1024 : 2048;
     constexpr int HITS_BYTES = SP_HCAP * 4, MQ_BYTES = NWS * 128 * 4;
-    constexpr int MKEY_OFF = 3 * SMAX * 4 > HITS_BYTES ? 3 * SMAX * 4 : HITS_BYTES;
-    constexpr int OVL_BYTES = NWS == 8 ? MKEY_OFF + 128 * 8 : HITS_BYTES + 2 * SP_NW * 128 * 4;
+    constexpr int SUPER_BYTES = HIER ? 2 * NWS * 64 * 4 : 0;   // (hierarchical search: the super-box hit list lies behind the chunk hit list)
+    constexpr int MKEY_OFF = 3 * SMAX * 4 > HITS_BYTES + SUPER_BYTES ? 3 * SMAX * 4 : HITS_BYTES + SUPER_BYTES;
+    constexpr int OVL_BYTES = NWS != 16 ? MKEY_OFF + 128 * 8 : HITS_BYTES + 2 * SP_NW * 128 * 4;
     constexpr int TR_BYTES = TAIL ? ((TAIL == 2 ? 28 : 18) * 65 + 64) * 8 : 0;
     static_assert(TR_BYTES <= HITS_BYTES, "the tail's transpose buffer overlays the hit list");
     // hits a wave fetches per trip to memory (its stage holds them): 8 per gather instruction; the hierarchical search (no box
@@ -1213,8 +1231,8 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
 #define SP_SHARED (!HIER && TAIL != 0 && fuse.share_prev != nullptr)
 #define SP_ORDERED (HIER && TAIL != 0 && fuse.row_order != nullptr)   // (compiled into the hierarchical search only: the flat kernels have no register to spare)
 #define SP_ROW ((SP_SHARED || SP_ORDERED) ? __builtin_amdgcn_readfirstlane(role[0]) : (int)blockIdx.x)
-#define SP_PART (SP_SHARED ? __builtin_amdgcn_readfirstlane(role[1]) : (int)blockIdx.y)
-#define SP_PARTS (SP_SHARED ? __builtin_amdgcn_readfirstlane(role[2]) : (int)gridDim.y)
+#define SP_PART ((SP_SHARED || SP_ORDERED) ? __builtin_amdgcn_readfirstlane(role[1]) : (int)blockIdx.y)
+#define SP_PARTS ((SP_SHARED || SP_ORDERED) ? __builtin_amdgcn_readfirstlane(role[2]) : (int)gridDim.y)
     if constexpr (!HIER && TAIL != 0) {
         if (fuse.share_prev != nullptr) {
             const int R = fuse.share_rows, t = threadIdx.x;
@@ -1287,9 +1305,16 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
         }
     }
     if constexpr (HIER && TAIL != 0) {
-        // ordered rows (many more rows than the machine holds blocks): the blocks take the rows heaviest first (launch_row_order)
+        // ordered rows (many more rows than the machine holds blocks): the blocks take the rows heaviest first, and the
+        // heaviest of all are split over several blocks (launch_row_order deals the roles; NN_ORDER_*, icp_kernels.h)
         if (fuse.row_order != nullptr) {
-            if (threadIdx.x == 0) role[0] = fuse.row_order[blockIdx.x];
+            const int ro = fuse.row_order[blockIdx.x];   // (one word for the whole block)
+            if (ro < 0) return;                          // a spare block the split rows did not need
+            if (threadIdx.x == 0) {
+                role[0] = ro & ((1 << NN_ROLE_ROW_BITS) - 1);
+                role[1] = (ro >> NN_ROLE_ROW_BITS) & ((1 << NN_ROLE_PART_BITS) - 1);
+                role[2] = 1 << ((ro >> (NN_ROLE_ROW_BITS + NN_ROLE_PART_BITS)) & 7);
+            }
             __syncthreads();
         }
     }
@@ -1337,7 +1362,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
     }
     f2 px, py, pz;
     if (from_slots) {
-        const float* ss = fuse.slot_state + ibase;
+        const float* ss = fuse.slot_state + (fuse.slot_flip ? 6 * (size_t)n_pad : 0) + ibase;
         px = f2{ss[0], ss[64]};
         py = f2{ss[(size_t)n_pad], ss[(size_t)n_pad + 64]};
         pz = f2{ss[2 * (size_t)n_pad], ss[2 * (size_t)n_pad + 64]};
@@ -1484,7 +1509,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
                 fuse.P_out[(size_t)n_pad + i] = y;
                 fuse.P_out[2 * (size_t)n_pad + i] = z;
                 if (fuse.slot_state != nullptr) {   // (and in slot order, for the next pass's front end)
-                    float* ss = fuse.slot_state + (fresh(SP_ROW * 128) + lane + t * 64);   // (recomputed: no register held for it)
+                    float* ss = fuse.slot_state + (fuse.slot_flip ? 0 : 6 * (size_t)n_pad) + (fresh(SP_ROW * 128) + lane + t * 64);   // (recomputed: no register held for it)
                     ss[0] = x; ss[(size_t)n_pad] = y; ss[2 * (size_t)n_pad] = z;
                 }
                 if (i < fuse.n) {
@@ -1815,6 +1840,9 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
         const float* tboxes = sboxes + (size_t)n2_all * 8;
         const int s_lo = c_lo >> 6, s_hi = (c_hi + 63) >> 6;     // a segment starts on a super-box boundary (nn_plan)
         const int t_lo = s_lo >> 6, t_hi = (s_hi + 63) >> 6;
+        // a split row: this block takes the super boxes whose number is its part modulo the parts (2, 4, .. 64 of them) --
+        // the same lanes of every level-3 box's children
+        const bool my_super = SP_ORDERED ? (lane & (SP_PARTS - 1)) == SP_PART : true;
         // one box per lane against the group box: true where the box may hold a winner
         auto near_box = [&](const float4 b0, const float4 b1, float B) {
             const float gx = __builtin_fmaxf(__builtin_fmaxf(b0.x - ghi[0], glo[0] - b0.w), 0.f);
@@ -1859,7 +1887,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 8 ? 4 : 1) void nn_match_sparse(co
                 const int tend = min(tg + 2 * NWS, TH);
                 for (int k = tg + w; k < tend; k += NWS) {
                     const int sidx = (thits[k] << 6) + lane;
-                    const bool in = sidx >= s_lo && sidx < s_hi;
+                    const bool in = sidx >= s_lo && sidx < s_hi && my_super;
                     const float4* bp = reinterpret_cast<const float4*>(sboxes + (size_t)(in ? sidx : s_lo) * 8);
                     append(in && near_box(bp[0], bp[1], Bs), sidx, shits, scount);
                     if constexpr (DIAG) wk_upper += 64u;
@@ -3341,14 +3369,84 @@ __global__ void prep_slot_map_kernel(const int32_t* __restrict__ perm, int n, in
     if (k < n_pad) out[k] = k < n ? perm[k] : k;
 }
 
-__global__ void row_order_keys_kernel(unsigned int* __restrict__ hits, int rows, unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+__global__ void row_order_keys_kernel(unsigned int* __restrict__ hits, int rows, unsigned int* __restrict__ keys, int32_t* __restrict__ vals,
+                                      unsigned long long* __restrict__ total_add, unsigned long long* __restrict__ total_zero)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const unsigned int h = hits[r];
-    hits[r] = 0u;                                          // (the next launch counts afresh)
-    keys[r] = 0xfffffu - (h > 0xfffffu ? 0xfffffu : h);   // ascending sort of this = descending hits; ties keep the row order (stable)
-    vals[r] = r;
+    unsigned int h = 0u;
+    if (r < rows) {
+        h = hits[r];
+        hits[r] = 0u;                                          // (the next launch counts afresh)
+        h = h > 0xfffffu ? 0xfffffu : h;
+        keys[r] = 0xfffffu - h;                                // ascending sort of this = descending hits; ties keep the row order (stable)
+        vals[r] = r;
+    }
+    // the sum of the counters (the target of the split rows derives from it): two words, this launch adds to one and clears
+    // the other for the next
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h += (unsigned int)__shfl_xor((int)h, off, 64);
+    if ((threadIdx.x & 63) == 0 && h != 0u) atomicAdd(total_add, (unsigned long long)h);
+    if (r == 0) *total_zero = 0ull;
+}
+
+// the roles of an ordered launch's blocks (NN_ORDER_*, icp_kernels.h): every block works the split of the NN_ORDER_HEAD heaviest
+// rows out for itself (one scan of 1024 counters), block 0 writes their roles, all write the roles behind them
+__global__ __launch_bounds__(1024) void row_roles_kernel(const unsigned int* __restrict__ keys, const int32_t* __restrict__ vals, int rows,
+                                                         const unsigned long long* __restrict__ total, int min_part, int total_div, int32_t* __restrict__ roles)
+{
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int head = rows < NN_ORDER_HEAD ? rows : NN_ORDER_HEAD;
+    const unsigned int h = t < head ? 0xfffffu - keys[t] : 0u;
+    auto block_sum = [&](int v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        __syncthreads();   // (the words are free again)
+        if (lane == 0) wsum[w] = v;
+        __syncthreads();
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += wsum[k];
+        return s;
+    };
+    unsigned long long T = *total / (unsigned long long)(total_div > 0 ? total_div : 1024);
+    if (T < (unsigned long long)min_part) T = (unsigned long long)min_part;
+    int parts = t < head ? 1 : 0, E = head;
+    if (min_part > 0) {
+        for (int it = 0; it < 24; ++it) {   // (the target doubles until the parts fit the spare blocks: at most 20 times, the counters have 20 bits)
+            unsigned int p = 1u;
+            if ((unsigned long long)h > T) {
+                const unsigned long long want = ((unsigned long long)h + T - 1ull) / T;   // >= 2
+                p = want >= 64ull ? 64u : 1u << (32 - __builtin_clz((unsigned int)want - 1u));
+            }
+            parts = t < head ? (int)p : 0;
+            E = block_sum(parts);
+            if (E - head <= NN_ORDER_EXTRA) break;
+            T *= 2ull;
+            parts = t < head ? 1 : 0;
+            E = head;
+        }
+    }
+    int v = parts;   // inclusive running sum within the wave, then across the waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); v += lane >= o ? u : 0; }
+    __syncthreads();
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) base += k < w ? wsum[k] : 0;
+    const int excl = base + v - parts;
+    if (blockIdx.x == 0 && t < head) {
+        const int row = vals[t];
+        const int lg = 31 - __builtin_clz((unsigned int)parts);
+        for (int p = 0; p < parts; ++p) roles[excl + p] = row | (p << NN_ROLE_ROW_BITS) | (lg << (NN_ROLE_ROW_BITS + NN_ROLE_PART_BITS));
+    }
+    const int j = E + (int)blockIdx.x * 1024 + t;   // the roles behind the head: one block each, in the sorted order
+    if (j < rows + NN_ORDER_EXTRA) {
+        const int src = head + (j - E);
+        roles[j] = src < rows ? vals[src] : -1;
+    }
 }
 
 size_t row_order_temp_bytes(int rows)
@@ -3359,16 +3457,20 @@ size_t row_order_temp_bytes(int rows)
     return bytes;
 }
 
-hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int rows, const int32_t** order_out, hipStream_t st)
+hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int rows, const int32_t** roles_out, hipStream_t st)
 {
-    if (rows <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(row_order_keys_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, hits, rows, b.keys[0], b.vals[0]);
+    if (rows <= 0 || rows >= (1 << NN_ROLE_ROW_BITS) || b.roles == nullptr || b.totals == nullptr) return hipErrorInvalidValue;
+    unsigned long long* tot = b.totals + (b.seq & 1ull);
+    hipLaunchKernelGGL(row_order_keys_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, hits, rows, b.keys[0], b.vals[0], tot, b.totals + ((b.seq + 1ull) & 1ull));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t bytes = b.temp_bytes;
     e = rocprim::radix_sort_pairs(b.temp, bytes, b.keys[0], b.keys[1], b.vals[0], b.vals[1], (unsigned int)rows, 0, 20, st);
-    *order_out = b.vals[1];
-    return e;
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(row_roles_kernel, dim3((rows + NN_ORDER_EXTRA + 1023) / 1024), dim3(1024), 0, st, b.keys[1], b.vals[1], rows,
+                       (const unsigned long long*)tot, b.min_part, b.total_div, b.roles);
+    *roles_out = b.roles;
+    return hipGetLastError();
 }
 
 size_t prep_sort_temp_bytes(int count)
@@ -4281,6 +4383,12 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense)
             pl.nw = 16;
             // (without spare blocks the 8-wave form loses: 65 536 points = 512 rows, 88 us per iteration against 79 with 16 waves
             // in two rounds; with an eighth of the machine to spare it wins -- 50 176 points: 39.6 against 53.4)
+            // The hierarchical search with rows for several rounds of blocks runs them as 8-wave blocks as well, two to a CU: late in
+            // a registration a block is a chain of short dependent steps (front end, three levels of boxes, a handful of hits, the
+            // row's close: ~19 us for a median of 110 hits) and a second block on the CU fills the waits of the first -- 10 M x 10 M on
+            // one GPU: 11.2 -> 8.3 ms per iteration, every pass faster (the first 35.0 -> 33.9 ms, the thirtieth 5.4 -> 3.3)
+            // ... and 4-wave blocks, four to a CU: 8.4 -> 7.5 ms (the thirtieth pass 3.2 -> 2.5 ms; the first, cold, stays on 8 waves)
+            if (pl.hier && S == 1 && env_w128 != 16 && (env_w128 == 8 || env_w128 == 4 || pl.blocks_x >= 2 * num_cus)) pl.nw = env_w128 == 8 ? 8 : 4;
             if (!pl.hier && S == 1 && (env_w128 == 8 || (env_w128 != 16 && pl.blocks_x > num_cus && pl.blocks_x <= 2 * num_cus - num_cus / 4))) {
                 pl.nw = 8;
                 if (env_share && pl.blocks_x < 2 * num_cus && pl.blocks_x <= 8 * 64) pl.share_blocks = 2 * num_cus;
@@ -4381,7 +4489,7 @@ bool nn_can_fuse_tail(const NNPlan& pl)
     return ((pl.version == 2 && pl.pts_per_thread == 2 && pl.chunk == 8) || pl.version == 3) && pl.n > 0 && pl.m > 0;
 }
 
-int nn_block_threads(const NNPlan& pl) { return pl.sparse ? (pl.row == 64 ? R64_NW * 64 : (pl.nw == 8 ? 8 : SP_NW) * 64) : NN_BLOCK; }
+int nn_block_threads(const NNPlan& pl) { return pl.sparse ? (pl.row == 64 ? R64_NW * 64 : (pl.nw == 8 ? 8 : (pl.nw == 4 && pl.hier) ? 4 : SP_NW) * 64) : NN_BLOCK; }
 
 static long long* g_phase_log = nullptr;
 static long long g_phase_log_cap = 0;
@@ -4417,6 +4525,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             fuse.want_lo = (unsigned int)(unsigned long long)ft->want;
             fuse.slot_state = (pl.sparse && pl.row != 64 && pl.splits == 1 && !ft->resident) ? (float*)ft->slot_state : nullptr;
             fuse.slot_valid = (fuse.slot_state && ft->slot_valid) ? 1 : 0;
+            fuse.slot_flip = ft->slot_flip ? 1 : 0;
             fuse.resident = ft->resident ? 1 : 0;
             const int env_spec = env_int("ICP_NN_SPECULATE", 1);   // (A/B runs and tests: 0 switches the speculative search of resident launches off)
             fuse.speculate = (ft->resident && env_spec) ? 1 : 0;
@@ -4430,6 +4539,11 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         } else {
             for (int k = 0; k < 9; ++k) rt.r[k] = (float)ft->R9[k];
             for (int k = 0; k < 3; ++k) rt.t[k] = (float)ft->t3[k];
+            // (round 3: a plain launch -- the loop of a cloud whose rows the device adds up -- leaves and finds its points and
+            // matches in slot order too, as an armed one does)
+            fuse.slot_state = (pl.sparse && pl.row != 64 && pl.splits == 1) ? (float*)ft->slot_state : nullptr;
+            fuse.slot_valid = (fuse.slot_state && ft->slot_valid) ? 1 : 0;
+            fuse.slot_flip = ft->slot_flip ? 1 : 0;
         }
         fuse.apply = 1;
         fuse.n = pl.n;
@@ -4451,6 +4565,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         tail.tag = ta->tag;
         tail.tag_lo = (unsigned int)(unsigned long long)ta->tag;
         tail.compact = (ta->compact && pl.sparse && ta->metric == ICP_POINT_TO_POINT) ? 1 : 0;
+        tail.rows_on_device = (ta->rows_on_device && !tail.compact) ? 1 : 0;
     }
 #define ICP_LAUNCH_NN2T(CU, TL)                                                                                     \
     hipLaunchKernelGGL((nn_match_f32_v2<2, 8, CU, TL>), grid, dim3(NN_BLOCK), 0, st, (const float*)P, pl.n_pad,      \
@@ -4527,24 +4642,33 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             return hipLaunchKernel(fn, g64, dim3(nw64 * 64), args, 0, st);
         }
         {
-            // ---- 128-point rows: one table of instantiations; 8-wave blocks exist with a fused tail and a flat search only ----
+            // ---- 128-point rows: one table of instantiations; 8-wave blocks exist with a fused tail only, 4-wave blocks with a fused
+            // tail and the hierarchical search only.  A plan of 4-wave blocks runs its COLD launches (no previous match: every block
+            // starts from the sample round, and the rows are split by counters that are a registration old) on 8 waves: 10 M x 10 M,
+            // first pass 34.9 ms against 44.1 ----
             const bool diag = fuse.tlog != nullptr || fuse.work != nullptr, perm = fuse.q_perm != nullptr, hier = pl.hier != 0;
             const int tl = !ta ? 0 : (ta->metric == ICP_POINT_TO_PLANE ? 2 : 1);
-            const int nw = (pl.nw == 8 && tl != 0 && !hier) ? 8 : SP_NW;
+            const bool cold_launch = fuse.seed_idx == nullptr && fuse.slot_valid == 0;
+            const int nw = (pl.nw == 8 && tl != 0) ? 8 : (pl.nw == 4 && tl != 0 && hier) ? ((cold_launch && env_int("ICP_NN_COLD8", 1)) ? 8 : 4) : SP_NW;
             if (passes > (hier ? SP_MAX_PASSES : SP_HCAP_FLAT / (nw * 64))) passes = hier ? SP_MAX_PASSES : SP_HCAP_FLAT / (nw * 64);
             if (!hier && (pl.m_pad >> 3) > 65536) return hipErrorInvalidValue;   // (the flat search lists 16-bit chunk numbers; nn_plan never asks for it)
 #define ICP_SP_FN(TL, DG, PM) {(const void*)nn_match_sparse<TL, DG, PM, false>, (const void*)nn_match_sparse<TL, DG, PM, true>}
-#define ICP_SP_FN8(TL, DG, PM) {(const void*)nn_match_sparse<TL, DG, PM, false, 8>, nullptr}
-            static const void* const fns[2][3][2][2][2] = {
+#define ICP_SP_FN8(TL, DG, PM) {(const void*)nn_match_sparse<TL, DG, PM, false, 8>, (const void*)nn_match_sparse<TL, DG, PM, true, 8>}
+#define ICP_SP_FN4(TL, DG, PM) {nullptr, (const void*)nn_match_sparse<TL, DG, PM, true, 4>}
+            static const void* const fns[3][3][2][2][2] = {
                 {{{ICP_SP_FN(0, false, false), ICP_SP_FN(0, false, true)}, {ICP_SP_FN(0, true, false), ICP_SP_FN(0, true, true)}},
                  {{ICP_SP_FN(1, false, false), ICP_SP_FN(1, false, true)}, {ICP_SP_FN(1, true, false), ICP_SP_FN(1, true, true)}},
                  {{ICP_SP_FN(2, false, false), ICP_SP_FN(2, false, true)}, {ICP_SP_FN(2, true, false), ICP_SP_FN(2, true, true)}}},
                 {{{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}},
                  {{ICP_SP_FN8(1, false, false), ICP_SP_FN8(1, false, true)}, {ICP_SP_FN8(1, true, false), ICP_SP_FN8(1, true, true)}},
-                 {{ICP_SP_FN8(2, false, false), ICP_SP_FN8(2, false, true)}, {ICP_SP_FN8(2, true, false), ICP_SP_FN8(2, true, true)}}}};
+                 {{ICP_SP_FN8(2, false, false), ICP_SP_FN8(2, false, true)}, {ICP_SP_FN8(2, true, false), ICP_SP_FN8(2, true, true)}}},
+                {{{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}},
+                 {{ICP_SP_FN4(1, false, false), ICP_SP_FN4(1, false, true)}, {ICP_SP_FN4(1, true, false), ICP_SP_FN4(1, true, true)}},
+                 {{ICP_SP_FN4(2, false, false), ICP_SP_FN4(2, false, true)}, {ICP_SP_FN4(2, true, false), ICP_SP_FN4(2, true, true)}}}};
 #undef ICP_SP_FN
 #undef ICP_SP_FN8
-            const void* fn = fns[nw == 8 ? 1 : 0][tl][diag ? 1 : 0][perm ? 1 : 0][hier ? 1 : 0];
+#undef ICP_SP_FN4
+            const void* fn = fns[nw == 8 ? 1 : nw == 4 ? 2 : 0][tl][diag ? 1 : 0][perm ? 1 : 0][hier ? 1 : 0];
             if (fn == nullptr) return hipErrorInvalidValue;
             const float* Pp = (const float*)P;
             const float* Qp = (const float*)Qsp;
@@ -4589,10 +4713,14 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
                 g = dim3(pl.share_blocks, 1);
             }
             fuse.seed_pub = opt->seed_pub;
-            if (pl.order && ta && !fuse.resident && opt->row_order != nullptr && opt->row_hits != nullptr) { fuse.row_order = opt->row_order; fuse.row_hits = opt->row_hits; }
+            if (pl.order && ta && !fuse.resident && opt->row_order != nullptr && opt->row_hits != nullptr) {
+                fuse.row_order = opt->row_order;
+                fuse.row_hits = opt->row_hits;
+                g = dim3(pl.blocks_x + NN_ORDER_EXTRA, 1);   // (the roles of the blocks beyond the rows: parts of split rows, or none)
+            }
             if (fuse.resident) {
                 if (!ta || pl.splits != 1) return hipErrorInvalidValue;
-                const int variant = ((((nw == 8 ? 2 : 0) + (tl == 2 ? 1 : 0)) * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0)) * 2 + (hier ? 1 : 0);
+                const int variant = ((((nw == 8 ? 2 : nw == 4 ? 4 : 0) + (tl == 2 ? 1 : 0)) * 2 + (diag ? 1 : 0)) * 2 + (perm ? 1 : 0)) * 2 + (hier ? 1 : 0);
                 // Every block must be on the machine at once (they all wait for the same host).  A cooperative launch
                 // guarantees that or refuses, but costs ~13 us more per launch here; the same guarantee comes from the
                 // occupancy query it is built on: the grid fits iff blocks <= CUs x resident blocks per CU.  Blocks that

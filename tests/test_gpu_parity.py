@@ -513,8 +513,8 @@ def _set_row(monkeypatch, row):
     """ICP_NN_ROW = 64 / 128, and "128w8": rows of 128 as 8-wave blocks, two to a CU, whose launches (one per pass) share the
     rows -- the form clouds of 33-65 k points get by themselves, forced here onto small ones (few rows, hundreds of spare blocks)"""
     monkeypatch.setenv("ICP_NN_ROW", row[:3] if row.startswith("128") else row)
-    if row == "128w8":
-        monkeypatch.setenv("ICP_NN_WAVES128", "8")
+    if row in ("128w8", "128w4"):   # ("128w4": 4-wave blocks, the hierarchical search's form for clouds with rows for several rounds of blocks)
+        monkeypatch.setenv("ICP_NN_WAVES128", row[-1])
     else:
         monkeypatch.delenv("ICP_NN_WAVES128", raising=False)
 
@@ -574,11 +574,25 @@ def test_ordered_rows_are_the_same_computation(pkg, orc, golden, monkeypatch, me
     P, Q = orc.hall_clouds(golden)
     fn = (lambda c: c.point_to_point(P, Q, max_iter=100, tol=1e-6)) if metric == "point_to_point" else (lambda c: c.point_to_plane(P, Q, max_iter=50, tol=1e-6))
     res = {}
+    # (split rows: the heaviest rows of an ordered launch are searched by 2 .. 64 blocks each; a target of 16 hits splits most
+    # of these, of 0 none)
     for name, env in (("index_order", {"ICP_NN_ORDER": "0", "ICP_RESIDENT": "0"}), ("ordered_armed", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0"}),
-                      ("ordered_stepwise", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_ARMED": "0"})):
-        monkeypatch.delenv("ICP_NN_ORDER", raising=False)
+                      ("ordered_stepwise", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_ARMED": "0"}),
+                      ("split_armed", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_NN_SPLIT_MIN": "16"}),
+                      ("split_stepwise", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_ARMED": "0", "ICP_NN_SPLIT_MIN": "16"}),
+                      ("unsplit_stepwise", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_ARMED": "0", "ICP_NN_SPLIT_MIN": "0"}),
+                      ("split_armed_8_waves", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_NN_SPLIT_MIN": "16", "ICP_NN_WAVES128": "8"}),
+                      ("split_stepwise_8_waves", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_ARMED": "0", "ICP_NN_SPLIT_MIN": "16", "ICP_NN_WAVES128": "8"}),
+                      ("resident_8_waves", {"ICP_NN_WAVES128": "8"}),
+                      ("split_armed_4_waves", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_NN_SPLIT_MIN": "16", "ICP_NN_WAVES128": "4"}),
+                      ("split_stepwise_4_waves", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_ARMED": "0", "ICP_NN_SPLIT_MIN": "16", "ICP_NN_WAVES128": "4"}),
+                      ("stepwise_4_waves_throughout", {"ICP_NN_ORDER": "2", "ICP_RESIDENT": "0", "ICP_ARMED": "0", "ICP_NN_WAVES128": "4", "ICP_NN_COLD8": "0"}),
+                      ("resident_4_waves", {"ICP_NN_WAVES128": "4", "ICP_NN_COLD8": "0"})):
+        for k in ("ICP_NN_ORDER", "ICP_NN_SPLIT_MIN", "ICP_NN_WAVES128", "ICP_NN_COLD8"):
+            monkeypatch.delenv(k, raising=False)
         res[name] = _run_form(pkg, monkeypatch, env, fn)
-    monkeypatch.delenv("ICP_NN_ORDER", raising=False)
+    for k in ("ICP_NN_ORDER", "ICP_NN_SPLIT_MIN", "ICP_NN_WAVES128", "ICP_NN_COLD8"):
+        monkeypatch.delenv(k, raising=False)
     ref = res["index_order"]
     for name, r in res.items():
         assert r.iterations == ref.iterations and np.array_equal(r.T, ref.T) and np.array_equal(r.err, ref.err) and np.array_equal(r.idx, ref.idx), name
@@ -844,7 +858,7 @@ def _fuzz_cloud(rng, n, kind, scale):
 # (sort, hier, row): Morton views forbidden / forced; flat search with 64-point rows (nn_match_row64) and with 128-point rows
 # (nn_match_sparse), and the box hierarchy (128-point rows only)
 FUZZ_VARIANTS = [("0", "0", "64"), ("1", "0", "64"), ("0", "0", "128"), ("1", "0", "128"), ("0", "1", "128"), ("1", "1", "128"),
-                 ("0", "0", "128w8"), ("1", "0", "128w8")]
+                 ("0", "0", "128w8"), ("1", "0", "128w8"), ("0", "1", "128w8"), ("1", "1", "128w8"), ("0", "1", "128w4"), ("1", "1", "128w4")]
 
 
 @pytest.mark.parametrize("sort,hier,row", FUZZ_VARIANTS)
@@ -1084,8 +1098,9 @@ def test_configs4_share_loop_ordered_rows_and_padding(pkg, monkeypatch):
     P = np.ascontiguousarray(D[lo:lo + cnt])
     del D
     res = {}
-    for name, env in (("ordered", {}), ("index_order", {"ICP_NN_ORDER": "0"})):
+    for name, env in (("ordered", {}), ("index_order", {"ICP_NN_ORDER": "0"}), ("split_small", {"ICP_NN_SPLIT_MIN": "256"})):
         monkeypatch.delenv("ICP_NN_ORDER", raising=False)
+        monkeypatch.delenv("ICP_NN_SPLIT_MIN", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with pkg.Context(0) as c:
@@ -1096,9 +1111,13 @@ def test_configs4_share_loop_ordered_rows_and_padding(pkg, monkeypatch):
                 c.nn_match_resident()
                 after = c.get_indices()
     monkeypatch.delenv("ICP_NN_ORDER", raising=False)
-    a, b = res["ordered"], res["index_order"]
-    assert a.iterations == b.iterations == 5
-    assert np.array_equal(a.T, b.T) and np.array_equal(a.err[:-1], b.err[:-1]) and np.array_equal(a.idx, b.idx) and np.array_equal(a.moved, b.moved)
+    monkeypatch.delenv("ICP_NN_SPLIT_MIN", raising=False)
+    a = res["ordered"]
+    assert a.iterations == 5
+    for name in ("index_order", "split_small"):   # (split rows: the heaviest rows are searched by several blocks each)
+        b = res[name]
+        assert b.iterations == 5, name
+        assert np.array_equal(a.T, b.T) and np.array_equal(a.err[:-1], b.err[:-1]) and np.array_equal(a.idx, b.idx) and np.array_equal(a.moved, b.moved), name
     assert (np.diff(a.err[1:]) < 0).all()
     sample = np.concatenate([np.random.default_rng(5).integers(0, cnt, 24), np.arange(cnt - 16, cnt)])   # (+ the padded last row)
     for i in sample:
