@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
 """Phase log of a launch of the hierarchical 16-wave kernel (ICP_NN_PHASES, ICP_NN_PHASE_SLOTS large enough for every block):
 how long the blocks took, what that adds up to per CU, and how long the launch lasted -- the difference is imbalance.
-usage: hier_blocks.py ph.bin [cus=256]"""
+usage: hier_blocks.py ph.bin [cus=256] [waves per block=16] [blocks of the launch: the log is not wiped between launches, and
+an earlier launch of more or larger blocks leaves its stamps behind the last one's]"""
 import sys, numpy as np
-a = np.fromfile(sys.argv[1], dtype=np.int64); a = a[: len(a) // 160 * 160].reshape(-1, 16, 10)
+NW = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+a = np.fromfile(sys.argv[1], dtype=np.int64); a = a[: len(a) // (NW * 10) * (NW * 10)].reshape(-1, NW, 10)
 cus = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+if len(sys.argv) > 4: a = a[: int(sys.argv[4])]
 live = (a[:, 0, 9] > 0) & (a[:, 0, 0] > 0)
 a = a[live]
 start = a[:, :, 0].min(1); end = a[:, 0, 9]
 dur = (end - start) / 100.0
+dur = np.where(dur > 0, dur, 0.0)   # (a part of a split row that does not close it leaves no end stamp)
 hits = a[:, 1, 9] & 0xffffffff
 t0 = start.min(); span = (end.max() - t0) / 100.0
 print(f"blocks {len(a)}; launch span {span:.0f} us; block time: median {np.median(dur):.1f} mean {dur.mean():.1f} p99 {np.percentile(dur, 99):.1f} max {dur.max():.0f} us; "

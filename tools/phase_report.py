@@ -12,10 +12,12 @@ import numpy as np
 
 a = np.fromfile(sys.argv[1], dtype=np.int64)
 a = a[: len(a) // 10 * 10].reshape(-1, 10)
+for arg in sys.argv:   # --waves=N: only the first N waves of the log (the log is not wiped between launches)
+    if arg.startswith("--waves="): a = a[: int(arg[8:])]
 if "--hier" in sys.argv:
     # two-level search: waves other than wave 0 of a block leave, in slots 6..9, the ticks spent in the super-box find,
     # the chunk find and the hit processing (barriers included) and (super hits << 32 | chunk hits) of the block
-    nw = 16
+    nw = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 16
     w = np.arange(len(a)) % nw
     r = a[(w == 1) & (a[:, 1] > 0)]
     sf, cf, pr = r[:, 6] / 100.0, r[:, 7] / 100.0, r[:, 8] / 100.0
