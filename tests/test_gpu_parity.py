@@ -767,7 +767,8 @@ def test_rows_added_on_the_device_give_the_same_registration(pkg, orc, monkeypat
     with pkg.Context(0) as c:
         got = c.point_to_point(D, M, max_iter=12, tol=1e-6, fixed_iterations=True)
     assert got.passes == ref.passes and np.array_equal(got.idx, ref.idx)
-    assert rel(got.T, ref.T) < 1e-12 and np.abs(got.err - ref.err).max() < 1e-12
+    # (the same fp64 terms in another association; the error comes out of the moment sums by a difference that cancels ~30x)
+    assert rel(got.T, ref.T) < 1e-12 and np.abs(got.err - ref.err).max() < 1e-11
     want = orc.icp_p2p_f32x(D, M, 12, 1e-6, fixed=True)
     assert np.array_equal(got.idx, want["idx"]) and rel(got.T, want["T"]) < TOL_T
 
