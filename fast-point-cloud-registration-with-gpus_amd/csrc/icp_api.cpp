@@ -267,6 +267,8 @@ struct icp_ctx {
     bool have_model = false, have_moving = false, have_normals = false;
     DevBuf P0;  // pristine copy of the moving cloud as uploaded (icp_reset_moving)
     DevBuf Qbox;  // chunk bounding boxes of Qs
+    DevBuf Qrec;  // large models (hierarchical search): one 160-byte record per chunk -- box, coordinates, indices (launch_model_records)
+    bool have_records = false;
     DevBuf Qsamp; // one point per chunk of Qs
     DevBuf Qss;   // Morton-ordered scan copy (sparse kernel), when the model's own order has no locality
     DevBuf Qperm; // ... and its permutation: sorted position -> model index
@@ -775,7 +777,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->work, &c->fin_scratch, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->order_roles, &c->order_totals, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->work, &c->fin_scratch, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->order_roles, &c->order_totals, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qrec, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -962,6 +964,7 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
     c->idx_valid = false;
     c->have_model = false;     // (until the upload has been accepted)
     c->have_scan_copy = false;
+    c->have_records = false;
     if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q)) return rc;
     if (precision == ICP_F32 && m > 0) {
         // scan copy for the early-out matching kernels: exact duplicates of a lower-index point (and the padding)
@@ -991,6 +994,12 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         HIP_TRY(icp::launch_model_boxes(view, m_pad, (float*)c->Qbox.p, c->stream));
         HIP_TRY(c->Qsamp.ensure(icp::model_samples_bytes(m_pad)));
         HIP_TRY(icp::launch_model_samples(view, m_pad, (float*)c->Qsamp.p, c->stream));
+        c->have_records = false;
+        if (group2 > 0) {   // a model searched through the box hierarchy: the hits are fetched from per-chunk records
+            HIP_TRY(c->Qrec.ensure(icp::model_records_bytes(m_pad)));
+            HIP_TRY(icp::launch_model_records(view, (const float*)c->Qbox.p, c->model_sorted ? (const int32_t*)c->Qperm.p : nullptr, m_pad, (float*)c->Qrec.p, c->stream));
+            c->have_records = true;
+        }
         c->have_scan_copy = true;
         // A model searched through the box hierarchy: how far apart the (at most 2048) samples of a sample round lie -- the
         // model's extent from its top-level boxes, its area from the extents (a surface in that box), spacing^2 = area / samples.
@@ -1177,6 +1186,7 @@ static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
     if (c->count_work) o.work = (unsigned long long*)c->work.p;
     if (c->plan.order && c->row_order != nullptr) { o.row_order = c->row_order; o.row_hits = (unsigned int*)c->row_hits.p; }
+    if (c->have_records && c->use_boxes && c->plan.hier) o.records = (const float*)c->Qrec.p;
     if (c->plan.share_blocks > 0 && c->share_counts.p != nullptr) { o.share_counts = (unsigned int*)c->share_counts.p; o.share_seq = &c->share_seq; o.share_cold_seq = &c->share_cold_seq; o.seed_pub = (float*)c->seed_pub.p; }
     return o;
 }

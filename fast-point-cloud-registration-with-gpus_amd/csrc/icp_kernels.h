@@ -136,6 +136,7 @@ struct NNCullInputs {
     // ordered rows (NNPlan::order): block b of the launch works on row row_order[b]; every block adds the hits of its lists to row_hits[row]
     const int32_t* row_order = nullptr;
     unsigned int* row_hits = nullptr;
+    const float* records = nullptr;   // hierarchical search: one 160-byte record per chunk of the searched view (launch_model_records) or NULL
 };
 // What the sparse kernel EXECUTED (it returns the brute-force answer without evaluating most pairs): wave-level tallies.
 // One "hit" = one 8-point model chunk processed by one wave = 64 lanes x 2 moving points against that chunk.
@@ -204,6 +205,11 @@ unsigned int share_rows_plan(const unsigned int* hits, int rows, int blocks, int
 constexpr int NN_ORDER_EXTRA = 4096;   // blocks of an ordered launch beyond its rows
 constexpr int NN_ORDER_HEAD = 1024;    // rows (the heaviest) that may be split
 constexpr int NN_ROLE_ROW_BITS = 21, NN_ROLE_PART_BITS = 6;   // role = row | part << 21 | log2(parts) << 27
+// the hierarchical search fetches a hit from one 160-byte record per chunk (icp_kernels.hip, model_records_kernel)
+constexpr int NN_REC_WORDS = 40;
+size_t model_records_bytes(int m_pad);
+hipError_t launch_model_records(const void* Qs_soa, const float* boxes, const int32_t* perm, int m_pad, float* rec, hipStream_t st);
+
 struct RowOrderBuffers {
     unsigned int* keys[2];   // >= rows each
     int32_t* vals[2];        // >= rows each; the order ends up in vals[1]

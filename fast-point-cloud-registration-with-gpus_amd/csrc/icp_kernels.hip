@@ -519,6 +519,7 @@ struct NNFuse {
     int share_min;             // a part is never made smaller than this many hits (of the previous launch)
     const int32_t* row_order;  // ordered rows: block b works on row row_order[b] (heaviest first) -- or NULL
     unsigned int* row_hits;    // ... and adds the hits of its lists to row_hits[row]
+    const float* records;      // hierarchical search: one 160-byte record per chunk (model_records_kernel) -- a hit is fetched from it -- or NULL
     float* seed_pub;           // resident launch with shared rows: [rows][3][128] -- whichever block closes a split row leaves the matches' coordinates
                                // here (they seed the next pass and are what its error is measured against) for the row's other blocks
 };
@@ -1703,8 +1704,12 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
                 const int r0 = lane >> 3, h0 = hb + r0 * NWS + w, h8 = hb + (r0 + 8) * NWS + w;
                 const bool on0 = h0 < h1, on8 = HB > 8 && h8 < h1;
                 const int ch0 = on0 ? (int)hits[h0] : 0, ch8 = on8 ? (int)hits[h8] : 0;
-                const float* src0 = part < 2 ? fuse.boxes + (size_t)ch0 * 8 + part * 4 : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)ch0 * 8 + (part & 1) * 4;
-                const float* src8 = part < 2 ? fuse.boxes + (size_t)ch8 * 8 + part * 4 : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)ch8 * 8 + (part & 1) * 4;
+                // (a large model -- the hierarchical search: the hit's record, 160 contiguous bytes in the stage's own layout, two cache
+                // lines instead of 32-byte pieces of five arrays)
+                const float* src0 = HIER ? fuse.records + (size_t)ch0 * NN_REC_WORDS + part * 4
+                                         : part < 2 ? fuse.boxes + (size_t)ch0 * 8 + part * 4 : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)ch0 * 8 + (part & 1) * 4;
+                const float* src8 = HIER ? fuse.records + (size_t)ch8 * NN_REC_WORDS + part * 4
+                                         : part < 2 ? fuse.boxes + (size_t)ch8 * 8 + part * 4 : Q + (size_t)((part - 2) >> 1) * m_pad + (size_t)ch8 * 8 + (part & 1) * 4;
                 float4 v0 = float4{0.f, 0.f, 0.f, 0.f}, v8 = v0;
                 if (on0) v0 = *reinterpret_cast<const float4*>(src0);
                 if constexpr (HB > 8) { if (on8) v8 = *reinterpret_cast<const float4*>(src8); }
@@ -1716,7 +1721,8 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
                     const int h2 = hb + r2 * NWS + w;
                     if (lane < 2 * HB && h2 < h1)
                         *reinterpret_cast<int4*>(stage + r2 * STG + 32 + half * 4) =
-                            *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)(int)hits[h2] * 8 + half * 4);
+                            HIER ? *reinterpret_cast<const int4*>(fuse.records + (size_t)(int)hits[h2] * NN_REC_WORDS + 32 + half * 4)
+                                 : *reinterpret_cast<const int4*>(fuse.q_perm + (size_t)(int)hits[h2] * 8 + half * 4);
                 }
             }
             lds_same_wave_order();
@@ -3736,6 +3742,38 @@ hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipSt
     return hipGetLastError();
 }
 
+// One record per chunk for the hierarchical search of a large model: {box lo.xyz hi.x | hi.yz - - | x[8] | y[8] | z[8] | index[8]}
+// = 40 words = 160 contiguous bytes, the layout of a hit's stage in LDS.  A hit is then two cache lines instead of five
+// 32-byte pieces of five arrays (a model of millions of points is not L2-resident: 10 M x 10 M fetched 23 GB per early pass).
+__global__ void model_records_kernel(const float* __restrict__ Qs, const float* __restrict__ boxes, const int32_t* __restrict__ perm, int m_pad,
+                                     float* __restrict__ rec)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece each
+    const long long chunks = m_pad >> 3;
+    if (t >= chunks * 10) return;
+    const long long ch = t / 10;
+    const int part = (int)(t % 10);
+    float4 v;
+    if (part < 2) v = *reinterpret_cast<const float4*>(boxes + ch * 8 + part * 4);
+    else if (part < 8) v = *reinterpret_cast<const float4*>(Qs + (size_t)((part - 2) >> 1) * m_pad + ch * 8 + (part & 1) * 4);
+    else {
+        const int k0 = (int)(ch * 8) + (part - 8) * 4;
+        int4 iv = perm ? *reinterpret_cast<const int4*>(perm + k0) : int4{k0, k0 + 1, k0 + 2, k0 + 3};
+        v = float4{__int_as_float(iv.x), __int_as_float(iv.y), __int_as_float(iv.z), __int_as_float(iv.w)};
+    }
+    *reinterpret_cast<float4*>(rec + ch * NN_REC_WORDS + part * 4) = v;
+}
+
+size_t model_records_bytes(int m_pad) { return (size_t)(m_pad >> 3) * NN_REC_WORDS * sizeof(float); }
+
+hipError_t launch_model_records(const void* Qs_soa, const float* boxes, const int32_t* perm, int m_pad, float* rec, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const long long pieces = (long long)(m_pad >> 3) * 10;
+    hipLaunchKernelGGL(model_records_kernel, dim3((unsigned int)((pieces + 255) / 256)), dim3(256), 0, st, (const float*)Qs_soa, boxes, perm, m_pad, rec);
+    return hipGetLastError();
+}
+
 // lexicographic (d, j) minimum over the S segment partials: segments are ascending model ranges,
 // so the first strict minimum in segment order is the lowest index.
 template <typename F>
@@ -4426,7 +4464,7 @@ NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense)
             // (ICP_NN_ORDER = 0: index order; 2: also where the rows are few -- the parity tests; not cached)
             {
                 const int env_order = env_int("ICP_NN_ORDER", 1);
-                pl.order = (pl.hier && S == 1 && env_order && (env_order == 2 || pl.blocks_x >= 2 * num_cus)) ? 1 : 0;
+                pl.order = (pl.hier && S == 1 && env_order && (env_order == 2 || pl.blocks_x >= 2 * num_cus) && pl.blocks_x < (1 << NN_ROLE_ROW_BITS)) ? 1 : 0;   // (a role holds 21 bits of row)
             }
             return pl;
         }
@@ -4742,6 +4780,8 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
                 g = dim3(pl.share_blocks, 1);
             }
             fuse.seed_pub = opt->seed_pub;
+            fuse.records = hier ? opt->records : nullptr;
+            if (hier && fuse.records == nullptr) return hipErrorInvalidValue;   // (the hierarchical search fetches its hits from the records)
             if (pl.order && ta && !fuse.resident && opt->row_order != nullptr && opt->row_hits != nullptr) {
                 fuse.row_order = opt->row_order;
                 fuse.row_hits = opt->row_hits;

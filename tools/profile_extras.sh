@@ -22,6 +22,7 @@ for w in 8 16; do
   ICP_NN_WAVES=$w ICP_NN_PHASE_PASS=6 ICP_NN_PHASES=$O/ph.bin python3 tools/phase_run.py 9 > /dev/null 2>&1 && python3 tools/phase_report.py $O/ph.bin $w > $O/${T}_phase_log_resident_pass_${w}_waves.txt
   rm -f $O/ph.bin
 done
+python3 tools/bunny_first.py > $O/${T}_bunny_first_registration.txt 2>&1
 python3 tools/work_counters.py > $O/${T}_work_counters_one_registration.json 2> /dev/null
 python3 tools/nn_compare.py hall bunny grid128 big > $O/${T}_nn_compare_sparse_vs_dense.txt 2>&1
 python3 tools/dense_sweep.py hall > $O/${T}_dense_kernel_sweep.txt 2>&1
