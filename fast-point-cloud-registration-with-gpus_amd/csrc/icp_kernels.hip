@@ -4612,6 +4612,10 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
     fuse.tlog_cap = g_phase_log_cap;
     static const int env_tpass = env_int("ICP_NN_PHASE_PASS", -1);
     fuse.tlog_pass = env_tpass;
+    // (diagnostic: ICP_NN_PHASE_WIPE=1 clears the log ahead of every launch -- launches of different block sizes, spare blocks
+    // and the parts of split rows that do not close them would otherwise leave older stamps among the last launch's)
+    static const int env_twipe = env_int("ICP_NN_PHASE_WIPE", 0);
+    if (env_twipe && g_phase_log != nullptr && hipMemsetAsync(g_phase_log, 0, (size_t)g_phase_log_cap * sizeof(long long), st) != hipSuccess) return hipErrorInvalidValue;
     fuse.work = opt ? opt->work : nullptr;
     const void* Qscan = Q;
     if (pl.cull && opt && opt->Q_scan) {

@@ -8,11 +8,13 @@ NW = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 a = np.fromfile(sys.argv[1], dtype=np.int64); a = a[: len(a) // (NW * 10) * (NW * 10)].reshape(-1, NW, 10)
 cus = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 if len(sys.argv) > 4: a = a[: int(sys.argv[4])]
-live = (a[:, 0, 9] > 0) & (a[:, 0, 0] > 0)
+# (run with ICP_NN_PHASE_WIPE=1: the log then holds the last launch only.  A spare block leaves nothing; a part of a split row
+# that does not close it ends at its ticket, phase 7; the closing block at phase 9)
+live = a[:, 0, 0] > 0
 a = a[live]
-start = a[:, :, 0].min(1); end = a[:, 0, 9]
+start = a[:, :, 0].min(1)
+end = np.maximum(a[:, 0, :].max(1), a[:, :, :6].max(axis=(1, 2)))   # (slots 6..9 of the other waves hold durations and counts, not stamps)
 dur = (end - start) / 100.0
-dur = np.where(dur > 0, dur, 0.0)   # (a part of a split row that does not close it leaves no end stamp)
 hits = a[:, 1, 9] & 0xffffffff
 t0 = start.min(); span = (end.max() - t0) / 100.0
 print(f"blocks {len(a)}; launch span {span:.0f} us; block time: median {np.median(dur):.1f} mean {dur.mean():.1f} p99 {np.percentile(dur, 99):.1f} max {dur.max():.0f} us; "
