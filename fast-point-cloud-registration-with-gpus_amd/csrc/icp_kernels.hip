@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
     // hits a wave fetches per trip to memory (its stage holds them): 8 per gather instruction; the hierarchical search (no box
     // cache in LDS) has the room for two -- a block with 9..16 hits per wave makes one trip, not two, and the median block of a
     // late pass on the 10 M-point model has 8.3
-    constexpr int HB = (HIER && NWS == 16) ? 16 : 8;
+    constexpr int HB = HIER ? 16 : 8;
     constexpr int STAGE_OFF = OVL_BYTES + 128 * 4 + 16, STAGE_BYTES = NWS * HB * STG * 4;
     constexpr int MSG_OFF = STAGE_OFF + STAGE_BYTES, SEED_OFF = MSG_OFF + 64;  // message: 12 floats + cmd; seeds: 3 x 128 floats
     constexpr int MQ_OFF = SEED_OFF + 3 * 128 * 4;                             // every wave's candidate coordinates: 3 x NWS x 128
