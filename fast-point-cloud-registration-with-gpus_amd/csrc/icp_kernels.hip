@@ -519,6 +519,7 @@ struct NNFuse {
     int share_min;             // a part is never made smaller than this many hits (of the previous launch)
     const int32_t* row_order;  // ordered rows: block b works on row row_order[b] (heaviest first) -- or NULL
     unsigned int* row_hits;    // ... and adds the hits of its lists to row_hits[row]
+    int round_supers;          // hierarchical search: super boxes per round of the chunk find (<= 64: the hit list holds their chunks)
     const float* records;      // hierarchical search: one 160-byte record per chunk (model_records_kernel) -- a hit is fetched from it -- or NULL
     float* seed_pub;           // resident launch with shared rows: [rows][3][128] -- whichever block closes a split row leaves the matches' coordinates
                                // here (they seed the next pass and are what its error is measured against) for the row's other blocks
@@ -1903,11 +1904,12 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
                 dg_lap(0);
                 dg_sh += SH;
                 const bool more_above = tend < TH || tb + TCAP < t_hi;
-                for (int sh0 = 0; sh0 < SH; sh0 += 64) {
+                const int rs_ = fuse.round_supers;
+                for (int sh0 = 0; sh0 < SH; sh0 += rs_) {
                     // one round: the chunks of up to 64 super boxes (<= SP_HCAP hits)
                     const float B = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
                     if (list_dirty && sh0 != 0) __syncthreads();  // (sh0 == 0: the barrier above)
-                    const int send = min(sh0 + 64, SH);
+                    const int send = min(sh0 + rs_, SH);
                     for (int k = sh0 + w; k < send; k += NWS) {
                         const int c0 = shits[k] << 6;
                         const float4* bp = reinterpret_cast<const float4*>(fuse.boxes + (size_t)(c0 + lane < c_hi ? c0 + lane : c_lo) * 8);
@@ -4822,6 +4824,10 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             }
             fuse.seed_pub = opt->seed_pub;
             fuse.records = hier ? opt->records : nullptr;
+            // (a round of the chunk find covers 16 listed super boxes -- the hit list would hold 64: every round starts from the largest
+            // bound the rounds before have left, so shorter rounds list less; 10 M x 10 M, rounds of 64 / 32 / 16 / 8: 1.41 / 1.29 / 1.19 /
+            // 1.13 G chunks listed per registration, 5.93 / 5.75 / 5.65 / 5.69 ms per iteration.  ICP_NN_ROUND_SUPERS for the A/B)
+            { const int rs = env_int("ICP_NN_ROUND_SUPERS", 16); fuse.round_supers = rs >= 1 && rs <= 64 ? rs : 16; }
             if (hier && fuse.records == nullptr) return hipErrorInvalidValue;   // (the hierarchical search fetches its hits from the records)
             if (pl.order && ta && !fuse.resident && opt->row_order != nullptr && opt->row_hits != nullptr) {
                 fuse.row_order = opt->row_order;
