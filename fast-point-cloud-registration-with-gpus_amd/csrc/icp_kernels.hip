@@ -519,6 +519,7 @@ struct NNFuse {
     int share_min;             // a part is never made smaller than this many hits (of the previous launch)
     const int32_t* row_order;  // ordered rows: block b works on row row_order[b] (heaviest first) -- or NULL
     unsigned int* row_hits;    // ... and adds the hits of its lists to row_hits[row]
+    int refine_min, refine_cnt; // hierarchical search: a pass that lists at least refine_min super boxes takes a refinement round over <= refine_cnt of their chunk samples (0: never)
     int round_supers;          // hierarchical search: super boxes per round of the chunk find (<= 64: the hit list holds their chunks)
     const float* records;      // hierarchical search: one 160-byte record per chunk (model_records_kernel) -- a hit is fetched from it -- or NULL
     float* seed_pub;           // resident launch with shared rows: [rows][3][128] -- whichever block closes a split row leaves the matches' coordinates
@@ -1901,6 +1902,42 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
                 }
                 __syncthreads();   // the super list is complete (and, after a processed round, the chunk list's reset is seen)
                 const int SH = *scount;
+                if (tb == t_lo && tg == 0 && fuse.samples != nullptr && fuse.refine_min > 0 && SH >= fuse.refine_min) {
+                    // REFINEMENT ROUND (a pass whose bounds are loose lists many super boxes): before any chunk is listed, the row's
+                    // points are measured against the chunk samples of the super boxes just listed -- every k-th of them, at most
+                    // refine_cnt -- staged over the (still empty) chunk hit list.  Any model point gives a valid bound; these lie
+                    // where the row's neighbours are, a few point spacings apart, so the rounds below start from near-final bounds
+                    // instead of reaching them hit by hit.
+                    constexpr int RSTRIDE = 1024;                      // (12 KB: below the super-box list in every block size)
+                    const int ns_pad_r = (((m_pad / 8) + 7) / 8) * 8, ns_r = m_pad >> 3;
+                    const int total = SH * 64, kstep = (total + fuse.refine_cnt - 1) / fuse.refine_cnt;
+                    const int cnt_r = (total / kstep) & ~7, ng_r = cnt_r >> 3;
+                    float* sl = reinterpret_cast<float*>(lds_raw);
+                    for (int i = threadIdx.x; i < cnt_r; i += NWS * 64) {
+                        const int e = i * kstep;
+                        int ci = (shits[e >> 6] << 6) + (e & 63);
+                        ci = ci < ns_r ? ci : ns_r - 1;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) sl[a * RSTRIDE + i] = fuse.samples[(size_t)a * ns_pad_r + ci];
+                    }
+                    __syncthreads();
+                    float sbr[2] = {inf_<float>(), inf_<float>()};
+                    for (int gp = w; gp < ng_r; gp += NWS) {
+                        const float4* a = reinterpret_cast<const float4*>(sl + gp * 8);
+                        const float4* b = reinterpret_cast<const float4*>(sl + RSTRIDE + gp * 8);
+                        const float4* c = reinterpret_cast<const float4*>(sl + 2 * RSTRIDE + gp * 8);
+                        scan8_min(a[0], a[1], b[0], b[1], c[0], c[1], px, py, pz, sbr);
+                        if constexpr (DIAG) ++wk_samp;
+                    }
+                    if (real[0]) atomicMin(&smin[lane], __float_as_uint(sbr[0]));
+                    if (real[1]) atomicMin(&smin[lane + 64], __float_as_uint(sbr[1]));
+                    __syncthreads();   // (also: the staging area is the hit list again)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const unsigned int v = smin[lane + q * 64];
+                        if (real[q] && v < 0x7f800000u && __uint_as_float(v + 1u) < best[q]) { best[q] = __uint_as_float(v + 1u); bj[q] = -1; }
+                    }
+                }
                 dg_lap(0);
                 dg_sh += SH;
                 const bool more_above = tend < TH || tb + TCAP < t_hi;
@@ -4699,7 +4736,9 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         // pass on the hall scan, where a few blocks take the full round without gaining from it; 2048 on large models
         static const int env_sgroups = env_int("ICP_NN_SAMPLE_GROUPS", 0);
         fuse.sample_groups = env_sgroups > 0 ? env_sgroups : (pl.m_pad <= 32768 ? 64 : 256);
-        fuse.resample_bound = (opt->sample_spacing2 > 0.f && pl.hier) ? opt->sample_spacing2 * env_float("ICP_NN_RESAMPLE", 2.0f) : 0.f;
+        // (round 3, later: with the refinement round of the traversal -- local samples, where the row's neighbours are -- the coarse
+        // round of a SEEDED pass costs more than it adds: off unless ICP_NN_RESAMPLE=k asks for it; 5.14 -> 5.10 ms)
+        fuse.resample_bound = (opt->sample_spacing2 > 0.f && pl.hier) ? opt->sample_spacing2 * env_float("ICP_NN_RESAMPLE", 0.0f) : 0.f;
         static const int env_passes = env_int("ICP_NN_PASSES", 0);
         // seeded: few hits, long rounds; cold: short rounds so that the exchanged minima start pruning early
         static const int env_waves = env_int("ICP_NN_WAVES", 0);
@@ -4827,6 +4866,10 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             // (a round of the chunk find covers 16 listed super boxes -- the hit list would hold 64: every round starts from the largest
             // bound the rounds before have left, so shorter rounds list less; 10 M x 10 M, rounds of 64 / 32 / 16 / 8: 1.41 / 1.29 / 1.19 /
             // 1.13 G chunks listed per registration, 5.93 / 5.75 / 5.65 / 5.69 ms per iteration.  ICP_NN_ROUND_SUPERS for the A/B)
+            // (the refinement round of a pass that lists >= 12 super boxes, over <= 256 of their chunk samples: 10 M x 10 M 5.68 -> 5.14 ms,
+            // 1.19 -> 0.99 G chunks listed and 370 -> 327 M evaluated per registration; 24 / 512: 5.26, 12 / 128: 5.15, 8 / 256: 5.17.
+            // ICP_NN_REFINE_MIN=0: never -- A/B runs; not cached)
+            { const int rm = env_int("ICP_NN_REFINE_MIN", 12), rc = env_int("ICP_NN_REFINE_SAMPLES", 256); fuse.refine_min = rm > 0 ? rm : 0; fuse.refine_cnt = rc >= 64 && rc <= 1024 ? rc : 256; }
             { const int rs = env_int("ICP_NN_ROUND_SUPERS", 16); fuse.round_supers = rs >= 1 && rs <= 64 ? rs : 16; }
             if (hier && fuse.records == nullptr) return hipErrorInvalidValue;   // (the hierarchical search fetches its hits from the records)
             if (pl.order && ta && !fuse.resident && opt->row_order != nullptr && opt->row_hits != nullptr) {
