@@ -353,8 +353,9 @@ class S5(Workload):
     metric_id = "ICP iterations/sec, synthetic 10M-point cloud (BASELINE configs[4])"
     workload = "synthetic 10M-point cloud point-to-point ICP, moving cloud sharded over the ranks (BASELINE configs[4])"
     kernel = ("nn_match_sparse<1, ..., HIER, 4> (rows of 128 points, 4 waves per block and four blocks to a CU -- 8 waves for the cold first "
-              "pass --, three-level box hierarchy over the Morton view of the model, rows taken heaviest first, the heaviest split over "
-              "2..64 blocks), ONE launch per pass")
+              "pass of a context without history --, three-level box hierarchy over the Hilbert-ordered view of the model, rows taken "
+              "heaviest first, the heaviest split over 2..64 blocks, a refinement round over local samples before the chunks are listed), "
+              "ONE launch per pass")
     scaling = "strong"
     regime = "fixed"
 

@@ -279,6 +279,8 @@ struct icp_ctx {
     mutable unsigned long long share_cold_seq = 0;   // ... and those that were the first pass of a registration
     DevBuf order_roles, order_totals;  // ... the roles of the launch's blocks (split rows: icp_kernels.h, NN_ORDER_*), the sum of the counters
     unsigned long long order_seq = 0;
+    int order_regs = 0;                // registrations (loops) that have run ordered launches with these counters
+    int order_launches = 0;            // ... ordered launches of the loop that is running
     int split_min = -1;                // the smallest part of a split row, in hits of the launch before (ICP_NN_SPLIT_MIN; 0: no row is split; -1: 512 per wave of a block)
     DevBuf row_hits, order_keys[2], order_vals[2], order_tmp;   // ordered rows (NNPlan::order): hits per row, and the sort that turns them into the next launch's order
     const int32_t* row_order = nullptr;          // ... the order the next launch follows (device; NULL: index order)
@@ -454,6 +456,8 @@ int ensure_work_buffers(icp_ctx* c)
         if (rb > c->row_hits.cap || before.blocks_x != pl.blocks_x) {
             HIP_TRY(c->row_hits.ensure(rb));
             HIP_TRY(hipMemsetAsync(c->row_hits.p, 0, c->row_hits.cap, c->stream));   // "nothing known": index order
+            c->order_regs = 0;
+            c->order_launches = 0;
         }
         for (int k = 0; k < 2; ++k) { HIP_TRY(c->order_keys[k].ensure(rb)); HIP_TRY(c->order_vals[k].ensure(rb)); }
         HIP_TRY(c->order_roles.ensure(((size_t)pl.blocks_x + icp::NN_ORDER_EXTRA) * sizeof(int32_t)));
@@ -1164,6 +1168,7 @@ static int prepare_row_order(icp_ctx* c)
     b.roles = (int32_t*)c->order_roles.p;
     b.totals = (unsigned long long*)c->order_totals.p;
     b.seq = c->order_seq++;
+    c->order_launches++;
     // (8192 hits for a 16-wave block, and in proportion for smaller ones; the target itself: a quarter of a block slot's mean load)
     const int nw = c->plan.nw > 0 ? c->plan.nw : 16;
     b.min_part = c->split_min >= 0 ? c->split_min : 512 * nw;
@@ -1185,7 +1190,7 @@ static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
     o.waves64 = c->exclusive ? 16 : 0;
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
     if (c->count_work) o.work = (unsigned long long*)c->work.p;
-    if (c->plan.order && c->row_order != nullptr) { o.row_order = c->row_order; o.row_hits = (unsigned int*)c->row_hits.p; }
+    if (c->plan.order && c->row_order != nullptr) { o.row_order = c->row_order; o.row_hits = (unsigned int*)c->row_hits.p; o.order_history = c->order_regs > 0; }
     if (c->have_records && c->use_boxes && c->plan.hier) o.records = (const float*)c->Qrec.p;
     if (c->plan.share_blocks > 0 && c->share_counts.p != nullptr) { o.share_counts = (unsigned int*)c->share_counts.p; o.share_seq = &c->share_seq; o.share_cold_seq = &c->share_cold_seq; o.seed_pub = (float*)c->seed_pub.p; }
     return o;
@@ -1423,6 +1428,7 @@ int icp_loop_begin(icp_ctx* c, const icp_params* prm)
     if (int rc = ensure_work_buffers(c)) return rc;
     LoopState& L = c->loop;
     L = LoopState();
+    if (c->order_launches > 0) { c->order_regs++; c->order_launches = 0; }   // (the loop before left its rows' counters: history for this one's cold pass)
     if (int rc = L.H.begin(*prm)) return fail(rc, "bad loop parameters");
     L.active = true;
     L.from_pristine = c->moving_untouched;

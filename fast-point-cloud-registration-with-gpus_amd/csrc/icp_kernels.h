@@ -136,6 +136,7 @@ struct NNCullInputs {
     // ordered rows (NNPlan::order): block b of the launch works on row row_order[b]; every block adds the hits of its lists to row_hits[row]
     const int32_t* row_order = nullptr;
     unsigned int* row_hits = nullptr;
+    bool order_history = false;      // ... the counters behind row_order were filled by launches of an EARLIER registration too
     const float* records = nullptr;   // hierarchical search: one 160-byte record per chunk of the searched view (launch_model_records) or NULL
 };
 // What the sparse kernel EXECUTED (it returns the brute-force answer without evaluating most pairs): wave-level tallies.

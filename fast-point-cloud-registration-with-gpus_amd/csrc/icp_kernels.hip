@@ -4798,7 +4798,11 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             const bool diag = fuse.tlog != nullptr || fuse.work != nullptr, perm = fuse.q_perm != nullptr, hier = pl.hier != 0;
             const int tl = !ta ? 0 : (ta->metric == ICP_POINT_TO_PLANE ? 2 : 1);
             const bool cold_launch = fuse.seed_idx == nullptr && fuse.slot_valid == 0;
-            const int nw = (pl.nw == 8 && tl != 0) ? 8 : (pl.nw == 4 && tl != 0 && hier) ? ((cold_launch && env_int("ICP_NN_COLD8", 1)) ? 8 : 4) : SP_NW;
+            // (... unless the rows' counters hold a registration's history -- a context's second registration on: the cold pass of a
+            // repeat then splits its heavy rows about right and the 4-wave form wins, 5.13 -> 5.04 ms per iteration; without history
+            // the share of one rank of eight ran its first registration in 24.1 ms on 8 waves against 26.3 on 4)
+            const bool cold8 = cold_launch && env_int("ICP_NN_COLD8", 1) && !(opt->row_order != nullptr && opt->order_history);
+            const int nw = (pl.nw == 8 && tl != 0) ? 8 : (pl.nw == 4 && tl != 0 && hier) ? (cold8 ? 8 : 4) : SP_NW;
             if (passes > (hier ? SP_MAX_PASSES : SP_HCAP_FLAT / (nw * 64))) passes = hier ? SP_MAX_PASSES : SP_HCAP_FLAT / (nw * 64);
             if (!hier && (pl.m_pad >> 3) > 65536) return hipErrorInvalidValue;   // (the flat search lists 16-bit chunk numbers; nn_plan never asks for it)
 #define ICP_SP_FN(TL, DG, PM) {(const void*)nn_match_sparse<TL, DG, PM, false>, (const void*)nn_match_sparse<TL, DG, PM, true>}
