@@ -872,6 +872,7 @@ template <> struct SpHit<true> { using type = int; };
 // simply "lowest k".
 // Returns how far the hit got (wave-uniform; only the work-counting instantiation looks at it): 0 = rejected by the
 // per-point box test, 1 = by the xy early-out, 2 = the eight distances were evaluated in full.
+constexpr bool SP_XY_EARLY_OUT = false;
 template <bool PERM>
 __device__ __forceinline__ int scan_hit(const float* sb, int ch, const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
                                         float (&bq)[2][3])
@@ -900,13 +901,20 @@ __device__ __forceinline__ int scan_hit(const float* sb, int ch, const f2 px, co
         d[kk + 2] = ax * ax + ay * ay;
         ax = pk_sub_bcast<1>(qxb, px); ay = pk_sub_bcast<1>(qyb, py);
         d[kk + 3] = ax * ax + ay * ay;
-        mxy0 = fmin_(fmin_(mxy0, d[kk].x), d[kk + 1].x);
-        mxy0 = fmin_(fmin_(mxy0, d[kk + 2].x), d[kk + 3].x);
-        mxy1 = fmin_(fmin_(mxy1, d[kk].y), d[kk + 1].y);
-        mxy1 = fmin_(fmin_(mxy1, d[kk + 2].y), d[kk + 3].y);
+        if constexpr (SP_XY_EARLY_OUT) {
+            mxy0 = fmin_(fmin_(mxy0, d[kk].x), d[kk + 1].x);
+            mxy0 = fmin_(fmin_(mxy0, d[kk + 2].x), d[kk + 3].x);
+            mxy1 = fmin_(fmin_(mxy1, d[kk].y), d[kk + 1].y);
+            mxy1 = fmin_(fmin_(mxy1, d[kk + 2].y), d[kk + 3].y);
+        }
     }
-    // d = fl(pxy + dz*dz) >= pxy: a chunk whose smallest pxy is above every lane's minimum cannot matter (ties pass)
-    if (__builtin_amdgcn_ballot_w64((mxy0 <= best[0]) | (mxy1 <= best[1])) == 0ull) return 1;
+    // d = fl(pxy + dz*dz) >= pxy: a chunk whose smallest pxy is above every lane's minimum cannot matter (ties pass).
+    // (Round 3: compiled out.  Behind the per-point box test this early-out stops 6-7 % of the chunks that reach it -- 10 M x 10 M:
+    // 328 M in, 304 M on; Bunny.csv 338 k / 318 k; the hall scan 56 565 / 56 565 -- and costs every one of them eight v_min, a
+    // ballot and a branch between the two halves of the arithmetic; nn_match_row64 dropped it in round 2 for the same reason.)
+    if constexpr (SP_XY_EARLY_OUT) {
+        if (__builtin_amdgcn_ballot_w64((mxy0 <= best[0]) | (mxy1 <= best[1])) == 0ull) return 1;
+    }
     float c0 = inf_<float>(), c1 = inf_<float>();  // the chunk's own minima
 #pragma unroll
     for (int kk = 0; kk < C; kk += 4) {
