@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path's measurements on MI355X, one JSON line per run.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config hall|hall_plane|bunny|s5|cpu_f64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config hall|hall_plane|bunny|s5|cpu_f64] [--shard strong|weak]
+                    [--repeats R] [--no-s5] [--no-rccl] [--no-cpu-baseline] [--no-fresh-pair]
 
 N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* from the environment), or plainly as `python bench.py --gpus N`, in which case this process starts
@@ -13,12 +14,23 @@ A child that does not answer in time is killed (its exact PID), the line is stil
 non-zero: a stuck communicator can neither hold the line back nor end as rc 0.  To profile, put the measuring process
 itself behind the profiler: `rocprofv3 --kernel-trace --stats -- python3 bench.py --leg main [--config ...]`.
 
+What `value` is (round 4).  The K-step region -- EXACTLY K steps between barrier + synchronize on both sides, the max over the
+ranks -- is repeated R times (R >= 25 where a region is short: the driver's `--steps 20` is 0.2 ms of work), each repeat
+between its own barriers; `ms_per_step` is the MEDIAN region / K, `value` = K / median region, the spread beside it
+(`ms_per_step_min` / `_max`, `repeats`).  For N > 1 `value` is the iteration rate of what the ranks compute TOGETHER: K / dt.
+Ranks that shard one cloud (hall, s5) run ONE registration; ranks that run replicas (hall_plane, bunny, cpu_f64) each run
+their own, and the sum over replicas is reported beside it as `aggregate_iterations_per_s`, never as `value`.
+
 Workloads (`--config`; every BASELINE.json config has one; each line carries `roofline` and `cpu_baseline`):
   hall        configs[2], the one BASELINE.json's metric is quoted on (default): point-to-point ICP on the hall LiDAR scan,
               16 384 x 16 384 points, fp32.  A step = one ICP iteration of back-to-back REAL registrations of the pair
               (tol 1e-6, MAX_ITER 100, src/CUDA/GPU_point_to_point_real.cu:18,404-405): each restarts from the pristine
               cloud, pays its launch and its cold first matching pass and stops by the reference's rule.
-              N > 1: weak scaling, a hall-sized shard of the moving cloud per rank, the full model on every rank.
+              N > 1 (`--shard strong`, the default: north_star's split on the metric's own cloud): the 16 384 moving points are
+              sharded over the ranks (icp_shard_range), the full model on every rank, one sum per iteration; `scaling` "strong".
+              The line carries beside it `weak_shards` (`--shard weak`: a hall-sized shard per rank, i.e. ONE registration of an
+              N x 16 384-point cloud against the hall model), `rccl` (the same sharded steps over the library-issued
+              ncclAllReduce) and -- every N, unless --no-s5 -- `s5`: the config north_star shards (configs[4]) in brief.
   hall_plane  configs[3]: the same pair, point-to-plane (kNN(4) + PCA normals of the model on the device, 6x6 solve on the
               host; MAX_ITER 50, tol 1e-6 as src/ICP_point_to_plane.cu).  Same regime.
   bunny       configs[1]: Bunny.csv 35 947 points against its moved copy, point-to-point, fp32, same regime; one replica
@@ -28,10 +40,12 @@ Workloads (`--config`; every BASELINE.json config has one; each line carries `ro
               the whole cloud; the timed region is ONE registration of K fixed iterations from the initial pose.
   cpu_f64     configs[0]: src/ICP_CPU.c's own run -- synthetic grid WIDTH x WIDTH (--width, 32 -> 1024 points), fp64,
               tol 1e-5, MAX_ITER 200 -- through the fp64 path (ICP_F64); same regime as hall.
-The only data that crosses ranks is the loop's 32-double moment vector, summed once per iteration.  `value` is measured
-with the node-local route (icp_comm_init_local: the vector is already in host memory; shared memory, ~1-2 us); the same
-steps are then repeated in the RCCL leg with ONE library-issued ncclAllReduce per iteration (icp_comm_init) and reported
-beside it as `rccl` -- for hall and for s5, the config north_star shards.
+The only data that crosses ranks is the loop's 32-double moment vector, summed once per iteration.  hall: `value` is measured
+with the node-local route (icp_comm_init_local: the vector is already in host memory; shared memory, ~1-2 us -- an RCCL
+all-reduce of 256 bytes costs more than the 9 us iteration) and the RCCL route is reported beside it (`rccl`).  s5, the config
+north_star shards: `value` is measured on the RCCL route north_star names (ONE library-issued ncclAllReduce per iteration,
+icp_comm_init; 0.5 % of a 5 ms iteration), the node-local route beside it (`local`); if RCCL refuses (two ranks rehearsed on
+one device) the line says so and `value` falls back to the node-local route.
 
 `roofline`: the dominant kernel of the config, its average launch duration by HIP events on the loop's own stream, the
 arithmetic it EXECUTED (kernel-side tallies of its instrumented instantiation, icp_get_work_counters) over that time,
@@ -80,6 +94,17 @@ def executed_flop(work, pts_per_hit=PTS_PER_HIT, waves_per_block=WAVES_PER_BLOCK
         "transforms": work["block_transforms"] * waves_per_block * pts_per_hit * FLOP_RT,
     }
     return float(sum(parts.values())), {k: float(v) for k, v in parts.items()}
+
+
+def cpu_model():
+    """the host CPU's model string (both CPU figures are labelled with it)"""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def usable_cores():
@@ -164,6 +189,48 @@ class Workload:
         if not (2 <= passes <= self.max_iter and err < 1e-3):
             raise SystemExit(f"[bench] the {self.name} registration did not converge: {passes} passes, rms error {err}")
 
+    # -- a pair the context has not seen -------------------------------------------------------------------------------
+    fresh_reps, fresh_warm = 10, 2
+    variant_base = None            # (angles, t) of the config's own model; variant k scales them
+
+    def variant_model(self, k):
+        ang, t = self.variant_base
+        f, g = 1.0 + 0.06 * (k + 1), 1.0 - 0.05 * (k + 1)
+        return self.pkg.datasets.make_model_gpu(self.P, tuple(a * f for a in ang), tuple(x * g for x in t))
+
+    def upload_pair(self, Q):
+        self.ctx.set_model(Q)
+        self.ctx.set_moving(self.P)
+
+    def fresh_pair(self):
+        """What a sensor's NEXT pair costs: icp_set_model (+ normals) + icp_set_moving + one registration of a pair this context has
+        not seen (the same moving cloud against a differently moved copy, another one every time), host buffers in, clouds not
+        resident.  The reference's method (src/CUDA/Matching_opt.cu:213-226): the minimum of `fresh_reps` after `fresh_warm`."""
+        models = [self.variant_model(k) for k in range(3)]
+        setup, total, iters = [], [], []
+        for r in range(-self.fresh_warm, self.fresh_reps):
+            Q = models[(r + self.fresh_warm) % len(models)]
+            t0 = time.perf_counter()
+            self.upload_pair(Q)
+            t1 = time.perf_counter()
+            self.ctx.loop_begin(self.metric, max_iter=self.args.steps if self.regime == "fixed" else self.max_iter, tol=self.tol,
+                                fixed_iterations=self.regime == "fixed")
+            k, done = 0, False
+            while not done:
+                kk, done = self.ctx.loop_run(1 << 20)
+                k += kk
+            t2 = time.perf_counter()
+            if r >= 0:
+                setup.append(t1 - t0); total.append(t2 - t0); iters.append(k)
+        import statistics
+        return {"fresh_pair_ms": 1e3 * min(total), "setup_ms": 1e3 * min(setup),
+                "fresh_pair": {"what": "icp_set_model (+ normals) + icp_set_moving + ONE registration of a pair the context has not seen (host buffers in; "
+                                       "the moving cloud against a differently moved copy, another copy every repeat); minimum of %d after %d "
+                                       "(the reference's method, src/CUDA/Matching_opt.cu:213-226)" % (self.fresh_reps, self.fresh_warm),
+                               "min_ms": 1e3 * min(total), "median_ms": 1e3 * statistics.median(total), "setup_min_ms": 1e3 * min(setup),
+                               "setup_median_ms": 1e3 * statistics.median(setup), "iterations": iters,
+                               "registration_alone_min_ms": 1e3 * min(t - u for t, u in zip(total, setup))}}
+
     # -- numbers ----------------------------------------------------------------------------------------------------
     def alg_flop_pass(self):
         return float(FLOP_PAIR) * self.n * self.m            # the brute-force scan's arithmetic (SURVEY 8d)
@@ -199,14 +266,25 @@ class Hall(Workload):
     kernel = "nn_match_row64<1> (rows of 64 points, one per lane; 16 waves per block with the device to itself, else 8; point-to-point row tail)"
 
     def build(self):
+        import numpy as np
         self.P, self.Q = _hall_pair(self.pkg, self.ctx)
+        self.shard = getattr(self.args, "shard", "strong") if self.world > 1 else "none"
+        if self.shard == "strong":
+            # north_star's split on the metric's own cloud: the 16 384 moving points sharded over the ranks, the model replicated
+            lo, cnt = self.pkg.shard_range(self.P.shape[0], self.rank, self.world)
+            self.n_global = self.P.shape[0]
+            self.P = np.ascontiguousarray(self.P[lo:lo + cnt])
+            self.scaling = "strong"
         self.n, self.m = self.P.shape[0], self.Q.shape[0]
-        self.n_global = self.n * self.world
+        if self.shard != "strong":
+            self.n_global = self.n * self.world      # (weak: a hall-sized shard per rank = one registration of an N x 16 384-point cloud)
         # one process per GPU and nothing else on it: the bench owns its device and says so (icp_set_exclusive: the rows of 64
         # points run as 16-wave blocks, one to a CU; same bits).  Not in the one-device rehearsal, where two ranks share a GPU.
         self.exclusive = os.environ.get("ICP_BENCH_ONE_DEVICE") != "1" and os.environ.get("ICP_BENCH_EXCLUSIVE", "1") != "0"
         if self.exclusive:
             self.ctx.set_exclusive(True)
+        ang, t_mm = self.pkg.datasets.HALL_MM
+        self.variant_base = (ang, tuple(x / 1000.0 for x in t_mm))     # (the fixture's pair is built in mm and scaled: the variants in metres)
         self.ctx.set_model(self.Q)
         self.ctx.set_moving(self.P)
 
@@ -226,7 +304,7 @@ class Hall(Workload):
         out = {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
                "sample": f"{iters} fixed point-to-point iterations of the same hall workload (16384x16384, fp32), "
                          f"oracle/icp_oracle.c single thread, {dt:.1f} s",
-               "host_cpus": os.cpu_count()}
+               "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
         # beside it: the same port with its matching loop spread over the cores this process may use (OpenMP over the
         # moving points; the minimisation stays scalar) -- the strongest thing the host can do with the reference's algorithm
         cores = usable_cores()
@@ -253,6 +331,11 @@ class HallPlane(Hall):
     kernel = "nn_match_row64<2> (rows of 64 points, one per lane; 16 waves per block with the device to itself, else 8; point-to-plane row tail: 21 + 6 sums)"
     max_iter, tol = 50, 1e-6      # src/ICP_point_to_plane.cu
 
+    def upload_pair(self, Q):
+        self.ctx.set_model(Q)
+        self.ctx.estimate_normals()      # (kNN(4) + PCA of the NEW model on the device: part of what a fresh pair costs)
+        self.ctx.set_moving(self.P)
+
     def build(self):
         super().build()
         self.metric = self.pkg.ICP_POINT_TO_PLANE
@@ -275,7 +358,7 @@ class HallPlane(Hall):
         out = {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
                "sample": f"{iters} fixed point-to-plane iterations of the same hall workload (16384x16384, fp32), oracle/icp_oracle.c "
                          f"single thread, {dt:.1f} s; the normals are not in the rate",
-               "host_cpus": os.cpu_count()}
+               "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
         t0 = time.perf_counter()
         nbr = orc.knn4(Q)
         orc.normals(Q, nbr)
@@ -312,6 +395,7 @@ class Bunny(Workload):
         import numpy as np
         B = np.fromfile(os.path.join(ROOT, "tests", "golden", "bunny_xyz_f32.bin"), dtype=np.float32).reshape(-1, 3)
         self.P = B
+        self.variant_base = self.pkg.datasets.BUNNY
         self.Q = self.pkg.datasets.make_model_gpu(B, *self.pkg.datasets.BUNNY)
         self.n, self.m = self.P.shape[0], self.Q.shape[0]
         self.n_global = self.n
@@ -330,7 +414,7 @@ class Bunny(Workload):
         out = {"value": 1.0 / min(ts), "unit": "iterations/s", "cores": 1, "kind": "port",
                "sample": "ONE point-to-point iteration of the same Bunny.csv workload (35947x35947, fp32) x 3, the minimum "
                          f"({min(ts):.2f} s; oracle/icp_oracle.c single thread, {sum(ts):.1f} s in all)",
-               "host_cpus": os.cpu_count()}
+               "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
         cores = usable_cores()
         if cores > 1:
             orc.set_threads(cores)
@@ -358,6 +442,12 @@ class S5(Workload):
               "ONE launch per pass")
     scaling = "strong"
     regime = "fixed"
+    fresh_reps, fresh_warm = 2, 1      # (a fresh 10 M-point pair is seconds of set-up: three in all)
+
+    def variant_model(self, k):
+        ang, t = self.pkg.datasets.P2P_GPU
+        f, g = 1.0 + 0.06 * (k + 1), 1.0 - 0.05 * (k + 1)
+        return self.pkg.datasets.make_model_gpu(self.P, tuple(a * f for a in ang), tuple(x * g for x in t))   # (N = 1: P is the whole cloud)
 
     def build(self):
         import numpy as np
@@ -398,7 +488,7 @@ class S5(Workload):
                "sample": f"EXTRAPOLATED: one point-to-point iteration of a {s} x {s}-point slice of the same clouds ({one:.2f} s, "
                          f"oracle/icp_oracle.c single thread) x (N / slice)^2 = {scale:.0f} -> {one * scale:.0f} s per iteration of the "
                          f"{self.n_global} x {self.m} workload",
-               "slice_points": s, "slice_iteration_s": one, "host_cpus": os.cpu_count()}
+               "slice_points": s, "slice_iteration_s": one, "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
         cores = usable_cores()
         if cores > 1:
             orc.set_threads(cores)
@@ -437,6 +527,11 @@ class CpuF64(Workload):
         self.ctx.set_model(self.Q)
         self.ctx.set_moving(self.P)
 
+    def variant_model(self, k):
+        ang, t = self.pkg.datasets.CPU_F64
+        f, g = 1.0 + 0.03 * (k + 1), 1.0 - 0.05 * (k + 1)
+        return self.pkg.datasets.make_model_cpu(self.P, tuple(a * f for a in ang), tuple(x * g for x in t))
+
     def geometry(self, info):
         return 64, (16 if info["blocks"] <= 256 else 8)    # (launch_row64_f64: 16 waves while every row has a CU of its own)
 
@@ -460,7 +555,7 @@ class CpuF64(Workload):
         dt = time.perf_counter() - t0
         out = {"value": its / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
                "sample": f"{reps} whole registrations of the same pair to convergence ({r['passes']} passes each, tol 1e-5), fp64 oracle single thread, {dt:.1f} s",
-               "iterations_per_registration": r["passes"], "final_rms_error": float(r["err"][-1]), "host_cpus": os.cpu_count()}
+               "iterations_per_registration": r["passes"], "final_rms_error": float(r["err"][-1]), "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
         cores = usable_cores()
         if cores > 1 and self.n >= 4096:
             orc.set_threads(cores)
@@ -540,8 +635,12 @@ def free_port():
 # ======================================================================================================================
 # --leg main: the measurement
 # ======================================================================================================================
-def timed_steps(wl, ranks, K, stride):
-    """EXACTLY K steps between barrier + synchronize on both sides; the max over ranks"""
+def timed_steps(wl, ranks, K, stride, repeats=None):
+    """The K-step region -- EXACTLY K steps between barrier + synchronize on both sides, the max over the ranks -- R times, every
+    repeat between its own barriers.  R: `--repeats`, else at least 25 where a region is short (the driver's `--steps 20` is 0.2 ms
+    of work: ONE such sample says nothing, and the boxes of the pool differ by up to 25 %), as many as make a quarter of a second
+    (at most 400), and 3..7 for regions that are long by themselves (s5: one registration of 30 iterations, 0.15 s).
+    Returns the R durations (every rank holds the same list) and the loop's event timing summed over all repeats."""
     import torch
     ctx = wl.ctx
 
@@ -549,17 +648,37 @@ def timed_steps(wl, ranks, K, stride):
         ranks.barrier()
         torch.cuda.synchronize(wl.local_rank)
 
+    def region(stats):
+        sync()
+        t0 = time.perf_counter()
+        wl.run_steps(K, stats)
+        sync()
+        return ranks.max(time.perf_counter() - t0)
+
     stats = {"registrations": 0, "iterations": 0}
     ctx.set_profiling(stride)     # (also restarts the stride: the first launch after this is a timed one)
-    sync()
-    t0 = time.perf_counter()
-    wl.run_steps(K, stats)
-    sync()
-    dt = ranks.max(time.perf_counter() - t0)
+    dts = [region(stats)]
+    if repeats is None or repeats < 1:
+        d0 = dts[0]
+        if d0 < 0.05:
+            repeats = max(25, min(400, int(0.25 / max(d0, 1e-6)) + 1))
+        else:
+            repeats = max(3, min(25, int(1.0 / d0) + 1))
+        if os.environ.get("ICP_BENCH_REPEATS"):
+            repeats = max(1, int(os.environ["ICP_BENCH_REPEATS"]))
+    for _ in range(repeats - 1):
+        dts.append(region(stats))
     sec, cnt = ctx.loop_timing()
     passes = ctx.loop_timing_passes()
     ctx.set_profiling(0)
-    return dt, stats, sec, cnt, passes
+    return dts, stats, sec, cnt, passes
+
+
+def region_stats(dts, K):
+    import statistics
+    med = statistics.median(dts)
+    return {"value": K / med, "ms_per_step": 1e3 * med / K, "ms_per_step_min": 1e3 * min(dts) / K, "ms_per_step_max": 1e3 * max(dts) / K,
+            "repeats": len(dts), "region_ms_median": 1e3 * med, "region_ms_min": 1e3 * min(dts), "region_ms_max": 1e3 * max(dts)}
 
 
 def roofline_leg(wl, K, passes_full, region, stride):
@@ -613,7 +732,7 @@ def roofline_leg(wl, K, passes_full, region, stride):
                          % (wl.dtype, wl.peak, "packed VALU ops (v_pk_add/mul_f32)" if wl.dtype == "f32" else "scalar fp64 VALU ops",
                             alg_flop / alg_bytes)),
         "achieved": achieved, "peak": wl.peak, "unit": "TFLOP/s", "frac": achieved / wl.peak,
-        "traffic": None, "traffic_source": None,
+        "traffic": None, "traffic_from_committed_profile": None,
         "what_frac_counts": "EXECUTED flop (kernel-side tallies of one whole registration, icp_get_work_counters) per matching pass x passes per "
                             "timed launch / average launch time; the kernel returns the brute-force answer bit for bit but proves for most pairs "
                             "that they cannot win",
@@ -635,13 +754,14 @@ def roofline_leg(wl, K, passes_full, region, stride):
     }
     # HBM traffic: PMC counters need rocprofv3 (separate --pmc passes), so the figure comes from this round's committed
     # profile of the config's kernel; left null when that profile is missing
-    for cand in (os.path.join(ROOT, "profiles", "r3", f"pmc_hbm_traffic_{wl.name}.json"),):
-        if wl.world == 1 and os.path.exists(cand):
+    # (NOT measured in this run: the key says so.  The newest round's record of this config wins.)
+    for cand in (os.path.join(ROOT, "profiles", "r4", f"pmc_hbm_traffic_{wl.name}.json"), os.path.join(ROOT, "profiles", "r3", f"pmc_hbm_traffic_{wl.name}.json")):
+        if wl.world == 1 and os.path.exists(cand) and roof["traffic"] is None:
             rec = json.load(open(cand))
             kk, k = next(((kk, v) for kk, v in rec.items() if wl.pmc_kernel in kk and isinstance(v, dict)), (None, None))
             if k:
                 roof["traffic"] = k["hbm_bytes_corrected"]
-                roof["traffic_source"] = ("%s (build %s): kernel %s, %s; FETCH_SIZE %.0f B raw (x2: gfx950 correction) + WRITE_SIZE %.0f B per launch, "
+                roof["traffic_from_committed_profile"] = ("%s (build %s): kernel %s, %s; FETCH_SIZE %.0f B raw (x2: gfx950 correction) + WRITE_SIZE %.0f B per launch, "
                                           "%d launches; against %.0f algorithmic bytes per launch (%.2f passes)"
                                           % (os.path.relpath(cand, ROOT), rec.get("_build", "unknown"), kk.replace("void icp::", ""), rec.get("_what", "one launch"),
                                              k["fetch_bytes_raw"], k["write_bytes"], k["launches"], alg_bytes * share * ppl, ppl))
@@ -664,7 +784,48 @@ def roofline_leg(wl, K, passes_full, region, stride):
     return roof
 
 
+def attach_route(pkg, ctx, ranks, route):
+    """the iteration's one sum over the ranks: 'local' = shared host memory (icp_comm_init_local), 'rccl' = the library-issued
+    ncclAllReduce (icp_comm_init).  Returns (route in force, reason it is not the one asked for or "")."""
+    use_dist = ranks.dist is not None or os.environ.get("ICP_BENCH_FORCE_DIST") == "1"
+    if not use_dist or route == "none":
+        return "none", ""
+    if route == "rccl":
+        ok, why = True, ""
+        try:
+            if ranks.dist:
+                pkg.distributed.attach_native_comm(ctx, ranks.dist)
+            else:
+                ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, f"{type(e).__name__}: {e}"
+        if ranks.min_int(1 if ok else 0) == 1:
+            return "rccl", ""
+        if ok:
+            ctx.comm_destroy()
+        why = why if not ok else "another rank could not create its communicator"
+        if not ranks.dist:
+            return "none", why
+        pkg.distributed.attach_local_comm(ctx, ranks.dist)
+        return "local", why
+    if ranks.dist:
+        pkg.distributed.attach_local_comm(ctx, ranks.dist)
+        return "local", ""
+    return "none", ""
+
+
+ROUTE_TEXT = {
+    "local": ("sum of the loop's moment vector (32 doubles, the 19 / 28 the metric uses travel) per iteration over the node's ranks through "
+              "shared host memory (icp_comm_init_local), rank order; every rank keeps its resident kernel"),
+    "rccl": ("ONE ncclAllReduce(sum, 32 doubles, in place) per iteration, issued by libicp_mi355x right behind the finalize kernel on the "
+             "loop's stream (icp_comm_init); one kernel launch per pass"),
+    "none": "none",
+}
+
+
 def leg_main(args, rank, local_rank, world):
+    """the measurement.  --brief: an auxiliary leg (another shard mode, another route, another config beside the line's own):
+    the timed regions only -- no roofline, no CPU baseline, no fresh pair."""
     import torch  # noqa: F401  (device synchronisation in the timed region)
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -672,13 +833,14 @@ def leg_main(args, rank, local_rank, world):
     K, W = args.steps, args.warmup
     wl = WORKLOADS[args.config](pkg, args, rank, local_rank, world)
     ctx = wl.ctx
-    use_dist = world > 1 or os.environ.get("ICP_BENCH_FORCE_DIST") == "1"
-    if ranks.dist:
-        pkg.distributed.attach_local_comm(ctx, ranks.dist)
+    brief = args.brief
+    sharded = args.config in ("hall", "s5")            # the configs whose ranks work on ONE cloud; the others run replicas
+    want = args.route or ("rccl" if (args.config == "s5" and world > 1) else "local")
+    route, route_note = attach_route(pkg, ctx, ranks, want if sharded else "none")
 
     passes_full = wl.sanity()
     first_us = None
-    if wl.name == "bunny":    # (a context's very first registration ran above: what it cost per iteration is a figure of its own)
+    if wl.name == "bunny" and not brief:    # (a context's very first registration ran above: what it cost per iteration is a figure of its own)
         t0 = time.perf_counter()
         k2 = wl.registration()
         first_us = 1e6 * (time.perf_counter() - t0) / max(1, k2)
@@ -690,40 +852,53 @@ def leg_main(args, rank, local_rank, world):
         if wl.regime == "fixed":
             warm = ctx.loop_timing()
             ctx.set_profiling(0)
-    # HIP events around the loop's kernel inside the timed region: s5 -- every launch is a pass of milliseconds; a resident
-    # kernel is a whole registration, so every 7th is timed when the region holds many of them (1-2 % of overhead) and a
+    # HIP events around the loop's kernel inside the timed regions: s5 -- every launch is a pass of milliseconds; a resident
+    # kernel is a whole registration, so every 7th is timed when a region holds many of them (1-2 % of overhead) and a
     # region of a few registrations is not bracketed at all (the two event records and the wait for the kernel's end would
     # be a tenth of what is being measured)
     regs_expected = max(1, K // max(1, passes_full))
     if wl.regime == "fixed":
-        stride = 1
+        stride = 0 if brief else 1
     else:
-        stride = 7 if regs_expected >= 70 else 0
-    dt, stats, sec1, cnt1, passes1 = timed_steps(wl, ranks, K, stride)
+        stride = 7 if (regs_expected >= 70 and not brief) else 0
+    dts, stats, sec1, cnt1, passes1 = timed_steps(wl, ranks, K, stride, args.repeats)
     st = ctx.loop_state()
     out = None
     if rank == 0:
-        n_rep = world if wl.scaling == "weak" else 1
+        rs = region_stats(dts, K)
+        replicas = world if not sharded else 1
         out = {
-            "metric": wl.metric_id, "value": n_rep * K / dt, "unit": "iterations/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K,
+            "metric": wl.metric_id, "value": rs["value"], "unit": "iterations/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": rs["ms_per_step"],
+            "ms_per_step_min": rs["ms_per_step_min"], "ms_per_step_max": rs["ms_per_step_max"], "repeats": rs["repeats"],
             "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": wl.dtype, "data": wl.data,
             "config": {"workload": wl.workload, "moving_points_per_gpu": wl.n, "model_points": wl.m,
-                       "global_moving_points": wl.n_global if wl.scaling == "strong" else wl.n * world,
+                       "global_moving_points": wl.n_global,
+                       "ranks_compute": ("ONE registration: the moving cloud is sharded over the ranks (%s), the model replicated" %
+                                         ("--shard strong: the config's own cloud split" if wl.scaling == "strong" else
+                                          "--shard weak: a whole config-sized shard per rank")) if (sharded and world > 1) else
+                                        ("%d independent replicas of the registration, nothing crosses ranks" % world if world > 1 else "one registration"),
+                       "what_value_is": "K / (median over `repeats` regions of: max over ranks of the time between barrier + synchronize on both sides "
+                                        "of EXACTLY K steps); an iteration rate for any N, never multiplied by the number of ranks",
                        "regime": ("one registration of `steps` fixed iterations from the initial pose (cold first pass)" if wl.regime == "fixed" else
                                   "back-to-back full registrations from the initial pose (cold first pass, tol %g, stop rule on); "
                                   "a step = one iteration of such a registration" % wl.tol),
                        "registrations_timed": stats["registrations"],
+                       "registrations_per_region": stats["registrations"] / rs["repeats"],
                        "iterations_per_registration": stats["iterations"] / max(1, stats["registrations"]),
                        "passes_of_a_full_registration": passes_full,
-                       "collective": ("sum of the loop's moment vector (32 doubles, the 19 / 28 the metric uses travel) per iteration over the node's "
-                                      "ranks through shared host memory (icp_comm_init_local), rank order; the RCCL route is measured beside it (`rccl`)")
-                                     if ranks.dist else "none"},
+                       "collective_route": route, "collective": ROUTE_TEXT[route]},
             "final_rms_error": float(st["err"][-1]) if wl.regime == "fixed" else wl.final_err,
         }
+        if route_note:
+            out["config"]["collective_route_note"] = "asked for the %s route: %s" % (want, route_note)
+        if replicas > 1:
+            out["aggregate_iterations_per_s"] = replicas * rs["value"]      # (the replicas' rates added up: whole-job throughput, not an iteration rate)
+        if sharded and world > 1:
+            out["aggregate_moving_point_iterations_per_s"] = float(wl.n_global) * rs["value"]
         if wl.name == "s5":
             out["config"]["set_up_ms_rank0"] = 1e3 * wl.setup_s
-            out["pairs_per_s_algorithmic"] = float(wl.n_global) * float(wl.m) * K / dt
+            out["pairs_per_s_algorithmic"] = float(wl.n_global) * float(wl.m) * rs["value"]
             out["rms_error_series_head"] = [float(e) for e in st["err"][:6]]
         if first_us is not None:
             out["config"]["second_registration_of_the_context_us_per_iteration"] = first_us
@@ -731,9 +906,16 @@ def leg_main(args, rank, local_rank, world):
             out["config"]["normals_on_device_ms"] = 1e3 * wl.normals_s
         if getattr(wl, "exclusive", False):
             out["config"]["exclusive_device"] = "icp_set_exclusive(ctx, 1): this process owns its GPU (16-wave blocks, one row of 64 points per CU)"
-    if ranks.dist:
+        if brief:
+            out = {k: out[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "repeats", "scaling", "final_rms_error")
+                   if k in out} | {"ranks": world, "us_per_iteration": 1e3 * rs["ms_per_step"], "route": route, "registrations_timed": stats["registrations"],
+                                   "moving_points_per_gpu": wl.n, "global_moving_points": wl.n_global, "model_points": wl.m, "steps": K,
+                                   **({"route_note": out["config"]["collective_route_note"]} if route_note else {}),
+                                   **({"aggregate_moving_point_iterations_per_s": out["aggregate_moving_point_iterations_per_s"]} if "aggregate_moving_point_iterations_per_s" in out else {}),
+                                   **({"set_up_ms_rank0": 1e3 * wl.setup_s, "rms_error_series_head": out["rms_error_series_head"]} if wl.name == "s5" else {})}
+    if route != "none":
         ctx.comm_destroy()     # rank 0 measures its roofline leg alone: no communicator may wait for the others
-    if rank == 0:
+    if rank == 0 and not brief:
         region = None
         if cnt1 > 0:
             region = {"launches_timed": cnt1, "avg_launch_us": 1e6 * sec1 / cnt1, "passes_per_launch": passes1 / cnt1}
@@ -744,57 +926,17 @@ def leg_main(args, rank, local_rank, world):
             out["roofline"]["all_launches_incl_warmup"] = {"launches": warm[1] + cnt1, "avg_launch_us": 1e6 * (warm[0] + sec1) / (warm[1] + cnt1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
-    # the RCCL leg runs in a process of its own (the supervisor starts it): agree on its port here
-    port = 0
-    if use_dist and args.config in ("hall", "s5") and not args.no_rccl:
-        port = ranks.max_int(free_port() if rank == 0 else 0)
+        if world == 1 and not args.no_fresh_pair:
+            out.update(wl.fresh_pair())
+    # the auxiliary legs run in processes of their own (the supervisor starts them): agree on their ports here
+    ports = []
+    if not brief:
+        for _ in range(4):
+            ports.append(ranks.max_int(free_port() if rank == 0 else 0))
     ranks.barrier()
     ctx.close()
     ranks.close()
-    return out, {"rccl_port": port}
-
-
-# ======================================================================================================================
-# --leg rccl: the same K steps with the iteration's collective done by RCCL (library-issued ncclAllReduce)
-# ======================================================================================================================
-def leg_rccl(args, rank, local_rank, world):
-    import torch  # noqa: F401
-    from __graft_entry__ import load_package
-    pkg = load_package()
-    ranks = Ranks(rank, world)
-    K, W = args.steps, args.warmup
-    wl = WORKLOADS[args.config](pkg, args, rank, local_rank, world)
-    ctx = wl.ctx
-    rccl = {"route": "icp_comm_init: ONE ncclAllReduce(sum, 32 doubles, in place) per iteration, issued by libicp_mi355x right behind the "
-                     "finalize kernel on the loop's stream; one kernel launch per pass (no resident kernel)",
-            "ranks": world}
-    ok, why = True, ""
-    try:
-        if ranks.dist:
-            pkg.distributed.attach_native_comm(ctx, ranks.dist)
-        else:
-            ctx.comm_init(ctx.comm_unique_id(), 0, 1)
-    except Exception as e:  # noqa: BLE001
-        ok, why = False, f"{type(e).__name__}: {e}"
-    all_ok = ranks.min_int(1 if ok else 0) == 1
-    if all_ok:
-        wl.sanity()
-        if W > 0:
-            wl.run_steps(min(W, 50))
-        dt, stats, _, _, _ = timed_steps(wl, ranks, K, 0)
-        st = ctx.loop_state()
-        n_rep = world if wl.scaling == "weak" else 1
-        rccl.update({"value": n_rep * K / dt, "unit": "iterations/s", "us_per_iteration": 1e6 * dt / K,
-                     "registrations_timed": stats["registrations"],
-                     "final_rms_error": float(st["err"][-1]) if wl.regime == "fixed" else wl.final_err})
-    else:
-        rccl["error"] = why if not ok else "another rank could not create its communicator"
-    if ok:
-        ctx.comm_destroy()
-    ranks.barrier()
-    ctx.close()
-    ranks.close()
-    return (rccl if rank == 0 else None), {}
+    return out, {"ports": ports}
 
 
 # ======================================================================================================================
@@ -817,11 +959,12 @@ def spawn_ranks(n):
     return bad[0] if bad else 0
 
 
-def run_leg(leg, argv, env, timeout):
-    """one leg in a fresh child process; (rc or None when it had to be killed, its stdout, the side record it left)"""
+def run_leg(leg, argv, env, timeout, extra=()):
+    """one leg in a fresh child process; (rc or None when it had to be killed, its stdout, the side record it left).
+    `extra`: options of an auxiliary leg (they follow the caller's, so they win)"""
     fd, side = tempfile.mkstemp(prefix="icp_bench_", suffix=".json")
     os.close(fd)
-    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--leg", leg, "--side-file", side]
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + list(extra) + ["--leg", leg, "--side-file", side]
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
     try:
         out, _ = p.communicate(timeout=timeout)
@@ -864,6 +1007,7 @@ def supervise(args, argv):
     env = dict(os.environ)
     t_main = float(os.environ.get("ICP_BENCH_TIMEOUT", "2400"))
     t_rccl = float(os.environ.get("ICP_BENCH_RCCL_TIMEOUT", "240"))
+    t_aux = float(os.environ.get("ICP_BENCH_AUX_TIMEOUT", "600"))
     rc, text, side = run_leg("main", argv, env, t_main)
     line = last_json_line(text) if rank == 0 else None
     if rc is None:
@@ -872,26 +1016,42 @@ def supervise(args, argv):
     if rc != 0:
         return rc
     exit_code = 0
-    port = int(side.get("rccl_port", 0) or 0)
-    if port:
+    ports = [int(x) for x in (side.get("ports") or [])]
+    dist = world > 1 or os.environ.get("ICP_BENCH_FORCE_DIST") == "1"
+    # the auxiliary legs: (key of the line, options, time limit, does a failure fail the run?)
+    aux = []
+    if dist and args.config == "hall" and not args.no_rccl:
+        aux.append(("rccl", ["--brief", "--route", "rccl"], t_rccl, True))
+    if dist and args.config == "s5" and not args.no_rccl:
+        # (the line's own value is on the RCCL route; world == 1 under ICP_BENCH_FORCE_DIST: the line ran without a communicator)
+        aux.append(("local" if world > 1 else "rccl", ["--brief", "--route", "local" if world > 1 else "rccl"], t_rccl, True))
+    if world > 1 and args.config == "hall" and args.shard == "strong":
+        aux.append(("weak_shards", ["--brief", "--shard", "weak", "--route", "local"], t_aux, False))
+    if args.config == "hall" and not args.no_s5 and not os.environ.get("ICP_BENCH_NO_S5"):
+        aux.append(("s5", ["--brief", "--config", "s5", "--steps", "30", "--warmup", "5", "--repeats", "3"] + (["--route", "rccl"] if world > 1 else []), t_aux, False))
+    for n_aux, (key, extra, limit, fatal) in enumerate(aux):
+        if n_aux >= len(ports) or not ports[n_aux]:
+            break
         # (a rendezvous of its own on the agreed port: under torch.distributed.run the ranks would otherwise look for the
         # launcher's store there, which lives on the launcher's port)
-        env2 = dict(env, MASTER_PORT=str(port), MASTER_ADDR=env.get("MASTER_ADDR", "127.0.0.1"), TORCHELASTIC_USE_AGENT_STORE="False")
-        rc2, text2, _ = run_leg("rccl", argv, env2, t_rccl)
-        rccl = last_json_line(text2) if rank == 0 else None
+        env2 = dict(env, MASTER_PORT=str(ports[n_aux]), MASTER_ADDR=env.get("MASTER_ADDR", "127.0.0.1"), TORCHELASTIC_USE_AGENT_STORE="False")
+        rc2, text2, _ = run_leg("main", argv, env2, limit, extra)
+        rec = last_json_line(text2) if rank == 0 else None
         if rc2 is None:
-            rccl = {"ranks": world, "error": f"no answer within {t_rccl:.0f} s: the process was killed (a stuck communicator?)", "hung": True}
+            rec = {"ranks": world, "error": f"no answer within {limit:.0f} s: the process was killed (a stuck communicator?)", "hung": True}
             exit_code = 3
         elif rc2 != 0:
-            rccl = {"ranks": world, "error": f"the RCCL leg ended with exit code {rc2}"}
-            exit_code = 4
-        elif rank == 0 and rccl is None:
-            rccl = {"ranks": world, "error": "the RCCL leg printed no record"}
-            exit_code = 4
-        # (a communicator that REFUSES -- RCCL does for two ranks rehearsed on one device -- says so in the record: the line's
-        # `value` does not depend on that leg, and nothing is left hanging, so the run itself has not failed)
+            rec = {"ranks": world, "error": f"the leg ended with exit code {rc2}"}
+            exit_code = 4 if fatal else exit_code
+        elif rank == 0 and rec is None:
+            rec = {"ranks": world, "error": "the leg printed no record"}
+            exit_code = 4 if fatal else exit_code
+        elif rank == 0 and key == "rccl" and rec.get("route") != "rccl":
+            # (a communicator that REFUSES -- RCCL does for two ranks rehearsed on one device -- says so in the record: the line's
+            # `value` does not depend on that leg, and nothing is left hanging, so the run itself has not failed)
+            rec = {"ranks": world, "error": rec.get("route_note", "the RCCL communicator could not be created")}
         if line is not None:
-            line["rccl"] = rccl
+            line[key] = rec
     if rank == 0:
         if line is None:
             sys.stderr.write("[bench] the measuring process printed no line\n")
@@ -909,8 +1069,15 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000, help="s5: size of the synthetic cloud")
     ap.add_argument("--width", type=int, default=32, help="cpu_f64: WIDTH of the synthetic grid (src/ICP_CPU.c ships 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-rccl", action="store_true", help="N > 1: skip the RCCL leg")
-    ap.add_argument("--leg", choices=("main", "rccl"), default=None, help="(internal) run this leg in this process")
+    ap.add_argument("--no-rccl", action="store_true", help="N > 1: skip the leg that measures the other route")
+    ap.add_argument("--shard", choices=("strong", "weak"), default="strong",
+                    help="hall, N > 1: strong = the 16 384 moving points split over the ranks (north_star); weak = a hall-sized shard per rank")
+    ap.add_argument("--repeats", type=int, default=None, help="repeats of the K-step region (default: >= 25 for short regions, see timed_steps)")
+    ap.add_argument("--no-s5", action="store_true", help="hall: skip the brief configs[4] leg beside the line")
+    ap.add_argument("--no-fresh-pair", action="store_true")
+    ap.add_argument("--route", choices=("local", "rccl", "none"), default=None, help="(internal) the iteration's sum over the ranks")
+    ap.add_argument("--brief", action="store_true", help="(internal) an auxiliary leg: timed regions only")
+    ap.add_argument("--leg", choices=("main",), default=None, help="(internal) run the measurement in this process")
     ap.add_argument("--side-file", default=None, help="(internal)")
     args = ap.parse_args()
     if args.steps is None:
@@ -937,7 +1104,7 @@ def main():
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    out, side = (leg_main if args.leg == "main" else leg_rccl)(args, rank, local_rank, world)
+    out, side = leg_main(args, rank, local_rank, world)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)

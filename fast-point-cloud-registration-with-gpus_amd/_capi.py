@@ -1,4 +1,4 @@
-"""ctypes binding of libicp_mi355x.so -- exactly the symbols include/icp_mi355x.h declares.
+"""ctypes binding of libicp_mi355x.so -- exactly the symbols include/icp_mi355x.h and include/icp_mi355x_diag.h declare.
 
 This is the stub a maintainer of a Python host would write; it contains no
 arithmetic.  Loading fails loudly when the shared library has not been built: there is no
@@ -34,13 +34,14 @@ class icp_params(C.Structure):
 class icp_result(C.Structure):
     _fields_ = [("T", C.c_double * 16), ("iterations", C.c_int), ("passes", C.c_int),
                 ("err", C.POINTER(C.c_double)), ("idx", C.POINTER(C.c_int32)), ("moved", C.c_void_p),
-                ("seconds_total", C.c_double), ("seconds_nn", C.c_double)]
+                ("seconds_total", C.c_double), ("seconds_nn", C.c_double),
+                ("seconds_host", C.c_double), ("seconds_setup", C.c_double)]
 
 
 _vp, _i, _pi = C.c_void_p, C.c_int, C.POINTER(C.c_int)
 _pd, _pf, _pi32, _pu32 = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
 
-# name -> (restype, argtypes); every symbol of include/icp_mi355x.h, in header order
+# name -> (restype, argtypes); every symbol of include/icp_mi355x.h and include/icp_mi355x_diag.h
 SIGNATURES = {
     "icp_abi_version": (_i, []),
     "icp_strerror": (C.c_char_p, [_i]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     "icp_loop_state": (_i, [_vp, _pi, _pi, _pd, _i, _pd]),
     "icp_loop_timing": (_i, [_vp, _pd, _pi]),
     "icp_loop_timing_passes": (_i, [_vp, C.POINTER(C.c_longlong)]),
+    "icp_loop_phase_seconds": (_i, [_vp, _pd, _pd]),
     "icp_loop_indices": (_i, [_vp, _vp]),
     "icp_comm_unique_id": (_i, [_vp]),
     "icp_comm_init": (_i, [_vp, _vp, _i, _i]),
@@ -135,8 +137,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.icp_abi_version() != 1:
-        raise ImportError("libicp_mi355x.so ABI version mismatch")
+    ABI = 2
+    if lib.icp_abi_version() != ABI and not os.environ.get("ICP_LIB_PATH"):   # (an older build loaded for an A/B run has the shorter icp_result: nothing reads the new tail)
+        raise ImportError(f"libicp_mi355x.so ABI version {lib.icp_abi_version()}, this stub binds version {ABI}")
     _lib = lib
     return lib
 

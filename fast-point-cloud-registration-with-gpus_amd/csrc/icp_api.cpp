@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/icp_mi355x.h"
+#include "../../include/icp_mi355x_diag.h"
 #include "icp_comm.h"
 #include "icp_lcomm.h"
 #include "icp_host_loop.h"
@@ -221,8 +222,10 @@ struct LoopState {
     int applied_idx = 0;    // idx buffer used by the last applied transform
     int mom_blocks = 0, err_blocks = 0;
     double seconds_nn = 0.0;
+    double seconds_host = 0.0;  // host half of the passes (error, stop rule, solve), summed while profiling is on
     int nn_launches = 0;
     bool timed_nn = false;
+    bool numeric_failure = false;  // the minimisation refused the last pass's moments: the loop is over, its state stays readable
     bool host_reduce = false;  // how the pending enqueue's partial rows are being reduced
     bool matched = false;      // a matching pass of THIS loop has filled idx[cur]
     bool rows_have_err = false; // slot 0 of the pending moment rows carries the error shares (fused tail)
@@ -502,9 +505,10 @@ int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision,
     // the staging buffer is reused by the next upload: order them on the stream, and make sure the
     // pageable host source has been consumed before returning
     HIP_TRY(hipStreamSynchronize(c->stream));
-    // Non-finite coordinates are refused (include/icp_mi355x.h, "Non-finite input").  The reference has no defined answer
-    // for them: src/ICP_CPU.c:232's `c == 0 || d < best` leaves a NaN point at index 0, and its centroid sums (:342-366)
-    // then turn the whole transform into NaN -- nothing a caller could use, and the pruned search has no bound to go by.
+    // Non-finite coordinates are refused (include/icp_mi355x.h, "non-finite input": a deliberate deviation).  The reference
+    // does not look at its input: the match of such a point is whatever cblas_idamin (src/ICP_CPU.c:232) answers for a vector
+    // that holds NaN -- MKL documents nothing -- and the centroid sums (:342-366) then turn the whole transform into NaN:
+    // nothing a caller could use, and the pruned search has no bound to go by.
     if (const unsigned int bad = *(volatile unsigned int*)c->h_nonfinite) {
         char msg[160];
         std::snprintf(msg, sizeof msg, "%u of the %d points have a NaN or infinite coordinate: non-finite input is refused", bad, count);
@@ -848,6 +852,10 @@ int icp_comm_init_local(icp_ctx* c, const void* id_bytes, int rank, int world)
     if (!id_bytes || world < 1 || rank < 0 || rank >= world) return fail(ICP_ERR_INVALID, "bad communicator arguments");
     if (c->loop.pending) return fail(ICP_ERR_STATE, "an enqueue is in flight");
     if (c->comm) return fail(ICP_ERR_STATE, "a device communicator is attached: destroy it first");
+    // (a caller that installed its own moments buffer sums it across ranks itself, between enqueue and complete: with the node
+    // communicator on top the vector would be summed twice -- the advisor's finding on round 3)
+    if (c->mom_dev != nullptr && c->mom_dev != (double*)c->mom_own.p)
+        return fail(ICP_ERR_STATE, "an external moments buffer is installed (icp_loop_set_moments_dev): its owner reduces it; remove it first");
     if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
     std::string err;
     const int rc = icp::lcomm_create(id_bytes, rank, world, &c->lcomm, err);
@@ -1559,6 +1567,9 @@ int icp_loop_set_moments_dev(icp_ctx* c, void* dev_ptr)
         HIP_TRY(c->mom_own.ensure(ICP_NMOM * sizeof(double)));
         c->mom_dev = (double*)c->mom_own.p;
     } else {
+        // (whoever owns the buffer reduces it across ranks; a library-side exchange on top would add the ranks up twice)
+        if (c->lcomm) return fail(ICP_ERR_STATE, "a node communicator is attached (icp_comm_init_local): the library exchanges the vector itself");
+        if (c->comm) return fail(ICP_ERR_STATE, "a device communicator is attached (icp_comm_init): the library all-reduces its own vector");
         c->mom_dev = (double*)dev_ptr;
     }
     return ICP_OK;
@@ -1746,15 +1757,20 @@ static int loop_complete_body(icp_ctx* c, int* done)
         c->prof_nn_launches += 1;
         c->prof_nn_passes += 1;
     }
-    if (c->lcomm) {  // the node's ranks exchange their sums (rank order: identical on every rank)
+    if (c->lcomm && c->mom_dev == (double*)c->mom_own.p) {  // the node's ranks exchange their sums (rank order: identical on every rank)
         std::string err;
         // (only the entries the metric uses travel: 19 doubles = 3 cache lines per slot instead of 5)
         const int used = L.H.prm.metric == ICP_POINT_TO_PLANE ? ICP_MOM_B + 6 : ICP_MOM_SQQ + 1;
         if (int rc = icp::lcomm_allreduce_sum_f64(c->lcomm, c->h_mom, used, err)) return fail(rc, err);
     }
+    // (the host half of a pass is timed only while profiling is on: two clock reads are 0.5 % of a 9 us iteration)
+    const bool time_host = c->profile_stride > 0;
+    const auto th0 = time_host ? std::chrono::steady_clock::now() : tr2;
     const int adv = L.H.advance(c->h_mom);
+    if (time_host) L.seconds_host += std::chrono::duration<double>(std::chrono::steady_clock::now() - th0).count();
     if (adv != ICP_OK) {
         if (done) *done = 1;
+        L.numeric_failure = true;   // (the loop is over; what its completed passes produced stays readable: icp_loop_state)
         return fail(adv, "minimisation failed (degenerate correspondences)");
     }
     if (c->trace) {
@@ -2026,7 +2042,12 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     }
     if (alive) send(icp::ICP_CMD_EXIT, base + (double)sent);
     L.live_mailbox = nullptr;
-    if (rc != ICP_OK) {
+    if (rc != ICP_OK && L.numeric_failure) {
+        // the pass completed on the device and the MINIMISATION refused its sums: the kernel has been told to exit, the cloud
+        // is in the state the last applied transform left, the loop's counters and error series stay readable
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+    } else if (rc != ICP_OK) {
         // a pass did not complete: blocks may have applied its transform to their part of the cloud and others not.
         // Nothing of that state is offered to the caller: the loop is over, the moving cloud goes back to what
         // icp_set_moving uploaded (materialised from the pristine copy on its next use), the matches are void.
@@ -2098,10 +2119,17 @@ int icp_loop_run(icp_ctx* c, int max_steps, int* steps_done, int* done)
     const icp_params prm = c->loop.H.prm;
     const long long steps_before = c->loop.steps;
     c->rows_timed_out = false;
+    // (should the registration have to be run again, the aborted attempt's share of the profiling and trace totals is taken back)
+    const double keep_nn = c->prof_seconds_nn, keep_tr[4] = {c->tr_enqueue, c->tr_wait, c->tr_reduce, c->tr_solve};
+    const int keep_launches = c->prof_nn_launches;
+    const long long keep_passes = c->prof_nn_passes;
+    const uint64_t keep_tr_n = c->tr_n;
     int k = 0, d = 0;
     int rc = loop_run_inner(c, max_steps, &k, &d);
     if (rc == ICP_ERR_HIP && c->rows_timed_out && can_redo) {
         const std::string first = g_last_error;
+        c->prof_seconds_nn = keep_nn; c->prof_nn_launches = keep_launches; c->prof_nn_passes = keep_passes;
+        c->tr_enqueue = keep_tr[0]; c->tr_wait = keep_tr[1]; c->tr_reduce = keep_tr[2]; c->tr_solve = keep_tr[3]; c->tr_n = keep_tr_n;
         if (c->trace) std::fprintf(stderr, "[icp trace] %s -- running the registration again step-wise\n", first.c_str());
         c->loop.active = false;
         c->loop.pending = false;
@@ -2137,13 +2165,16 @@ static int loop_run_inner(icp_ctx* c, int max_steps, int* k_out, int* d_out)
             if (int rc = loop_arm(c)) return rc;
         if (int rc = loop_complete_body(c, &d)) {
             loop_withdraw_armed(c);
-            // (as after a failed resident pass: nothing half-transformed is offered to the caller)
             (void)hipStreamSynchronize(c->stream);
             (void)hipGetLastError();
-            c->moving_is_pristine = true;
-            c->idx_valid = false;
-            c->loop.active = false;
-            c->loop.pending = false;
+            if (!c->loop.numeric_failure) {
+                // (as after a failed resident pass: nothing half-transformed is offered to the caller; a numeric failure -- the
+                // minimisation refused the sums of a pass that completed -- leaves the loop's state readable instead)
+                c->moving_is_pristine = true;
+                c->idx_valid = false;
+                c->loop.active = false;
+                c->loop.pending = false;
+            }
             return rc;
         }
         if (c->loop.armed) {
@@ -2187,6 +2218,14 @@ int icp_loop_timing(icp_ctx* c, double* seconds_nn, int* nn_launches)
     return ICP_OK;
 }
 
+int icp_loop_phase_seconds(icp_ctx* c, double* seconds_nn, double* seconds_host)
+{
+    if (!c) return fail(ICP_ERR_INVALID, "null context");
+    if (seconds_nn) *seconds_nn = c->loop.seconds_nn;
+    if (seconds_host) *seconds_host = c->loop.seconds_host;
+    return ICP_OK;
+}
+
 int icp_loop_timing_passes(icp_ctx* c, long long* passes)
 {
     if (!c || !passes) return fail(ICP_ERR_INVALID, "null argument");
@@ -2201,7 +2240,7 @@ int icp_loop_indices(icp_ctx* c, int32_t* out)
     return download_idx(c, c->loop.H.applied > 0 ? c->loop.applied_idx : c->cur, out);
 }
 
-static int run_loop(icp_ctx* c, const icp_params* prm, icp_result* out)
+static int run_loop(icp_ctx* c, const icp_params* prm, icp_result* out, double seconds_setup)
 {
     ScopedPin pin(c);
     if (int rc = icp_loop_begin(c, prm)) return rc;
@@ -2217,6 +2256,8 @@ static int run_loop(icp_ctx* c, const icp_params* prm, icp_result* out)
         out->passes = L.H.applied;
         out->seconds_total = std::chrono::duration<double>(t1 - t0).count();
         out->seconds_nn = L.seconds_nn;
+        out->seconds_host = L.seconds_host;
+        out->seconds_setup = seconds_setup;
         if (out->err)
             for (size_t i = 0; i < L.H.err.size(); ++i) out->err[i] = L.H.err[i];
         if (out->idx)
@@ -2236,9 +2277,10 @@ int icp_point_to_point(icp_ctx* c, const void* data, int n, const void* model, i
     if (m <= 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
     icp_params p = *prm;
     p.metric = ICP_POINT_TO_POINT;
+    const auto s0 = std::chrono::steady_clock::now();
     if (int rc = icp_set_model(c, model, m, p.precision)) return rc;
     if (int rc = icp_set_moving(c, data, n, p.precision)) return rc;
-    return run_loop(c, &p, out);
+    return run_loop(c, &p, out, std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count());
 }
 
 int icp_point_to_plane(icp_ctx* c, const void* data, int n, const void* model, int m, const void* normals,
@@ -2250,6 +2292,7 @@ int icp_point_to_plane(icp_ctx* c, const void* data, int n, const void* model, i
     if (m <= 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
     icp_params p = *prm;
     p.metric = ICP_POINT_TO_PLANE;
+    const auto s0 = std::chrono::steady_clock::now();
     if (int rc = icp_set_model(c, model, m, p.precision)) return rc;
     if (normals) {
         if (int rc = icp_set_model_normals(c, normals, m)) return rc;
@@ -2257,7 +2300,7 @@ int icp_point_to_plane(icp_ctx* c, const void* data, int n, const void* model, i
         if (int rc = icp_estimate_normals(c, nullptr, nullptr)) return rc;
     }
     if (int rc = icp_set_moving(c, data, n, p.precision)) return rc;
-    return run_loop(c, &p, out);
+    return run_loop(c, &p, out, std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count());
 }
 
 int icp_os1_packets_to_cartesian(icp_ctx* c, const uint8_t* packets, int n_packets, const float alt16[16],

@@ -29,6 +29,8 @@ class Result:
     moved: np.ndarray        # (N, 3) final moving cloud
     seconds_total: float = 0.0
     seconds_nn: float = 0.0
+    seconds_host: float = 0.0    # host half of the iterations (error, stop rule, solve), summed; 0 unless profiling is on
+    seconds_setup: float = 0.0   # icp_set_model (+ normals) + icp_set_moving inside the call
     extra: dict = field(default_factory=dict)
 
 
@@ -226,7 +228,8 @@ class Context:
         self._dtype, self._n, self._m = D.dtype, n, m
         return Result(T=np.array(res.T[:], dtype=np.float64).reshape(4, 4), iterations=res.iterations,
                       passes=res.passes, err=err[: res.passes + 1].copy(), idx=idx, moved=moved,
-                      seconds_total=res.seconds_total, seconds_nn=res.seconds_nn)
+                      seconds_total=res.seconds_total, seconds_nn=res.seconds_nn,
+                      seconds_host=res.seconds_host, seconds_setup=res.seconds_setup)
 
     def point_to_point(self, D, M, max_iter=40, tol=1e-6, fixed_iterations=False):
         return self._run(capi.ICP_POINT_TO_POINT, D, M, None, max_iter, tol, fixed_iterations)
@@ -276,6 +279,12 @@ class Context:
         sec, cnt = C.c_double(0), C.c_int(0)
         capi.check(self._lib.icp_loop_timing(self._h, C.byref(sec), C.byref(cnt)), "icp_loop_timing")
         return sec.value, cnt.value
+
+    def loop_phase_seconds(self):
+        """(matching-kernel seconds, host-solve seconds) of the current / last loop; both 0 unless profiling is on"""
+        a, b = C.c_double(0), C.c_double(0)
+        capi.check(self._lib.icp_loop_phase_seconds(self._h, C.byref(a), C.byref(b)), "icp_loop_phase_seconds")
+        return a.value, b.value
 
     def loop_timing_passes(self):
         n = C.c_longlong(0)

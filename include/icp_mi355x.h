@@ -15,11 +15,13 @@
  *     distance (dx*dx + dy*dy) + dz*dz with every operation rounded separately (no FMA), the
  *     LOWEST model index wins ties, every idx[i] is always written.
  *   - rotation matrices are row-major 3x3 (R maps moving -> model), transforms row-major 4x4.
- *   - non-finite input: a cloud (or normal set) with a NaN or an infinite coordinate is REFUSED -- icp_set_model,
- *     icp_set_moving, icp_set_model_normals and everything built on them (icp_nn_match_*, icp_point_to_*) return
- *     ICP_ERR_INVALID and the context keeps no such cloud.  The reference has no usable answer for such input:
- *     src/ICP_CPU.c:232 (`c == 0 || d < best`) leaves a NaN point at index 0, after which its centroid sums
- *     (:342-366) make the whole transform NaN.
+ *   - non-finite input -- a DELIBERATE DEVIATION from the reference, listed in INTEGRATION.md under "entry points that change
+ *     behaviour": a cloud (or normal set) with a NaN or an infinite coordinate is REFUSED -- icp_set_model, icp_set_moving,
+ *     icp_set_model_normals and everything built on them (icp_nn_match_*, icp_point_to_*) return ICP_ERR_INVALID and the
+ *     context keeps no such cloud.  The reference does not check its input: its distances come from vdSub / vdSqr / vdAdd
+ *     (src/ICP_CPU.c:227-231) and the match from cblas_idamin (:232), whose answer for a vector that holds NaN is whatever
+ *     the BLAS at hand does (MKL documents none); whichever index comes back, the centroid sums (:342-366) then turn the
+ *     whole transform into NaN.  There is nothing usable to reproduce, so the library says so at the door.
  *   - a context is bound to one HIP device; calls on one context are not re-entrant, distinct
  *     contexts are independent.  Every device entry point fails with ICP_ERR_NO_DEVICE when no
  *     gfx950 device is usable -- there is no CPU fallback.
@@ -34,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ICP_ABI_VERSION 1
+#define ICP_ABI_VERSION 2 /* 2: icp_result gained seconds_host / seconds_setup, icp_loop_phase_seconds */
 
 /* return codes */
 #define ICP_OK 0
@@ -82,6 +84,11 @@ typedef struct icp_result {
     void* moved;         /* caller-allocated 3n values of the run's precision, AoS (or NULL): final moving cloud */
     double seconds_total;   /* wall-clock of the loop (upload/download excluded) */
     double seconds_nn;      /* device time of the matching kernels, summed (0 unless profiling enabled) */
+    /* per-phase seconds (the reference's match_time / minimization_time / transf_time / error_time,
+     * src/CUDA/GPU_point_to_point_real.cu:241,386-403).  Transformation and error estimation have no time of their own
+     * here: they are the front end of the matching kernel (same launch) and are inside seconds_nn. */
+    double seconds_host;    /* host half of the iterations, summed: error + stop rule + 3x3 SVD / 6x6 solve (0 unless profiling enabled) */
+    double seconds_setup;   /* icp_point_to_*: icp_set_model (+ normals) + icp_set_moving of this call -- upload, layout, order, boxes */
 } icp_result;
 
 /* ---- library / context ------------------------------------------------------------------- */
@@ -128,40 +135,15 @@ int icp_get_indices(icp_ctx* ctx, int32_t* idx_out);        /* n int32: the most
 /* one matching pass over the resident clouds; indices stay on the device.  kernel_ms (optional)
  * receives the hipEvent time of the matching kernel(s) alone. */
 int icp_nn_match_resident(icp_ctx* ctx, float* kernel_ms);
-/* `reps` back-to-back launches of the matching kernel alone between two hipEvents on the context's
- * stream; total_ms / reps is the kernel's average launch duration (bench.py roofline leg) */
-int icp_nn_match_bench(icp_ctx* ctx, int reps, float* total_ms);
-/* same; seeded != 0 hands the kernel the most recent correspondences as its starting bound (what the ICP
- * loop does from its second pass on), seeded == 0 starts it cold (what icp_nn_match_* does) */
-int icp_nn_match_bench_ex(icp_ctx* ctx, int reps, int seeded, float* total_ms);
-/* The reference's own kernel-timing method (src/CUDA/Matching_opt.cu:213-226: cudaEventRecord around every launch,
- * minimum of 10 after warm-up): `warmups` untimed launches, then `reps` launches with a hipEvent pair around each one;
- * each_ms[r] receives the duration of launch r.  mode 0: the matching kernel as the loop launches it (seeded with the
- * most recent correspondences), 1: cold (no seed), 2: the dense packed kernel, which EXECUTES every one of the
- * n_pad x m_pad pairs (fp32 only; no boxes, no early-out) -- the brute-force scan the roofline arithmetic is about. */
-int icp_nn_match_bench_launches(icp_ctx* ctx, int reps, int warmups, int mode, float* each_ms);
-/* geometry of the last matching launch, for the roofline arithmetic in bench.py */
+/* geometry of the last matching launch (the programs print it as the reference prints its Grid Size / Block Size,
+ * src/CUDA/GPU_point_to_point_real.cu:237) */
 int icp_nn_launch_info(icp_ctx* ctx, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad);
-/* ... of the launch the resident clouds get from the production plan (dense == 0) or from the dense packed kernel */
-int icp_nn_launch_info_ex(icp_ctx* ctx, int dense, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad);
-/* Executed-work accounting of the sparse matching kernel (it returns the brute-force answer of Matching<<<>>> without
- * evaluating most pairs, so the roofline of EXECUTED arithmetic needs a count).  enable != 0: every following sparse
- * launch of this context runs its instrumented instantiation and adds wave-level tallies to 8 device counters;
- * icp_get_work_counters reads them (uint64 x ICP_WORK_SLOTS) and optionally zeroes them.  Slots:
- *   0 chunk boxes tested against a block's group box (one lane each)      1 upper-level boxes (large models)
- *   2 hits = (wave, 8-point chunk) pairs through the per-point box test   3 ... through the xy half of the distances
- *   4 ... evaluated in full (each hit: 64 lanes x 2 moving points x 8 model points)
- *   5 cold-start sample groups scanned (128 x 8 pairs each)   6 (block, pass) pairs   7 ... that applied a transform
- * Timing with counting on is not representative (atomics, extra registers): count in a separate run. */
-#define ICP_WORK_SLOTS 12 /* 8..11: speculative lists entered / that covered the pass / their hits / hits of ordinarily built lists */
 /* The caller owns the device (no other context of this or any other process keeps kernels resident on it): clouds of up to
  * 16 384 moving points (one row of 64 per CU) then run their rows as 16-wave blocks, one to a CU, instead of 8-wave blocks that
  * leave room for a second resident context -- hall pair 9.5 -> 9.15 us per iteration (profiles/r2/r2_02_waves_8_vs_16.txt).
  * The results are the same bits.  Off by default: the library cannot see who else is on the device.  (The reference's
  * programs own their GPU implicitly, src/ICP_point_to_point.cu:90.) */
 int icp_set_exclusive(icp_ctx* ctx, int on);
-int icp_set_work_counting(icp_ctx* ctx, int enable);
-int icp_get_work_counters(icp_ctx* ctx, uint64_t* out_slots, int reset);
 
 /* ---- model normals: replaces knn + Normals + host ssyev loop
  *      src/CUDA/GPU_point_to_plane_real.cu:54-188,391-423 (k = 4 neighbours, self excluded).
@@ -201,7 +183,11 @@ int icp_loop_run(icp_ctx* ctx, int max_steps, int* steps_done, int* done);
  * only if that fails as well.  icp_recoveries: how often this context has done so (the reference's loops,
  * src/ICP_point_to_point.cu:308-421, are plain launches throughout and have nothing to recover from). */
 int icp_recoveries(icp_ctx* ctx);
-/* current state: iterations so far, error series (count doubles), composed transform */
+/* current state: iterations so far, error series (count doubles), composed transform.
+ * After a FAILED icp_loop_run / icp_loop_complete: a numeric failure (degenerate correspondences: ICP_ERR_SINGULAR /
+ * ICP_ERR_INVALID from the minimisation) ends the loop but keeps its state readable -- this call, icp_loop_indices and
+ * icp_get_moving answer for the passes that completed.  A device failure (ICP_ERR_HIP, a pass that never delivered its rows)
+ * discards the loop: this call then returns ICP_ERR_STATE and icp_get_moving the cloud as icp_set_moving uploaded it. */
 int icp_loop_state(icp_ctx* ctx, int* iterations, int* passes, double* err, int err_cap, double* T16);
 /* summed hipEvent time and count of the matching-kernel launches timed since icp_set_profiling was last called
  * (cumulative over loops; the bench's roofline leg reads the timed region through this) */
@@ -210,6 +196,9 @@ int icp_loop_timing(icp_ctx* ctx, double* seconds_nn, int* nn_launches);
  * when icp_loop_run keeps ONE resident kernel for a whole registration (that kernel is then the timed launch, every
  * n-th one, host round trips between its passes included) */
 int icp_loop_timing_passes(icp_ctx* ctx, long long* passes);
+/* the current (or last) loop's own phase sums: matching-kernel seconds and host-solve seconds, as icp_result reports them
+ * (both 0 unless icp_set_profiling is on); either pointer may be NULL */
+int icp_loop_phase_seconds(icp_ctx* ctx, double* seconds_nn, double* seconds_host);
 /* correspondences of the last pass that contributed to T (ping-pong buffer), n int32 */
 int icp_loop_indices(icp_ctx* ctx, int32_t* idx_out);
 
@@ -258,11 +247,6 @@ int icp_host_loop_note_applied(icp_host_loop* h);
 int icp_host_loop_state(icp_host_loop* h, int* iterations, int* passes, double* err, int err_cap, double* T16);
 /* contiguous shard [begin, begin+count) of n moving points for `rank` of `world` */
 int icp_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t* count);
-/* shared rows (clouds of 33-57 k moving points): how a matching launch of `blocks` blocks deals itself to `rows`
- * rows of 128 moving points, given the hit chunks every row listed in the launch before -- parts[r] blocks search row r
- * (>= 1 each, their sum <= blocks whatever the counts hold), *target = hits per block the split aims at.  The kernel computes
- * exactly this in every block; no device is involved here (no reference counterpart: its kernels are thread-per-point). */
-int icp_share_rows_plan(const uint32_t* hits, int rows, int blocks, int model_points, int min_hits, int32_t* parts, uint32_t* target);
 /* symmetric 3x3 eigen-solve used for the normals (upper triangle of row-major A read);
  * w ascending, Z[i*3+k] = component i of eigenvector k */
 int icp_eigh3(const double* A9, double* w3, double* Z9);

@@ -227,14 +227,36 @@ def test_icp_point_to_point_program_bunny_and_hall(pkg, orc, golden, tmp_path):
     r = subprocess.run([os.path.join(BIN, "ICP_point_to_point"), "--hall", str(raw), os.path.join(golden, "beam_intrinsics.csv"),
                         "--transform"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    assert re.search(r"The ICP algorithm was computed in \d+\.\d{4} ms with \d+ iterations", r.stdout)   # ..._real.cu:386
-    assert "The matching step represents the" in r.stdout
+    # the report of src/CUDA/GPU_point_to_point_real.cu:386-403, line by line: `iteration + 1` and four phase lines
+    m = re.search(r"\nThe ICP algorithm was computed in (\d+\.\d{4}) ms with (\d+) iterations\n\n", r.stdout)
+    assert m, r.stdout[-800:]
+    phases = {}
+    for name in ("matching", "minimization", "transformation", "error estimation"):
+        ph = re.search(r"The %s step represents the (\d+\.\d{4})%% of the total time with (\d+\.\d{4}) ms\n\n" % name, r.stdout)
+        assert ph, f"missing the {name} line:\n" + r.stdout[-800:]
+        phases[name] = (float(ph.group(1)), float(ph.group(2)))
+    order = [r.stdout.index("The %s step" % n) for n in ("matching", "minimization", "transformation", "error estimation")]
+    assert order == sorted(order)                       # in the reference's order
+    assert phases["matching"][1] > 0.0 and phases["minimization"][1] > 0.0
+    # transformation and error estimation ride in the front of the matching kernel: their own lines read zero
+    assert phases["transformation"] == (0.0, 0.0) and phases["error estimation"] == (0.0, 0.0)
     T = _transform(r.stdout)
     ang, t_mm = pkg.datasets.HALL_MM
     assert np.abs(T[:3, 3] - np.array(t_mm) / 1000.0).max() < 5e-3 and abs(T[1, 0] - np.sin(ang[2])) < 5e-3
     err = _errors(r.stdout)
     # like the reference, the program prints E[0..iterations]: the value that tripped the stop rule is not shown
     assert err[0] == 0.0 and len(err) >= 3 and err[-1] < 0.5 * err[1]
+    assert int(m.group(2)) == len(err)                  # "with %d iterations" prints iteration + 1 = the entries of the error list (:383,387)
+    # the same dump in the reference's own file form, at full size: one decimal byte value per line, 806 912 lines
+    # (Donut_1024x16.csv, :432-488) -- read by the text path of icp_read_os1_ranges, same registration to the last digit
+    csv = tmp_path / "Donut_1024x16.csv"
+    with open(csv, "w") as f:
+        f.write("\n".join(map(str, pk.tolist())) + "\n")
+    assert sum(1 for _ in open(csv)) == 806912
+    r2 = subprocess.run([os.path.join(BIN, "ICP_point_to_point"), "--hall", str(csv), os.path.join(golden, "beam_intrinsics.csv"),
+                         "--transform"], capture_output=True, text=True, timeout=180)
+    assert r2.returncode == 0, r2.stderr
+    assert np.array_equal(_errors(r2.stdout), err) and np.array_equal(_transform(r2.stdout), T)
 
 
 def test_icp_point_to_plane_program(pkg):

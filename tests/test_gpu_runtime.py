@@ -209,6 +209,16 @@ def test_bench_with_the_drivers_arguments():
     d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["unit"] == "iterations/s"
     assert abs(d["value"] - 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+    # round 4: the 0.2 ms region is repeated (each repeat between its own barriers), the median is the figure, the spread beside it
+    assert d["repeats"] >= 25 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert d["config"]["registrations_per_region"] == 2 and d["config"]["registrations_timed"] == 2 * d["repeats"]
+    assert "aggregate_iterations_per_s" not in d
+    # ... what a pair the context has not seen costs, and the host's model string beside the CPU figure
+    assert 0 < d["setup_ms"] < d["fresh_pair_ms"] and len(d["fresh_pair"]["iterations"]) == 10
+    assert d["cpu_baseline"]["cpu_model"] and d["cpu_baseline"]["cpu_model"] != "unknown"
+    assert "traffic_from_committed_profile" in d["roofline"] and "traffic_source" not in d["roofline"]
+    # ... and the config north_star shards, in brief, beside the hall line (the anchor of its scaling curve)
+    assert d["s5"]["value"] > 0 and d["s5"]["global_moving_points"] == 10_000_000 and d["s5"]["repeats"] == 3
     r = d["roofline"]
     assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert r["launches_timed"] >= 1 and r["avg_launch_us"] > 0 and r["timed_in"]
@@ -228,6 +238,7 @@ def test_bench_every_config_carries_roofline_and_cpu_baseline(cfg, extra):
     """BASELINE configs[0], [1], [3], [4] through `bench.py --config ...`: a line with an EXECUTED-work roofline of the config's own
     kernel (frac <= 1, recomputable from its parts) and a CPU baseline timed beside it"""
     d = _bench(["--config", cfg] + extra)
+    assert d["fresh_pair_ms"] > d["setup_ms"] > 0 and d["repeats"] >= 3
     assert d["value"] > 0 and d["unit"] == "iterations/s" and d["dtype"] == ("f64" if cfg == "cpu_f64" else "f32")
     r = d["roofline"]
     assert r["peak"] == (78.6 if cfg == "cpu_f64" else 157.3) and r["unit"] == "TFLOP/s" and r["bound"] == "valu"
@@ -248,14 +259,22 @@ def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher: the parent spawns the ranks (rehearsed with both on the one GPU)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["ICP_BENCH_ONE_DEVICE"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "120", "--warmup", "20"], env=env,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "120", "--warmup", "20", "--no-s5"], env=env,
                          capture_output=True, text=True, timeout=420)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_moving_points"] == 2 * 16384
-    assert "shared host memory" in d["config"]["collective"]
+    # the default for N > 1 is north_star's split of the metric's own cloud: 16 384 moving points over the ranks, ONE registration
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["global_moving_points"] == 16384 and d["config"]["moving_points_per_gpu"] == 8192
+    assert "shared host memory" in d["config"]["collective"] and d["config"]["collective_route"] == "local"
+    # `value` is an iteration rate: K over the median region, never multiplied by the ranks
+    assert abs(d["value"] - 120 / (d["ms_per_step"] * 120e-3)) < 1e-6 * d["value"] and "aggregate_iterations_per_s" not in d
+    # beside it: a hall-sized shard per rank (one registration of a 2 x 16 384-point cloud), also as K / dt
+    w = d["weak_shards"]
+    assert w["global_moving_points"] == 2 * 16384 and w["scaling"] == "weak" and w["value"] > 0 and w["route"] == "local"
+    assert abs(w["aggregate_moving_point_iterations_per_s"] - 2 * 16384 * w["value"]) < 1e-6 * w["aggregate_moving_point_iterations_per_s"]
     # RCCL refuses two ranks on one device: the leg must say so instead of hanging or killing the line
     assert d["rccl"]["ranks"] == 2 and ("error" in d["rccl"] or d["rccl"]["value"] > 0)
     assert 0 < d["roofline"]["frac"] <= 1.0
@@ -280,6 +299,13 @@ def test_bench_sharded_cloud_two_ranks_on_one_device():
         d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
         assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_moving_points"] == 600000
         assert d["rms_error_series_head"][1] > d["final_rms_error"] > 0
+        # north_star's route for the config it shards is RCCL: asked for, refused for two ranks on ONE device, said so, and the line
+        # falls back to the node-local route (on two devices `value` is the RCCL figure and `local` the one beside it)
+        assert d["config"]["collective_route"] in ("rccl", "local")
+        if d["config"]["collective_route"] == "local":
+            assert "rccl" in d["config"]["collective_route_note"]
+        assert d["local"]["value"] > 0 and d["local"]["route"] == "local"
+        assert abs(d["local"]["final_rms_error"] - d["final_rms_error"]) < 1e-9
         errs.append(d["final_rms_error"])
     assert abs(errs[0] - errs[1]) < 1e-12 * errs[0], errs
 
@@ -290,14 +316,14 @@ def test_bench_under_torch_distributed_run():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["ICP_BENCH_ONE_DEVICE"] = "1"
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29637", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "120", "--warmup", "20"],
+                          "--master-port", "29637", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "120", "--warmup", "20", "--no-s5"],
                          env=env, capture_output=True, text=True, timeout=420)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["rccl"]["ranks"] == 2
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["rccl"]["ranks"] == 2 and d["weak_shards"]["value"] > 0
 
 
 def test_bench_two_gpus_rccl_leg():
@@ -306,7 +332,7 @@ def test_bench_two_gpus_rccl_leg():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the driver's scaling run exercises this path)")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ICP_BENCH_ONE_DEVICE")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20"], env=env,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20", "--no-s5"], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
@@ -316,13 +342,13 @@ def test_bench_two_gpus_rccl_leg():
 
 def test_bench_rccl_leg_single_rank():
     """the library-issued ncclAllReduce route, exercised with the one rank this box has"""
-    d = _bench(["--steps", "120", "--warmup", "20", "--no-cpu-baseline"], {"ICP_BENCH_FORCE_DIST": "1"})
+    d = _bench(["--steps", "120", "--warmup", "20", "--no-cpu-baseline", "--no-s5", "--no-fresh-pair"], {"ICP_BENCH_FORCE_DIST": "1"})
     assert d["rccl"]["ranks"] == 1 and d["rccl"]["value"] > 0 and d["rccl"]["us_per_iteration"] > 0
 
 
 def test_bench_rccl_leg_on_the_sharded_config_single_rank():
     """configs[4] is the config north_star shards: its line carries the library-issued ncclAllReduce route too"""
-    d = _bench(["--config", "s5", "--points", "600000", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], {"ICP_BENCH_FORCE_DIST": "1"})
+    d = _bench(["--config", "s5", "--points", "600000", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-fresh-pair"], {"ICP_BENCH_FORCE_DIST": "1"})
     assert d["rccl"]["ranks"] == 1 and d["rccl"]["value"] > 0 and d["rccl"]["us_per_iteration"] > 0
     assert abs(d["rccl"]["final_rms_error"] - d["final_rms_error"]) < 1e-9      # the same registration through either route
 
@@ -330,8 +356,61 @@ def test_bench_rccl_leg_on_the_sharded_config_single_rank():
 def test_bench_a_stuck_rccl_leg_is_visible():
     """a communicator attempt that never answers: the process is killed at its time limit, the line is still printed (with the
     reason) and the run ends NON-zero -- never rc 0 (round 2 left through os._exit(0))"""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-s5", "--no-fresh-pair"],
                          env=dict(os.environ, ICP_BENCH_FORCE_DIST="1", ICP_BENCH_RCCL_TIMEOUT="0.2"), capture_output=True, text=True, timeout=420)
     assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
     assert d["value"] > 0 and d["rccl"]["hung"] is True and "killed" in d["rccl"]["error"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 4: the advisor's findings on round 3
+# ---------------------------------------------------------------------------------------------------
+def test_node_communicator_and_external_moments_buffer_refuse_each_other(pkg):
+    """an external moments buffer is reduced by its owner between enqueue and complete; with the node communicator on top the
+    ranks' sums would be added twice (silently: a wrong transform).  Either order of the two calls is ICP_ERR_STATE."""
+    import torch
+    buf = torch.zeros(32, dtype=torch.float64, device="cuda:0")
+    D = pkg.datasets.synthetic_grid(32, np.float32)
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    with pkg.Context(0) as c:
+        c.set_model(M); c.set_moving(D)
+        c.comm_init_local(pkg.Context.comm_random_id(), 0, 1)
+        with pytest.raises(pkg.IcpError) as e:
+            c.loop_set_moments_dev(buf.data_ptr())
+        assert e.value.code == pkg.capi.ICP_ERR_STATE
+        c.comm_destroy()
+        c.loop_set_moments_dev(buf.data_ptr())
+        with pytest.raises(pkg.IcpError) as e:
+            c.comm_init_local(pkg.Context.comm_random_id(), 0, 1)
+        assert e.value.code == pkg.capi.ICP_ERR_STATE
+        # the buffer alone works as before: the caller sees the sums between enqueue and complete
+        c.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=5, tol=1e-6)
+        c.loop_enqueue()
+        torch.cuda.synchronize()
+        done = c.loop_complete()
+        assert not done and float(buf[1].item()) == D.shape[0]
+        c.loop_set_moments_dev(0)
+        c.comm_init_local(pkg.Context.comm_random_id(), 0, 1)   # and with the library's own vector the communicator attaches again
+
+
+@pytest.mark.parametrize("form", ["run", "stepwise"])
+def test_a_numeric_failure_keeps_the_loop_readable(pkg, form):
+    """the minimisation refusing a pass's sums (degenerate correspondences) ends the loop, but what its completed passes produced
+    stays readable; only a DEVICE failure discards the loop (include/icp_mi355x.h, icp_loop_state)"""
+    g = np.stack(np.meshgrid(np.arange(8.0), np.arange(8.0), indexing="ij"), -1).reshape(-1, 2)
+    P = np.concatenate([g, np.zeros((64, 1))], 1).astype(np.float32)
+    N = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (64, 1))
+    with pkg.Context(0) as c:
+        c.set_model(P); c.set_model_normals(N); c.set_moving(P)
+        c.loop_begin(pkg.ICP_POINT_TO_PLANE, max_iter=3, tol=1e-6)
+        with pytest.raises(pkg.IcpError) as e:
+            if form == "run":
+                c.loop_run(3)
+            else:
+                c.loop_enqueue(); c.loop_complete()
+        assert e.value.code == pkg.capi.ICP_ERR_SINGULAR
+        st = c.loop_state()                                  # still answers
+        assert st["passes"] == 0 and st["iterations"] == 0 and np.array_equal(st["T"], np.eye(4))
+        assert np.array_equal(c.loop_indices(), np.arange(64, dtype=np.int32))   # the pass itself completed: a point is its own match
+        assert np.array_equal(c.get_moving(), P)

@@ -9,11 +9,11 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "icp_mi355x.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("icp_mi355x.h", "icp_mi355x_diag.h")]
 
 
 def declared_symbols():
-    src = open(HEADER).read()
+    src = "".join(open(h).read() for h in HEADERS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(icp_[a-z0-9_]+)\s*\(", src)))
 
@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, n)
     # and the Python stub binds exactly the header's surface
     assert sorted(pkg.capi.SIGNATURES) == names
-    assert lib.icp_abi_version() == 1
+    assert lib.icp_abi_version() == 2
 
 
 def test_matching_isa_has_no_fused_multiply_add():
@@ -244,3 +244,15 @@ def test_shared_rows_plan_always_fits_the_grid(pkg):
     assert (pkg.share_rows_plan(np.zeros(288, dtype=np.uint32), 512, 35947)[0] == 1).all()
     with pytest.raises(pkg.IcpError):
         pkg.share_rows_plan(hits, 100, 35947)                      # fewer blocks than rows
+
+
+def test_bench_region_statistics():
+    """round 4: `value` = K over the MEDIAN of the repeated K-step regions, the spread beside it -- never a single sample"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rs = bench.region_stats([0.30e-3, 0.22e-3, 0.25e-3, 0.21e-3, 0.90e-3], 20)
+    assert rs["repeats"] == 5 and abs(rs["value"] - 20 / 0.25e-3) < 1e-6
+    assert abs(rs["ms_per_step"] - 0.25 / 20) < 1e-12 and abs(rs["ms_per_step_min"] - 0.21 / 20) < 1e-12 and abs(rs["ms_per_step_max"] - 0.90 / 20) < 1e-12
+    assert bench.cpu_model() != ""

@@ -103,3 +103,119 @@ def test_hall_cloud_shape(orc, golden):
     assert P.shape == Q.shape == (16384, 3)
     assert int((np.abs(P).sum(1) == 0).sum()) == 4361      # no-return beams collapse onto the origin
     assert np.abs(P).max() < 200.0                          # metres
+
+
+# ---------------------------------------------------------------------------------------------------
+# (4) known-answer vectors from Intel MKL itself (tests/golden/mkl_vectors.npz, written in the build container by
+#     tests/golden/make_mkl_vectors.py: ctypes on the MKL 2021.4 runtime the reference links -- MKL does not travel).
+#     The reference's third-party statements, src/ICP_CPU.c:227-232 (vdSub, vdSqr, vdAdd x 2, cblas_idamin), :239-248
+#     (cblas_dgemm, LAPACKE_dgesvd, cblas_dgemm x 2, vdSub), :251-253 (cblas_dgemm, vdAdd), :266 (cblas_dnrm2), were
+#     restated from MKL's documentation; these replays check the restatement against the library.
+#     They pin the oracle's model of MKL, not a run of the reference program: "parity unpinned"  stands.
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def mkl(golden):
+    return np.load(os.path.join(golden, "mkl_vectors.npz"))
+
+
+def test_mkl_amin_is_the_first_minimum_of_the_absolute_values(mkl):
+    # cblas_i?amin (src/ICP_CPU.c:232): the oracle's `c == 0 || d < best` scan == first index of min |x|; distances are >= 0
+    assert "2021.4" in str(mkl["mkl_version"])
+    for k in range(int(mkl["amin_count"])):
+        v = mkl[f"amin_vec_{k}"]
+        first = int(np.argmin(np.abs(v)))                       # numpy: first occurrence
+        first32 = int(np.argmin(np.abs(v.astype(np.float32))))  # (1e-300 is zero in float)
+        assert int(mkl[f"amin_d_{k}"]) == first and int(mkl[f"amin_s_{k}"]) == first32, k
+        best, besti = 0.0, 0                                    # the oracle's loop, on a vector of distances (all >= 0)
+        for c, d in enumerate(np.abs(v)):
+            if c == 0 or d < best:
+                best, besti = d, c
+        assert besti == first
+
+
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+def test_mkl_matching_chain_on_lattice_ties(orc, mkl, tag, dtype):
+    # vdSub / vdSqr / vdAdd / vdAdd / idamin on clouds whose distances are exact and tie everywhere: the oracle's indices
+    P, Q = mkl[f"lattice_P_{tag}"], mkl[f"lattice_Q_{tag}"]
+    assert P.dtype == dtype
+    want = mkl[f"lattice_idx_{tag}"]
+    assert np.array_equal(orc.nn(P, Q), want)
+    d = ((Q[want] - P) ** 2)
+    assert np.array_equal(((d[:, 0] + d[:, 1]) + d[:, 2]).astype(dtype), mkl[f"lattice_dmin_{tag}"])
+    # the sample really is tie-laden: most points have several model points at the minimum
+    dist = (((Q[None, :, :] - P[:, None, :]) ** 2).sum(-1))
+    assert ((dist == dist.min(1, keepdims=True)).sum(1) > 1).mean() > 0.5
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", np.float32), ("f64", np.float64)])
+def test_mkl_matching_chain_on_hall_points(orc, mkl, golden, tag, dtype):
+    # the same chain on real coordinates: a spread sample of the hall scan (its coincident no-return points among them)
+    # against the whole 16 384-point model; VML rounds every sub / square / add on its own, as the oracle assumes
+    P = mkl["hall_P_f32"].astype(dtype)
+    Q = mkl["hall_Q_f32"].astype(dtype)
+    D, M = orc.hall_clouds(golden)                               # the fixture's model IS the oracle's hall model
+    assert np.array_equal(M, mkl["hall_Q_f32"]) and np.array_equal(D[mkl["hall_rows"]], mkl["hall_P_f32"])
+    want = mkl[f"hall_idx_{tag}"]
+    assert np.array_equal(orc.nn(P, Q), want)
+    dx, dy, dz = ((Q[want] - P) ** 2).T
+    assert np.array_equal(((dx + dy) + dz).astype(dtype), mkl[f"hall_dmin_{tag}"])   # bit for bit the minimum MKL found
+
+
+def _moments_of(P, Q, idx):
+    P = np.asarray(P, dtype=np.float64)
+    Qi = np.asarray(Q, dtype=np.float64)[idx]
+    mom = np.zeros(32)
+    mom[1] = P.shape[0]
+    mom[2:5] = P.sum(0)
+    mom[5:8] = Qi.sum(0)
+    mom[8:17] = (Qi.T @ P).reshape(9)
+    return mom
+
+
+def test_mkl_whole_passes_of_the_cpu_program(orc, mkl, pkg):
+    # src/ICP_CPU.c's own clouds (WIDTH 32), passes 0 / 1 / 5 / 30: matching, dgemm + dgesvd + dgemm (R = U Vt), t, the
+    # transformed cloud (dgemm + vdAdd) and the error (dnrm2) as MKL computes them, against the oracle's statements and the
+    # product's host solve
+    D, M = orc.synth_icp_cpu(int(mkl["synth_W"]))
+    for k in mkl["synth_passes"]:
+        pt = mkl[f"synth_pt_{k}"]
+        idx = mkl[f"synth_idx_{k}"]
+        assert np.array_equal(orc.nn(pt, M), idx), k
+        R, t, N = orc.p2p_minimize(pt, M, idx)
+        scale = np.abs(mkl[f"synth_N_{k}"]).max()
+        assert np.abs(N.reshape(9) - mkl[f"synth_N_{k}"]).max() < 1e-12 * scale           # dgemm's order of summation: rounding noise
+        assert np.abs(R.reshape(9) - mkl[f"synth_R_{k}"]).max() < 1e-12                    # R = U * Vt, no reflection fix
+        assert np.abs(t - mkl[f"synth_t_{k}"]).max() < 1e-12
+        U, Vt = mkl[f"synth_U_{k}"].reshape(3, 3), mkl[f"synth_Vt_{k}"].reshape(3, 3)
+        assert np.abs(U @ Vt - mkl[f"synth_R_{k}"].reshape(3, 3)).max() < 1e-14
+        # the product's host half from raw moments (icp_solve_point_to_point; csrc/icp_host_math.cpp)
+        R2, t2 = pkg.solve_point_to_point(_moments_of(pt, M, idx))
+        assert np.abs(R2.reshape(9) - mkl[f"synth_R_{k}"]).max() < 1e-10 and np.abs(t2 - mkl[f"synth_t_{k}"]).max() < 1e-10
+        # transformation: MKL's dgemm may fuse the three products of a row (fma) where the oracle and the kernels round each
+        # operation -- the clouds agree to an ulp or two of their coordinates, which is what the parity tests' 1e-11 allows
+        new = orc.transform(pt, mkl[f"synth_R_{k}"].reshape(3, 3), mkl[f"synth_t_{k}"])
+        assert np.abs(new - mkl[f"synth_new_{k}"]).max() < 4e-15 * max(1.0, np.abs(new).max())
+        E = orc.rms_error(mkl[f"synth_new_{k}"], M, idx)
+        assert abs(E - float(mkl[f"synth_E_{k}"])) < 1e-13 * max(1.0, E)
+
+
+def test_mkl_minimisation_on_the_hall_pair(orc, mkl, pkg):
+    # the hall pair widened to double, pass 0, all 16 384 x 16 384 pairs through MKL's chain: indices, R, t, error
+    P = mkl["hall_P_f32"]
+    D64 = None
+    Q64 = mkl["hall_Q_f32"].astype(np.float64)
+    rows = mkl["hall_rows"]
+    idx = mkl["hallmin_idx"]
+    assert np.array_equal(idx[rows], mkl["hall_idx_f64"])        # (the sampled test above is a subset of this run)
+    import oracle_lib  # noqa: F401
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    D, M = orc.hall_clouds(golden)
+    D64 = D.astype(np.float64)
+    assert np.array_equal(M.astype(np.float64), Q64) and np.array_equal(D[rows], P)
+    R, t, N = orc.p2p_minimize(D64, Q64, idx)
+    assert np.abs(N.reshape(9) - mkl["hallmin_N"]).max() < 1e-11 * np.abs(mkl["hallmin_N"]).max()
+    assert np.abs(R.reshape(9) - mkl["hallmin_R"]).max() < 1e-11 and np.abs(t - mkl["hallmin_t"]).max() < 1e-11
+    R2, t2 = pkg.solve_point_to_point(_moments_of(D64, Q64, idx))
+    assert np.abs(R2.reshape(9) - mkl["hallmin_R"]).max() < 1e-9 and np.abs(t2 - mkl["hallmin_t"]).max() < 1e-9
+    E = orc.rms_error(orc.transform(D64, mkl["hallmin_R"].reshape(3, 3), mkl["hallmin_t"]), Q64, idx)
+    assert abs(E - float(mkl["hallmin_E"])) < 1e-12 * max(1.0, E)

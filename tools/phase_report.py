@@ -35,8 +35,12 @@ names = ["entry", "points/message(+transform)", "bounds seeded", "scan", "handed
 last = np.zeros(len(a))
 for ph in range(first, 10):
     if ph > first:
-        last = np.where(a[:, ph - 1] > 0, a[:, ph - 1], last)  # most recent earlier stamp of the wave
+        last = np.where(a[:, ph - 1] >= t0, a[:, ph - 1], last)  # most recent earlier stamp of the wave (of this launch)
     m = a[:, ph] > 0
+    if not m.any():
+        continue
+    # (stamps from before this launch's first one are leftovers of an earlier launch or pass -- the log is not wiped: masked)
+    m = m & (a[:, ph] >= t0)
     if not m.any():
         continue
     line = f"phase {ph} {names[ph]:27s} n={m.sum():6d}  reached at median {np.median(us(a[m, ph])):6.2f}  p90 {np.percentile(us(a[m, ph]), 90):6.2f}  last {us(a[m, ph]).max():6.2f} us"
