@@ -312,8 +312,9 @@ struct icp_ctx {
     size_t rows_cap = 0;               // rows available in mom_partials / h_mom_partials
     int rows_format = -1;              // format of the rows last written to h_mom_partials: 1 compact, 0 full, -1 none yet
     bool fused_tail = true;            // ICP_FUSED_TAIL=0 keeps matching and moments as two kernels
-    bool use_boxes = true;             // ICP_NN_BOXES=0 disables the bounding-box level of the early-out
-    bool mail_wide = true;             // ICP_MAILBOX_AVX=0: write the mailbox line word by word (payload, fence, tags) -- the path of a CPU without AVX
+    bool use_boxes = true;             // (false with ICP_NN_SPARSE=0: the dense kernels, no boxes)
+    bool mail_wide = true;             // ICP_MAILBOX=plain: write the mailbox line word by word (payload, fence, tags) -- the path of a CPU without AVX
+    icp::NNTuning tune{};              // every switch the plan and the launchers look at, read once in icp_create
     double* mom_dev = nullptr;
     double* h_mom = nullptr;  // pinned: the reduced ICP_NMOM vector as the host solve reads it
     unsigned int* h_nonfinite = nullptr;  // pinned, coherent: points with a NaN / infinite coordinate seen by the last upload
@@ -339,12 +340,12 @@ struct icp_ctx {
     uint64_t tr_n = 0;
     void* comm = nullptr;              // RCCL communicator (icp_comm_init): the loop all-reduces its vector itself
     icp::LocalComm* lcomm = nullptr;   // host-memory communicator (icp_comm_init_local): the vector is summed over the node's ranks on the host
-    // test hook (ICP_DEBUG_STALL="pass:seconds", read by icp_create): the host sleeps once, right before it would publish
+    // test hook (ICP_DEBUG="stall=pass:seconds", read by icp_create): the host sleeps once, right before it would publish
     // the message of that pass of a registration -- a descheduled host thread, as the mailbox lease has to survive it
     int debug_stall_pass = -1;
     double debug_stall_s = 0.0;
-    int debug_lose_pass = -1;          // test hook (ICP_DEBUG_LOSE_MESSAGE=pass): the message of that pass is never posted, once
-    float sample_spacing2 = 0.f;       // large models: squared spacing of the samples of a sample round (0: unknown / not searched hierarchically)
+    int debug_lose_pass = -1;          // test hook (ICP_DEBUG=lose=pass): the message of that pass is never posted, once
+    bool debug_shared_resident = false; // test hook (ICP_DEBUG=shared_resident): ranks that share a device may keep resident kernels
     int moving_group = 0;              // group size the moving cloud's order was judged on (0: not judged)
     std::chrono::steady_clock::time_point posted_at{};   // resident loop: when the pending pass's message went out (the row poll's time-out counts from here)
     bool moving_untouched = false;     // c->P (or the pristine copy standing in for it) still holds what icp_set_moving uploaded
@@ -354,7 +355,7 @@ struct icp_ctx {
     bool have_local_cpus = false;
     cpu_set_t local_cpus;              // CPUs of the device's NUMA node (sysfs local_cpulist)
     std::chrono::steady_clock::time_point rows_done_at{};   // when the host last saw a pass's rows complete (mailbox lease)
-    bool poll = true;                  // ICP_NO_POLL=1 falls back to hipStreamSynchronize
+    bool poll = true;                  // (false: the host waits for a pass with a stream synchronisation instead of polling the row tags; no switch any more)
     bool arm = true;                   // ICP_ARMED=0: icp_loop_run never enqueues a pass ahead of its (R, t)
     bool shares_device = false;        // a rank of the attached node communicator runs on the same device: nothing is armed ahead (see icp_comm_init_local)
     int resident = 1;                  // ICP_RESIDENT=0: icp_loop_run never keeps one kernel for a whole registration; 2: also where shared rows are preferred
@@ -407,7 +408,7 @@ int use(icp_ctx* c)
 int ensure_work_buffers(icp_ctx* c)
 {
     const icp::NNPlan before = c->plan;
-    c->plan = icp::nn_plan(c->n, c->m, c->prec, c->num_cus);
+    c->plan = icp::nn_plan(c->n, c->m, c->prec, c->num_cus, c->tune);
     const icp::NNPlan& pl = c->plan;
     // the moving cloud's order was judged when it was uploaded, possibly before the model was known: now that the plan is
     // fixed, judge it again if the kernel works on groups of another size than the one assumed then
@@ -556,10 +557,10 @@ static int morton_decision(icp_ctx* c, int count, int group, int group2, bool* u
     HIP_TRY(hipMemcpyAsync(&h, c->prep_small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (voided_out) *voided_out = h.voided;
-    const char* force = std::getenv("ICP_SORT");   // ICP_SORT=0 never, =1 always (A/B runs, tests)
-    if (force && force[0] == '0') *use_sorted = false;
+    const int force = c->tune.sort;   // ICP_SORT=0 never, =1 always (A/B runs, tests)
+    if (force == 0) *use_sorted = false;
     else if (count <= group) *use_sorted = false;
-    else if (force && force[0] == '1') *use_sorted = true;
+    else if (force == 1) *use_sorted = true;
     else {
         *use_sorted = 3.0 * h.totals[1] < h.totals[0];
         // a model searched through the box hierarchy: the order also has to serve the level above the chunks (a
@@ -613,25 +614,6 @@ int icp_device_count(void)
         return fail(ICP_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
     }
     return n;
-}
-
-static void mailbox_selftest(icp_ctx* c, int slot, const char* when)
-{
-    icp::NNMailbox* mb = mail_slot(c->h_mail, slot);
-    volatile double* ack = c->h_mom;
-    *ack = 0.0;
-    post_message(mb, nullptr, nullptr, icp::ICP_CMD_MATCH, 1.0);
-    (void)icp::launch_mailbox_selftest(mb, c->h_mom, c->stream);
-    const auto t0 = std::chrono::steady_clock::now();
-    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    while (*ack != 1.0 && since() < 5.0) {}
-    const double t_start = since();
-    post_message(mb, nullptr, nullptr, icp::ICP_CMD_MATCH, 2.0);
-    while (*ack != 2.0 && *ack != -1.0 && since() < 10.0) {}
-    std::fprintf(stderr, "[icp selftest %s slot %d] kernel running after %.6f s; live store %s after %.6f s (ack %.0f)\n", when, slot, t_start,
-                 *ack == 2.0 ? "SEEN" : "NOT seen", since() - t_start, *ack);
-    (void)hipStreamSynchronize(c->stream);
-    post_message(mb, nullptr, nullptr, icp::ICP_CMD_EXIT, 0.0);
 }
 
 // The loop is a conversation between one host thread and the GPU (mailbox through the PCIe BAR, moment rows through pinned
@@ -704,9 +686,11 @@ int icp_create(int device, icp_ctx** out)
     if (e == hipSuccess) {
         // mailbox: fine-grained device memory written through the PCIe BAR when the machine allows it (every block
         // polls its own memory), else pinned host memory polled by block 0 and relayed (ICP_MAILBOX=host forces that)
+        // (ICP_MAILBOX: a comma list of `host` -- pinned memory + relay -- and `plain` -- the line written word by word)
         const char* mv = std::getenv("ICP_MAILBOX");
+        if (mv && std::strstr(mv, "plain")) c->mail_wide = false;
         int large_bar = 0;
-        if (!(mv && mv[0] == 'h') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
+        if (!(mv && std::strstr(mv, "host")) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
             hipExtMallocWithFlags((void**)&c->h_mail, kMailSlots * kMailSlotBytes, hipDeviceMallocFinegrained) == hipSuccess) {
             c->mail_in_bar = true;
         } else {
@@ -730,13 +714,18 @@ int icp_create(int device, icp_ctx** out)
         return fail(ICP_ERR_HIP, msg);
     }
     c->stream = c->own_stream;
-    if (const char* v = std::getenv("ICP_DEBUG_LOSE_MESSAGE")) c->debug_lose_pass = std::atoi(v);
-    if (const char* v = std::getenv("ICP_DEBUG_STALL")) {
-        int pass = -1;
-        double sec = 0.0;
-        if (std::sscanf(v, "%d:%lf", &pass, &sec) == 2 && pass >= 0 && sec > 0.0 && sec < 30.0) { c->debug_stall_pass = pass; c->debug_stall_s = sec; }
+    // test hooks, one variable: ICP_DEBUG="stall=pass:seconds,lose=pass,shared_resident" (tests/test_gpu_runtime.py, tests/test_gpu_parity.py)
+    if (const char* v = std::getenv("ICP_DEBUG")) {
+        if (const char* q = std::strstr(v, "lose=")) c->debug_lose_pass = std::atoi(q + 5);
+        if (const char* q = std::strstr(v, "stall=")) {
+            int pass = -1;
+            double sec = 0.0;
+            if (std::sscanf(q + 6, "%d:%lf", &pass, &sec) == 2 && pass >= 0 && sec > 0.0 && sec < 30.0) { c->debug_stall_pass = pass; c->debug_stall_s = sec; }
+        }
+        c->debug_shared_resident = std::strstr(v, "shared_resident") != nullptr;
     }
-    if (const char* v = std::getenv("ICP_NO_POLL")) c->poll = !(v[0] == '1');
+    c->tune = icp::nn_tuning_from_env();
+    c->use_boxes = c->tune.sparse != 0;
     if (const char* v = std::getenv("ICP_ARMED")) c->arm = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_RESIDENT")) c->resident = v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1);
     if (const char* v = std::getenv("ICP_SHARE_RESIDENT_AFTER")) c->share_resident_after = std::atoi(v);
@@ -745,23 +734,26 @@ int icp_create(int device, icp_ctx** out)
     if (const char* v = std::getenv("ICP_HOST_ROWS_MAX")) c->host_rows_max = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("ICP_TRACE")) { c->trace = v[0] == '1' || v[0] == '2'; c->trace_passes = v[0] == '2'; }
     if (const char* v = std::getenv("ICP_FUSED_TAIL")) c->fused_tail = !(v[0] == '0');
-    if (const char* v = std::getenv("ICP_NN_BOXES")) c->use_boxes = !(v[0] == '0');
-    if (const char* v = std::getenv("ICP_MAILBOX_AVX")) c->mail_wide = !(v[0] == '0');
     if (const char* v = std::getenv("ICP_NN_PHASES")) {
-        // diagnostic: the matching kernel stamps its phases per wave; the last launch's stamps are written to the
-        // named file (raw int64) when the context is destroyed -- tools/phase_report.py reads it
-        // (ICP_NN_PHASE_SLOTS: room for more than the default 3277 sixteen-wave blocks -- 160 stamps a block)
+        // diagnostic, ICP_NN_PHASES=file[:pass[:slots[:wipe]]] -- the matching kernel stamps its phases per wave; the last launch's
+        // stamps are written to the named file (raw int64) when the context is destroyed -- tools/phase_report.py reads it.
+        // pass: stamp this pass of a resident launch only (-1 / empty: every pass, the last one survives); slots: room for more than
+        // the default 3277 sixteen-wave blocks (160 stamps a block); wipe = 1: the log is cleared ahead of every launch
+        std::string spec = v;
+        std::vector<std::string> part;
+        for (size_t at = 0;;) { const size_t q = spec.find(':', at); part.push_back(spec.substr(at, q == std::string::npos ? q : q - at)); if (q == std::string::npos) break; at = q + 1; }
         size_t slots = kPhaseSlots;
-        if (const char* sl = std::getenv("ICP_NN_PHASE_SLOTS")) { const long long w = std::atoll(sl); if (w > 0 && w <= (1ll << 28)) slots = (size_t)w; }
-        if (v[0] && c->phase_log.ensure(slots * sizeof(long long)) == hipSuccess &&
+        if (part.size() > 1 && !part[1].empty()) c->tune.phase_pass = std::atoi(part[1].c_str());
+        if (part.size() > 2 && !part[2].empty()) { const long long w = std::atoll(part[2].c_str()); if (w > 0 && w <= (1ll << 28)) slots = (size_t)w; }
+        if (part.size() > 3 && !part[3].empty()) c->tune.phase_wipe = std::atoi(part[3].c_str()) != 0;
+        if (!part[0].empty() && c->phase_log.ensure(slots * sizeof(long long)) == hipSuccess &&
             hipMemset(c->phase_log.p, 0, slots * sizeof(long long)) == hipSuccess) {
-            c->phase_path = v;
+            c->phase_path = part[0];
             c->phase_slots = slots;
-            icp::set_phase_log((long long*)c->phase_log.p, (long long)slots);
+            c->tune.phase_log = (long long*)c->phase_log.p;
+            c->tune.phase_cap = (long long)slots;
         }
     }
-    if (const char* v = std::getenv("ICP_SELFTEST"))
-        if (v[0] == '1') mailbox_selftest(c, 3, "create");
     *out = c;
     return ICP_OK;
 }
@@ -778,7 +770,6 @@ void icp_destroy(icp_ctx* c)
     if (c->comm) { icp::comm_destroy(c->comm); c->comm = nullptr; }
     if (c->lcomm) { icp::lcomm_destroy(c->lcomm); c->lcomm = nullptr; }
     if (c->phase_log.p && !c->phase_path.empty()) {
-        icp::set_phase_log(nullptr, 0);
         std::vector<long long> h(c->phase_slots);
         if (hipMemcpy(h.data(), c->phase_log.p, c->phase_slots * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
             if (FILE* f = std::fopen(c->phase_path.c_str(), "wb")) { std::fwrite(h.data(), sizeof(long long), h.size(), f); std::fclose(f); }
@@ -989,7 +980,7 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         HIP_TRY(c->Qs.ensure(3 * (size_t)m_pad * sizeof(float)));
         HIP_TRY(icp::launch_duplicates_and_scan_copy(pb, (const float*)c->Q.p, m, m_pad, (unsigned char*)c->prep_voided.p, &small->voided,
                                                      (float*)c->Qs.p, c->stream));
-        const int group2 = icp::nn_plan(128, m, precision, c->num_cus).hier ? 512 : 0;   // (the model's size decides the search form)
+        const int group2 = icp::nn_plan(128, m, precision, c->num_cus, c->tune).hier ? 512 : 0;   // (the model's size decides the search form)
         HIP_TRY(icp::launch_morton_order(pb, (const float*)c->Q.p, m, m_pad, 8, group2, (int32_t*)c->prep_perm.p, small->totals, c->stream));
         if (int rc = morton_decision(c, m, 8, group2, &c->model_sorted, &c->voided)) return rc;
         // the sparse kernel's view: the same voided copy, in Morton order if the model's own order has no locality
@@ -1013,28 +1004,6 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
             c->have_records = true;
         }
         c->have_scan_copy = true;
-        // A model searched through the box hierarchy: how far apart the (at most 2048) samples of a sample round lie -- the
-        // model's extent from its top-level boxes, its area from the extents (a surface in that box), spacing^2 = area / samples.
-        // A seeded pass whose bounds are well above that takes the sample round too (icp_kernels.hip, resample_bound).
-        c->sample_spacing2 = 0.f;
-        if (group2 > 0) {
-            const int n2 = ((m_pad >> 3) + 63) >> 6, n3 = (n2 + 63) >> 6;
-            std::vector<float> top((size_t)n3 * 8);
-            HIP_TRY(hipMemcpyAsync(top.data(), (const float*)c->Qbox.p + (size_t)m_pad + (size_t)n2 * 8, top.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (int b = 0; b < n3; ++b)
-                for (int a = 0; a < 3; ++a) {
-                    const float l = top[(size_t)b * 8 + a], h = top[(size_t)b * 8 + 3 + a];
-                    if (l <= h) { lo[a] = std::min(lo[a], l); hi[a] = std::max(hi[a], h); }
-                }
-            if (lo[0] <= hi[0]) {
-                const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-                const double area = std::sqrt(ex * ey * ex * ey + ey * ez * ey * ez + ex * ez * ex * ez);
-                const int samples = std::min(m_pad / 8, 2048);
-                c->sample_spacing2 = (float)(area / (double)std::max(1, samples));
-            }
-        }
     }
     if (precision == ICP_F64 && m > 0) {
         // fp64 on the sparse structure: the scan copy (exact duplicates of a lower-index point and the padding voided to
@@ -1082,7 +1051,7 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
     if (precision == ICP_F32 && n > 128) {
         // judged on the groups the matching kernel will work on (rows of 64 or of 128 points: nn_plan's rule, overrides
         // included); with no model resident yet the plan assumes one of the moving cloud's size -- ensure_work_buffers looks again
-        const icp::NNPlan guess = icp::nn_plan(n, c->have_model && c->m > 0 ? c->m : n, precision, c->num_cus);
+        const icp::NNPlan guess = icp::nn_plan(n, c->have_model && c->m > 0 ? c->m : n, precision, c->num_cus, c->tune);
         if (int rc = decide_moving_order(c, c->P.p, (guess.sparse && guess.row == 64) ? 64 : 128)) return rc;
     }
     c->have_moving = true;
@@ -1135,10 +1104,9 @@ int icp_set_model_normals(icp_ctx* c, const void* nxyz, int m)
 // the compact two-cache-line form (icp_kernels.h, NNTailArgs)
 static bool use_compact_rows(const icp_ctx* c, const icp::NNPlan& pl, int metric, const double* rows)
 {
-    static const bool off = std::getenv("ICP_COMPACT_ROWS") && std::getenv("ICP_COMPACT_ROWS")[0] == '0';   // (A/B runs)
     // (fp32 only: the compact row spends the last 16 mantissa bits of the error share on its tag -- 2^-36 of a sum of squares
     // of floats is nothing, but the fp64 path is held to 1e-12 against src/ICP_CPU.c's arithmetic)
-    return !off && c->prec == ICP_F32 && pl.sparse && metric == ICP_POINT_TO_POINT && rows == c->h_mom_partials;
+    return c->prec == ICP_F32 && pl.sparse && metric == ICP_POINT_TO_POINT && rows == c->h_mom_partials;
 }
 
 // Completion tags are consecutive integers.  A compact row shows only the low NN_CROW_TAG_BITS bits of its tag, and a
@@ -1189,12 +1157,13 @@ static icp::NNCullInputs make_cull(const icp_ctx* c, const int32_t* seed)
 {
     if (c->prec == ICP_F64) {   // (fp64: no sorted views)
         icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
+        o.tune = &c->tune;
         if (c->count_work) o.work = (unsigned long long*)c->work.p;
         return o;
     }
     icp::NNCullInputs o{c->have_scan_copy ? c->Qs.p : nullptr, seed, c->use_boxes ? c->Qbox.p : nullptr, c->use_boxes ? c->Qsamp.p : nullptr};
     if (c->have_scan_copy && c->model_sorted) { o.Q_scan_sorted = c->Qss.p; o.q_perm = (const int32_t*)c->Qperm.p; }
-    o.sample_spacing2 = c->sample_spacing2;
+    o.tune = &c->tune;
     o.waves64 = c->exclusive ? 16 : 0;
     if (c->moving_sorted) o.p_perm = (const int32_t*)c->Pperm.p;
     if (c->count_work) o.work = (unsigned long long*)c->work.p;
@@ -1306,7 +1275,7 @@ int icp_nn_match_bench_launches(icp_ctx* c, int reps, int warmups, int mode, flo
     const bool dense = mode == 2;
     if (dense) {
         if (c->prec != ICP_F32) return fail(ICP_ERR_INVALID, "the dense packed kernel is fp32");
-        pl = icp::nn_plan(c->n, c->m, c->prec, c->num_cus, 1);
+        pl = icp::nn_plan(c->n, c->m, c->prec, c->num_cus, c->tune, 1);
         const size_t S = pl.splits > 0 ? (size_t)pl.splits : 1;
         HIP_TRY(c->part_d.ensure(S * (size_t)pl.n_pad * sizeof(float)));
         HIP_TRY(c->part_idx.ensure(S * (size_t)pl.n_pad * sizeof(int32_t)));
@@ -1338,7 +1307,7 @@ int icp_share_rows_plan(const uint32_t* hits, int rows, int blocks, int model_po
 int icp_nn_launch_info_ex(icp_ctx* c, int dense, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad)
 {
     if (!c) return fail(ICP_ERR_INVALID, "null context");
-    const icp::NNPlan pl = icp::nn_plan(c->n, c->m, c->prec, c->num_cus, dense ? 1 : 0);
+    const icp::NNPlan pl = icp::nn_plan(c->n, c->m, c->prec, c->num_cus, c->tune, dense ? 1 : 0);
     if (splits) *splits = pl.splits;
     if (blocks) *blocks = pl.blocks_x * pl.splits;
     if (threads) *threads = icp::nn_block_threads(pl);
@@ -1352,7 +1321,7 @@ int icp_nn_launch_info(icp_ctx* c, int* splits, int* blocks, int* threads, int* 
     if (!c) return fail(ICP_ERR_INVALID, "null context");
     // (the geometry of the resident clouds, also before their first launch has fixed the plan)
     const icp::NNPlan pl = (c->plan.n == c->n && c->plan.m == c->m && c->plan.precision == c->prec) ? c->plan
-                                                                                                       : icp::nn_plan(c->n, c->m, c->prec, c->num_cus);
+                                                                                                       : icp::nn_plan(c->n, c->m, c->prec, c->num_cus, c->tune);
     if (splits) *splits = pl.splits;
     if (blocks) *blocks = pl.blocks_x * pl.splits;
     if (threads) *threads = icp::nn_block_threads(pl);
@@ -1392,12 +1361,11 @@ int icp_estimate_normals(icp_ctx* c, void* nxyz_out, int32_t* nbr_out)
     const int m = c->m;
     if (m == 0) return fail(ICP_ERR_EMPTY, "empty model cloud");
     if (m < 5) return fail(ICP_ERR_INVALID, "normals need at least 5 model points (k = 4 neighbours + self)");
-    icp::NNPlan pl = icp::nn_plan(m, m, c->prec, c->num_cus);
+    icp::NNPlan pl = icp::nn_plan(m, m, c->prec, c->num_cus, c->tune);
     HIP_TRY(c->nbr.ensure((size_t)m * 4 * sizeof(int32_t)));
     const size_t es = icp::elem_size(c->prec);
     HIP_TRY(c->Nrm.ensure(3 * (size_t)pl.m_pad * es));
-    static const bool knn_v1 = std::getenv("ICP_KNN_V1") && std::getenv("ICP_KNN_V1")[0] == '1';
-    if (c->prec == ICP_F32 && !knn_v1) {
+    if (c->prec == ICP_F32) {
         int n_pad, bx, S, seg;
         icp::knn4_v2_geometry(m, c->num_cus, &n_pad, &bx, &S, &seg);
         // the per-segment top-5 lists reuse the matching partial buffers
@@ -1643,9 +1611,8 @@ static int loop_complete_body(icp_ctx* c, int* done)
             int b = 0;
             unsigned spins = 0;
             start_sum();
-            static const bool sweep_ok = !(std::getenv("ICP_ROW_SWEEP") && std::getenv("ICP_ROW_SWEEP")[0] == '0');   // (A/B runs)
             static_assert(ICP_NMOM == 32, "add_full_rows_avx takes rows of 32 doubles");
-            if (sweep_ok && L.mom_blocks <= 1024) {
+            if (L.mom_blocks <= 1024) {
                 // Compact rows: SWEEP over the rows whose tag is still missing -- the cache misses of different rows overlap,
                 // where polling row b to completion before looking at row b + 1 takes them one after the other -- fetch a
                 // row's second line as soon as its tag is seen, and add the rows up in block order once all are there
@@ -1917,8 +1884,8 @@ bool can_reside(icp_ctx* c)
     // (a plan with shared rows starts with armed launches, see share_wants_resident; ICP_RESIDENT=2: resident from the first pass)
     // (ranks of one node communicator that share a DEVICE never reside: each fits the machine alone, the two together need
     // not -- one rank's waiting blocks would hold the CUs the other's rows are waited for on, the circular wait of can_arm)
-    // ICP_SHARED_DEVICE_RESIDENT=1 (tests: two hall-sized ranks, 2 x 256 half-CU blocks, known to fit together) lifts it.
-    static const bool shared_ok = std::getenv("ICP_SHARED_DEVICE_RESIDENT") && std::getenv("ICP_SHARED_DEVICE_RESIDENT")[0] == '1';
+    // ICP_DEBUG=shared_resident (tests: two hall-sized ranks, 2 x 256 half-CU blocks, known to fit together) lifts it.
+    const bool shared_ok = c->debug_shared_resident;
     return c->resident && (!c->shares_device || shared_ok) && (c->resident > 1 || pl.share_blocks == 0 || share_wants_resident(c)) && (c->prec == ICP_F32 || pl.version == 3) && !c->resident_refused && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse &&
            icp::nn_can_fuse_tail(pl) && c->have_scan_copy && c->use_boxes && L.active && !L.pending && !L.H.done;
 }
@@ -1930,8 +1897,6 @@ int loop_run_resident(icp_ctx* c, int max_steps, int* k_io, int* d_io, bool* fel
     icp::NNPlan rp = c->plan;   // the resident kernel closes every row inside its block: one segment
     rp.splits = 1;
     rp.seg_len = icp::round_up(rp.m_pad, 8);
-    if (const char* v = std::getenv("ICP_SELFTEST"))
-        if (v[0] == '2') { mailbox_selftest(c, 0, "loop"); mailbox_selftest(c, 1, "loop"); }
     icp::NNMailbox* mb = mail_slot(c->h_mail, (int)(c->mail_seq++ % kMailSlots));
     const int pass_cap = L.H.prm.max_iter + 2;
     const double base = (double)take_tags(c, (uint64_t)pass_cap + 1);

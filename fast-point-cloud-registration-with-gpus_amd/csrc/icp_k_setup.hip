@@ -1,0 +1,656 @@
+// icp_k_setup.hip -- once per icp_set_model / icp_set_moving: exact-duplicate flags, Hilbert / Morton order and the extent test, chunk
+// boxes, samples, per-chunk records; and between two passes of a large cloud: the order and the roles of the next launch's rows.
+#include "icp_device.h"
+#include <math.h>
+#include <stdlib.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace icp {
+
+// ------------------------------------------------------------------------------------------------
+// preparation of a cloud for the sparse kernel, on the device (once per icp_set_model / icp_set_moving):
+// exact-duplicate flags (lexicographic order of the raw coordinate bits: three stable radix passes),
+// Morton order, and the grouped-extent test that decides whether the Morton-ordered view is used.
+// Everything is deterministic (fixed-order reductions): the decision must not change from run to run.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int canon_bits(float v) { return __float_as_uint(v == 0.0f ? 0.0f : v); }
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+    return x - x == 0.f && y - y == 0.f && z - z == 0.f;   // false for NaN and +-inf
+}
+
+// keys[s] = raw bits of coordinate `axis` of point order[s] (order == NULL: identity, and vals is initialised)
+__global__ void prep_axis_keys_kernel(const float* __restrict__ X, int n, int n_pad, int axis, const int32_t* __restrict__ order,
+                                      unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = order ? order[s] : s;
+    keys[s] = canon_bits(X[(size_t)axis * n_pad + i]);
+    if (!order) vals[s] = s;
+}
+
+// lex[s] ascending in (x, y, z, index): a point equal to its predecessor has a lower-index twin
+__global__ void prep_mark_duplicates_kernel(const float* __restrict__ X, int n, int n_pad, const int32_t* __restrict__ lex,
+                                            unsigned char* __restrict__ voided, int* __restrict__ count)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    bool v = false;
+    if (s > 0) {
+        const int a = lex[s - 1], b = lex[s];
+        const float bx = X[b], by = X[(size_t)n_pad + b], bz = X[2 * (size_t)n_pad + b];
+        const bool same = canon_bits(X[a]) == canon_bits(bx) && canon_bits(X[(size_t)n_pad + a]) == canon_bits(by) &&
+                          canon_bits(X[2 * (size_t)n_pad + a]) == canon_bits(bz);
+        const bool nan = bx != bx || by != by || bz != bz;
+        v = same && !nan;
+    }
+    voided[lex[s]] = v ? 1 : 0;
+    if (v) atomicAdd(count, 1);
+}
+
+// scan copy: the cloud with its flagged points (and the padding) voided to +inf
+__global__ void prep_scan_copy_kernel(const float* __restrict__ X, int n, int n_pad, const unsigned char* __restrict__ voided,
+                                      float* __restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    const bool keep = j < n && !voided[j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out[(size_t)a * n_pad + j] = keep ? X[(size_t)a * n_pad + j] : inf_<float>();
+}
+
+// ---- the same for a cloud in double: a 64-bit key is two stable 32-bit passes (low word, then high word) --------------
+__device__ __forceinline__ unsigned long long canon_bits64(double v) { return (unsigned long long)__double_as_longlong(v == 0.0 ? 0.0 : v); }
+
+__global__ void prep_axis_keys_f64_kernel(const double* __restrict__ X, int n, int n_pad, int axis, int high, const int32_t* __restrict__ order,
+                                          unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = order ? order[s] : s;
+    const unsigned long long b = canon_bits64(X[(size_t)axis * n_pad + i]);
+    keys[s] = high ? (unsigned int)(b >> 32) : (unsigned int)b;
+    if (!order) vals[s] = s;
+}
+
+__global__ void prep_mark_duplicates_f64_kernel(const double* __restrict__ X, int n, int n_pad, const int32_t* __restrict__ lex,
+                                                unsigned char* __restrict__ voided, int* __restrict__ count)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    bool v = false;
+    if (s > 0) {
+        const int a = lex[s - 1], b = lex[s];
+        const double bx = X[b], by = X[(size_t)n_pad + b], bz = X[2 * (size_t)n_pad + b];
+        const bool same = canon_bits64(X[a]) == canon_bits64(bx) && canon_bits64(X[(size_t)n_pad + a]) == canon_bits64(by) &&
+                          canon_bits64(X[2 * (size_t)n_pad + a]) == canon_bits64(bz);
+        const bool nan = bx != bx || by != by || bz != bz;
+        v = same && !nan;
+    }
+    voided[lex[s]] = v ? 1 : 0;
+    if (v) atomicAdd(count, 1);
+}
+
+__global__ void prep_scan_copy_f64_kernel(const double* __restrict__ X, int n, int n_pad, const unsigned char* __restrict__ voided,
+                                          double* __restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    const bool keep = j < n && !voided[j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out[(size_t)a * n_pad + j] = keep ? X[(size_t)a * n_pad + j] : inf_<double>();
+}
+
+// bounding cube of the finite points: box[0..2] = lo, box[3] = largest extent.  One block, or (partial != NULL) a grid of them
+// that leave {lo, hi} per block for prep_bbox_final_kernel -- minima and maxima: the result does not depend on the split
+// (a 10 M-point cloud through one block was 3.8 ms of a 37 ms set-up, twice)
+__global__ __launch_bounds__(1024) void prep_bbox_kernel(const float* __restrict__ X, int n, int n_pad, float* __restrict__ box, float* __restrict__ partial)
+{
+    __shared__ float red[6][1024];
+    float lo[3] = {inf_<float>(), inf_<float>(), inf_<float>()}, hi[3] = {-inf_<float>(), -inf_<float>(), -inf_<float>()};
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += 1024 * gridDim.x) {
+        const float x = X[i], y = X[(size_t)n_pad + i], z = X[2 * (size_t)n_pad + i];
+        if (!finite3(x, y, z)) continue;
+        lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+        hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+    }
+    for (int a = 0; a < 3; ++a) { red[a][threadIdx.x] = lo[a]; red[3 + a][threadIdx.x] = hi[a]; }
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int a = 0; a < 3; ++a) {
+                red[a][threadIdx.x] = fminf(red[a][threadIdx.x], red[a][threadIdx.x + w]);
+                red[3 + a][threadIdx.x] = fmaxf(red[3 + a][threadIdx.x], red[3 + a][threadIdx.x + w]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (partial != nullptr) {
+            for (int a = 0; a < 6; ++a) partial[blockIdx.x * 6 + a] = red[a][0];
+            return;
+        }
+        float ext = 0.f;
+        for (int a = 0; a < 3; ++a) { box[a] = red[a][0]; ext = fmaxf(ext, red[3 + a][0] - red[a][0]); }
+        box[3] = ext;   // -inf / NaN when there is no finite point: the codes below then all take the "last" value
+    }
+}
+
+__global__ __launch_bounds__(64) void prep_bbox_final_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ box)
+{
+    float v[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a] = a < 3 ? inf_<float>() : -inf_<float>();
+    for (int b = threadIdx.x; b < blocks; b += 64)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[a] = a < 3 ? fminf(v[a], partial[b * 6 + a]) : fmaxf(v[a], partial[b * 6 + a]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(v[a], off, 64); v[a] = a < 3 ? fminf(v[a], o) : fmaxf(v[a], o); }
+    if (threadIdx.x == 0) {
+        float ext = 0.f;
+        for (int a = 0; a < 3; ++a) { box[a] = v[a]; ext = fmaxf(ext, v[3 + a] - v[a]); }
+        box[3] = ext;
+    }
+}
+
+__device__ __forceinline__ unsigned int spread10(unsigned int v)
+{
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// position of cell (x, y, z) of a 1024^3 grid along the Hilbert curve (J. Skilling, "Programming the Hilbert curve", AIP Conf.
+// Proc. 707, 2004: axes -> transposed index, then the bits interleaved).  Consecutive positions are neighbouring cells -- a
+// Z-order range of 128 points straddles the curve's jumps, and the group box is the union: on the 10 M-point surface the rows
+// of 128 measure 0.027 x 0.027 x 0.031 in this order against 0.038 x 0.034 x 0.031 in Z-order, and every level of the search
+// lists 10-19 % fewer boxes (tools/s5_hits_model.py)
+__device__ __forceinline__ unsigned int hilbert30(unsigned int x, unsigned int y, unsigned int z)
+{
+    unsigned int X[3] = {x & 1023u, y & 1023u, z & 1023u};
+#pragma unroll
+    for (unsigned int Q = 512u; Q > 1u; Q >>= 1) {
+        const unsigned int P = Q - 1u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const unsigned int t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    unsigned int t = 0u;
+#pragma unroll
+    for (unsigned int Q = 512u; Q > 1u; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1u;
+    return (spread10(X[0] ^ t) << 2) | (spread10(X[1] ^ t) << 1) | spread10(X[2] ^ t);
+}
+
+// 30-bit space-filling-curve codes in one cube for all axes (cells stay cubic): the Hilbert curve, or Z-order (hilbert == 0:
+// ICP_ORDER=morton, A/B runs); non-finite points go last
+__global__ void prep_morton_keys_kernel(const float* __restrict__ X, int n, int n_pad, const float* __restrict__ box,
+                                        unsigned int* __restrict__ keys, int32_t* __restrict__ vals, int hilbert)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = X[i], y = X[(size_t)n_pad + i], z = X[2 * (size_t)n_pad + i];
+    unsigned int code = 0x7fffffffu;
+    const float ext = box[3];
+    if (finite3(x, y, z) && ext >= 0.f) {
+        const double scale = ext > 0.f ? 1023.0 / (double)ext : 0.0;
+        const unsigned int qx = (unsigned int)fmin(1023.0, fmax(0.0, ((double)x - (double)box[0]) * scale));
+        const unsigned int qy = (unsigned int)fmin(1023.0, fmax(0.0, ((double)y - (double)box[1]) * scale));
+        const unsigned int qz = (unsigned int)fmin(1023.0, fmax(0.0, ((double)z - (double)box[2]) * scale));
+        code = hilbert ? hilbert30(qx, qy, qz) : (spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2));
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
+// per group of `group` consecutive entries of an order (NULL: the cloud's own): extent dx + dy + dz of its finite points.
+// One wave per group (a thread per group walks 128 gathered points one after the other: 50 us for 128 groups).
+__global__ __launch_bounds__(64) void prep_group_extent_kernel(const float* __restrict__ X, int n, int n_pad, const int32_t* __restrict__ order,
+                                                               int group, double* __restrict__ ext)
+{
+    const int g = blockIdx.x, g0 = g * group, lane = threadIdx.x;
+    float lo[3] = {inf_<float>(), inf_<float>(), inf_<float>()}, hi[3] = {-inf_<float>(), -inf_<float>(), -inf_<float>()};
+    for (int k = g0 + lane; k < min(n, g0 + group); k += 64) {
+        const int i = order ? order[k] : k;
+        const float p[3] = {X[i], X[(size_t)n_pad + i], X[2 * (size_t)n_pad + i]};
+        if (!finite3(p[0], p[1], p[2])) continue;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+        }
+    if (lane == 0) ext[g] = hi[0] >= lo[0] ? (double)(hi[0] - lo[0]) + (double)(hi[1] - lo[1]) + (double)(hi[2] - lo[2]) : 0.0;
+}
+
+// out[which] = sum of ext[0..groups) in a fixed order (one block)
+__global__ __launch_bounds__(256) void prep_sum_kernel(const double* __restrict__ ext, int groups, double* __restrict__ out, int which)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int g = threadIdx.x; g < groups; g += 256) s += ext[g];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[which] = red[0];
+}
+
+// Morton-ordered view of a scan copy + its permutation, padded (+inf / 0x7fffffff)
+__global__ void prep_gather_sorted_kernel(const float* __restrict__ Qs, int m, int m_pad, const int32_t* __restrict__ perm,
+                                          float* __restrict__ out, int32_t* __restrict__ perm_pad)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m_pad) return;
+    const int j = k < m ? perm[k] : -1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out[(size_t)a * m_pad + k] = j >= 0 ? Qs[(size_t)a * m_pad + j] : inf_<float>();
+    perm_pad[k] = j >= 0 ? j : 0x7fffffff;
+}
+
+// slot -> point map of the moving cloud: the Morton order, padding slots keep themselves
+__global__ void prep_slot_map_kernel(const int32_t* __restrict__ perm, int n, int n_pad, int32_t* __restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_pad) out[k] = k < n ? perm[k] : k;
+}
+
+__global__ void row_order_keys_kernel(unsigned int* __restrict__ hits, int rows, unsigned int* __restrict__ keys, int32_t* __restrict__ vals,
+                                      unsigned long long* __restrict__ total_add, unsigned long long* __restrict__ total_zero)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int h = 0u;
+    if (r < rows) {
+        h = hits[r];
+        hits[r] = 0u;                                          // (the next launch counts afresh)
+        h = h > 0xfffffu ? 0xfffffu : h;
+        keys[r] = 0xfffffu - h;                                // ascending sort of this = descending hits; ties keep the row order (stable)
+        vals[r] = r;
+    }
+    // the sum of the counters (the target of the split rows derives from it): two words, this launch adds to one and clears
+    // the other for the next
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h += (unsigned int)__shfl_xor((int)h, off, 64);
+    __shared__ unsigned int wsum[4];   // (one add per block: 1200 adds to one address were 17 us of every pass)
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t != 0ull) atomicAdd(total_add, t);
+    }
+    if (r == 0) *total_zero = 0ull;
+}
+
+// the roles of an ordered launch's blocks (NN_ORDER_*, icp_kernels.h): every block works the split of the NN_ORDER_HEAD heaviest
+// rows out for itself (one scan of 1024 counters), block 0 writes their roles, all write the roles behind them
+__global__ __launch_bounds__(1024) void row_roles_kernel(const unsigned int* __restrict__ keys, const int32_t* __restrict__ vals, int rows,
+                                                         const unsigned long long* __restrict__ total, int min_part, int total_div, int32_t* __restrict__ roles)
+{
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int head = rows < NN_ORDER_HEAD ? rows : NN_ORDER_HEAD;
+    const unsigned int h = t < head ? 0xfffffu - keys[t] : 0u;
+    auto block_sum = [&](int v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        __syncthreads();   // (the words are free again)
+        if (lane == 0) wsum[w] = v;
+        __syncthreads();
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += wsum[k];
+        return s;
+    };
+    unsigned long long T = *total / (unsigned long long)(total_div > 0 ? total_div : 1024);
+    if (T < (unsigned long long)min_part) T = (unsigned long long)min_part;
+    int parts = t < head ? 1 : 0, E = head;
+    if (min_part > 0) {
+        for (int it = 0; it < 24; ++it) {   // (the target doubles until the parts fit the spare blocks: at most 20 times, the counters have 20 bits)
+            unsigned int p = 1u;
+            if ((unsigned long long)h > T) {
+                const unsigned long long want = ((unsigned long long)h + T - 1ull) / T;   // >= 2
+                p = want >= 64ull ? 64u : 1u << (32 - __builtin_clz((unsigned int)want - 1u));
+            }
+            parts = t < head ? (int)p : 0;
+            E = block_sum(parts);
+            if (E - head <= NN_ORDER_EXTRA) break;
+            T *= 2ull;
+            parts = t < head ? 1 : 0;
+            E = head;
+        }
+    }
+    int v = parts;   // inclusive running sum within the wave, then across the waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); v += lane >= o ? u : 0; }
+    __syncthreads();
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) base += k < w ? wsum[k] : 0;
+    const int excl = base + v - parts;
+    if (blockIdx.x == 0 && t < head) {
+        const int row = vals[t];
+        const int lg = 31 - __builtin_clz((unsigned int)parts);
+        for (int p = 0; p < parts; ++p) roles[excl + p] = row | (p << NN_ROLE_ROW_BITS) | (lg << (NN_ROLE_ROW_BITS + NN_ROLE_PART_BITS));
+    }
+    const int j = E + (int)blockIdx.x * 1024 + t;   // the roles behind the head: one block each, in the sorted order
+    if (j < rows + NN_ORDER_EXTRA) {
+        const int src = head + (j - E);
+        roles[j] = src < rows ? vals[src] : -1;
+    }
+}
+
+size_t row_order_temp_bytes(int rows)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned int*)nullptr, (unsigned int*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                    (unsigned int)(rows > 0 ? rows : 1), 0, 20);
+    return bytes;
+}
+
+hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int rows, const int32_t** roles_out, hipStream_t st)
+{
+    if (rows <= 0 || rows >= (1 << NN_ROLE_ROW_BITS) || b.roles == nullptr || b.totals == nullptr) return hipErrorInvalidValue;
+    unsigned long long* tot = b.totals + (b.seq & 1ull);
+    hipLaunchKernelGGL(row_order_keys_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, hits, rows, b.keys[0], b.vals[0], tot, b.totals + ((b.seq + 1ull) & 1ull));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    size_t bytes = b.temp_bytes;
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.keys[0], b.keys[1], b.vals[0], b.vals[1], (unsigned int)rows, 0, 20, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(row_roles_kernel, dim3((rows + NN_ORDER_EXTRA + 1023) / 1024), dim3(1024), 0, st, b.keys[1], b.vals[1], rows,
+                       (const unsigned long long*)tot, b.min_part, b.total_div, b.roles);
+    *roles_out = b.roles;
+    return hipGetLastError();
+}
+
+size_t prep_sort_temp_bytes(int count)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned int*)nullptr, (unsigned int*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                    (unsigned int)(count > 0 ? count : 1));
+    return bytes;
+}
+
+static hipError_t sort_pairs(const PrepBuffers& b, int count, int from, int end_bit, hipStream_t st)
+{
+    size_t bytes = b.temp_bytes;
+    return rocprim::radix_sort_pairs(b.temp, bytes, b.keys[from], b.keys[from ^ 1], b.vals[from], b.vals[from ^ 1], (unsigned int)count, 0,
+                                     (unsigned int)end_bit, st);
+}
+
+// voided[j] = 1 for every point with an exact lower-index twin, *count_dev += their number; then the scan copy
+hipError_t launch_duplicates_and_scan_copy(const PrepBuffers& b, const float* X, int n, int n_pad, unsigned char* voided, int* count_dev,
+                                           float* scan_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const dim3 blk(256), grd((n + 255) / 256);
+    int cur = 0;
+    for (int axis = 2; axis >= 0; --axis) {   // least significant key first, stable passes
+        hipLaunchKernelGGL(prep_axis_keys_kernel, grd, blk, 0, st, X, n, n_pad, axis, axis == 2 ? (const int32_t*)nullptr : b.vals[cur],
+                           b.keys[cur], b.vals[cur]);
+        if (hipError_t e = sort_pairs(b, n, cur, 32, st)) return e;
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(prep_mark_duplicates_kernel, grd, blk, 0, st, X, n, n_pad, b.vals[cur], voided, count_dev);
+    hipLaunchKernelGGL(prep_scan_copy_kernel, dim3((n_pad + 255) / 256), blk, 0, st, X, n, n_pad, voided, scan_out);
+    return hipGetLastError();
+}
+
+// the same for a cloud in double (six stable 32-bit passes: z low, z high, y low, ...)
+hipError_t launch_duplicates_and_scan_copy_f64(const PrepBuffers& b, const double* X, int n, int n_pad, unsigned char* voided, int* count_dev,
+                                               double* scan_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const dim3 blk(256), grd((n + 255) / 256);
+    int cur = 0;
+    bool first = true;
+    for (int axis = 2; axis >= 0; --axis)
+        for (int high = 0; high < 2; ++high) {
+            hipLaunchKernelGGL(prep_axis_keys_f64_kernel, grd, blk, 0, st, X, n, n_pad, axis, high, first ? (const int32_t*)nullptr : b.vals[cur],
+                               b.keys[cur], b.vals[cur]);
+            if (hipError_t e = sort_pairs(b, n, cur, 32, st)) return e;
+            cur ^= 1;
+            first = false;
+        }
+    hipLaunchKernelGGL(prep_mark_duplicates_f64_kernel, grd, blk, 0, st, X, n, n_pad, b.vals[cur], voided, count_dev);
+    hipLaunchKernelGGL(prep_scan_copy_f64_kernel, dim3((n_pad + 255) / 256), blk, 0, st, X, n, n_pad, voided, scan_out);
+    return hipGetLastError();
+}
+
+// perm_out[k] = k-th point in Morton order; totals[0] / totals[1] = summed group extents of the given / the Morton order
+// (group2 > 0: totals[2] / totals[3] = the same for groups of group2 -- the upper search level of a large model)
+hipError_t launch_morton_order(const PrepBuffers& b, const float* X, int n, int n_pad, int group, int group2, int32_t* perm_out,
+                               double* totals, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const dim3 blk(256), grd((n + 255) / 256);
+    {
+        // (large clouds: a grid of blocks; their partial boxes lie in the sort's second key buffer, idle until the sort)
+        const int bb = n >= (1 << 18) ? 256 : 1;
+        float* partial = bb > 1 ? reinterpret_cast<float*>(b.keys[1]) : nullptr;
+        hipLaunchKernelGGL(prep_bbox_kernel, dim3(bb), dim3(1024), 0, st, X, n, n_pad, b.box, partial);
+        if (bb > 1) hipLaunchKernelGGL(prep_bbox_final_kernel, dim3(1), dim3(64), 0, st, (const float*)partial, bb, b.box);
+    }
+    const int hilbert = 1;   // (Z-order, round 3's A/B: rows of 128 on the 10 M-point surface 10-19 % looser at every level; its switch is gone)
+    hipLaunchKernelGGL(prep_morton_keys_kernel, grd, blk, 0, st, X, n, n_pad, b.box, b.keys[0], b.vals[0], hilbert);
+    if (hipError_t e = sort_pairs(b, n, 0, 31, st)) return e;
+    if (hipError_t e = hipMemcpyAsync(perm_out, b.vals[1], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st)) return e;
+    const int groups = (n + group - 1) / group;
+    const dim3 ggrd(groups);
+    hipLaunchKernelGGL(prep_group_extent_kernel, ggrd, dim3(64), 0, st, X, n, n_pad, (const int32_t*)nullptr, group, b.ext);
+    hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups, totals, 0);
+    hipLaunchKernelGGL(prep_group_extent_kernel, ggrd, dim3(64), 0, st, X, n, n_pad, (const int32_t*)perm_out, group, b.ext);
+    hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups, totals, 1);
+    if (group2 > 0) {
+        const int groups2 = (n + group2 - 1) / group2;
+        hipLaunchKernelGGL(prep_group_extent_kernel, dim3(groups2), dim3(64), 0, st, X, n, n_pad, (const int32_t*)nullptr, group2, b.ext);
+        hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups2, totals, 2);
+        hipLaunchKernelGGL(prep_group_extent_kernel, dim3(groups2), dim3(64), 0, st, X, n, n_pad, (const int32_t*)perm_out, group2, b.ext);
+        hipLaunchKernelGGL(prep_sum_kernel, dim3(1), dim3(256), 0, st, b.ext, groups2, totals, 3);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_sorted(const float* Qs, int m, int m_pad, const int32_t* perm, float* out, int32_t* perm_pad, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_gather_sorted_kernel, dim3((m_pad + 255) / 256), dim3(256), 0, st, Qs, m, m_pad, perm, out, perm_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_slot_map(const int32_t* perm, int n, int n_pad, int32_t* out, hipStream_t st)
+{
+    if (n_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_slot_map_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, perm, n, n_pad, out);
+    return hipGetLastError();
+}
+
+// bounding box of every 8-point chunk of the duplicate-voided scan copy (voided = +inf entries are ignored; an
+// all-void chunk gets lo = +inf, hi = -inf and is skipped by construction).  Once per model.
+__global__ void model_boxes_kernel(const float* __restrict__ Qs, int m_pad, float* __restrict__ boxes)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * 8 >= m_pad) return;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = inf_<float>(); hi[a] = -inf_<float>(); }
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = Qs[(size_t)a * m_pad + j];
+            if (v < inf_<float>() && v > -inf_<float>()) { lo[a] = __builtin_fminf(lo[a], v); hi[a] = __builtin_fmaxf(hi[a], v); }
+        }
+    }
+    float* o = boxes + (size_t)c * 8;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+}
+
+// one representative per chunk of the scan copy (its first point that is not voided; +inf if there is none),
+// SoA over round_up(m_pad / 8, 8) entries: the thinned-out model of the sparse kernel's cold start
+__global__ void model_samples_kernel(const float* __restrict__ Qs, int m_pad, int ns_pad, float* __restrict__ samples)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ns_pad) return;
+    float v[3] = {inf_<float>(), inf_<float>(), inf_<float>()};
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+        const float x = Qs[j];
+        if (x < inf_<float>() && x > -inf_<float>()) { v[0] = x; v[1] = Qs[(size_t)m_pad + j]; v[2] = Qs[2 * (size_t)m_pad + j]; break; }
+    }
+    samples[c] = v[0];
+    samples[(size_t)ns_pad + c] = v[1];
+    samples[2 * (size_t)ns_pad + c] = v[2];
+}
+
+// the same two tables in double, for the fp64 form of the search (the model itself is the scan copy: nothing is voided)
+__global__ void model_boxes_f64_kernel(const double* __restrict__ Qs, int m_pad, double* __restrict__ boxes)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * 8 >= m_pad) return;
+    double lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = inf_<double>(); hi[a] = -inf_<double>(); }
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v = Qs[(size_t)a * m_pad + j];
+            if (v < inf_<double>() && v > -inf_<double>()) { lo[a] = __builtin_fmin(lo[a], v); hi[a] = __builtin_fmax(hi[a], v); }
+        }
+    }
+    double* o = boxes + (size_t)c * 8;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.0; o[7] = 0.0;
+}
+
+__global__ void model_samples_f64_kernel(const double* __restrict__ Qs, int m_pad, int ns_pad, double* __restrict__ samples)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ns_pad) return;
+    double v[3] = {inf_<double>(), inf_<double>(), inf_<double>()};
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+        const double x = Qs[j];
+        if (x < inf_<double>() && x > -inf_<double>()) { v[0] = x; v[1] = Qs[(size_t)m_pad + j]; v[2] = Qs[2 * (size_t)m_pad + j]; break; }
+    }
+    samples[c] = v[0];
+    samples[(size_t)ns_pad + c] = v[1];
+    samples[2 * (size_t)ns_pad + c] = v[2];
+}
+
+hipError_t launch_model_tables_f64(const void* Q_soa, int m_pad, void* boxes, void* samples, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const int chunks = (m_pad + 7) / 8, ns_pad = (chunks + 7) / 8 * 8;
+    hipLaunchKernelGGL(model_boxes_f64_kernel, dim3((chunks + 255) / 256), dim3(256), 0, st, (const double*)Q_soa, m_pad, (double*)boxes);
+    hipLaunchKernelGGL(model_samples_f64_kernel, dim3((ns_pad + 255) / 256), dim3(256), 0, st, (const double*)Q_soa, m_pad, ns_pad, (double*)samples);
+    return hipGetLastError();
+}
+size_t model_boxes_f64_bytes(int m_pad) { return (size_t)((m_pad + 7) / 8) * 8 * sizeof(double); }
+size_t model_samples_f64_bytes(int m_pad) { return 3 * (size_t)(((m_pad / 8) + 7) / 8 * 8) * sizeof(double); }
+
+size_t model_samples_bytes(int m_pad) { return 3 * (size_t)(((m_pad / 8) + 7) / 8 * 8) * sizeof(float); }
+
+hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const int ns_pad = ((m_pad / 8) + 7) / 8 * 8;
+    hipLaunchKernelGGL(model_samples_kernel, dim3((ns_pad + 255) / 256), dim3(256), 0, st, (const float*)Qs_soa, m_pad, ns_pad, samples);
+    return hipGetLastError();
+}
+
+// upper levels: the box of every 64 boxes of the level below (512, 32 768 model points), one wave per box; stored
+// behind the chunk boxes, level after level
+__global__ __launch_bounds__(256) void model_superboxes_kernel(const float* __restrict__ boxes, int chunks, int supers, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int sidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sidx >= supers) return;
+    const int c = sidx * 64 + lane;
+    float lo[3] = {inf_<float>(), inf_<float>(), inf_<float>()}, hi[3] = {-inf_<float>(), -inf_<float>(), -inf_<float>()};
+    if (c < chunks) {
+        const float4* bp = reinterpret_cast<const float4*>(boxes + (size_t)c * 8);
+        const float4 b0 = bp[0], b1 = bp[1];
+        lo[0] = b0.x; lo[1] = b0.y; lo[2] = b0.z; hi[0] = b0.w; hi[1] = b1.x; hi[2] = b1.y;
+    }
+    wave_box(lo, hi);
+    if (lane == 0) {
+        float* o = out + (size_t)sidx * 8;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
+size_t model_boxes_bytes(int m_pad)
+{
+    const size_t chunks = (size_t)(m_pad + 7) / 8, supers = (chunks + 63) / 64, thirds = (supers + 63) / 64;
+    return (chunks + supers + thirds) * 8 * sizeof(float);
+}
+
+hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const int chunks = (m_pad + 7) / 8;
+    hipLaunchKernelGGL(model_boxes_kernel, dim3((chunks + 255) / 256), dim3(256), 0, st, (const float*)Qs_soa, m_pad, boxes);
+    const int supers = (chunks + 63) / 64;
+    float* l2 = boxes + (size_t)chunks * 8;
+    hipLaunchKernelGGL(model_superboxes_kernel, dim3((supers + 3) / 4), dim3(256), 0, st, (const float*)boxes, chunks, supers, l2);
+    const int thirds = (supers + 63) / 64;
+    hipLaunchKernelGGL(model_superboxes_kernel, dim3((thirds + 3) / 4), dim3(256), 0, st, (const float*)l2, supers, thirds,
+                       l2 + (size_t)supers * 8);
+    return hipGetLastError();
+}
+
+// One record per chunk for the hierarchical search of a large model: {box lo.xyz hi.x | hi.yz - - | x[8] | y[8] | z[8] | index[8]}
+// = 40 words = 160 contiguous bytes, the layout of a hit's stage in LDS.  A hit is then two cache lines instead of five
+// 32-byte pieces of five arrays (a model of millions of points is not L2-resident: 10 M x 10 M fetched 23 GB per early pass).
+__global__ void model_records_kernel(const float* __restrict__ Qs, const float* __restrict__ boxes, const int32_t* __restrict__ perm, int m_pad,
+                                     float* __restrict__ rec)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece each
+    const long long chunks = m_pad >> 3;
+    if (t >= chunks * 10) return;
+    const long long ch = t / 10;
+    const int part = (int)(t % 10);
+    float4 v;
+    if (part < 2) v = *reinterpret_cast<const float4*>(boxes + ch * 8 + part * 4);
+    else if (part < 8) v = *reinterpret_cast<const float4*>(Qs + (size_t)((part - 2) >> 1) * m_pad + ch * 8 + (part & 1) * 4);
+    else {
+        const int k0 = (int)(ch * 8) + (part - 8) * 4;
+        int4 iv = perm ? *reinterpret_cast<const int4*>(perm + k0) : int4{k0, k0 + 1, k0 + 2, k0 + 3};
+        v = float4{__int_as_float(iv.x), __int_as_float(iv.y), __int_as_float(iv.z), __int_as_float(iv.w)};
+    }
+    *reinterpret_cast<float4*>(rec + ch * NN_REC_WORDS + part * 4) = v;
+}
+
+size_t model_records_bytes(int m_pad) { return (size_t)(m_pad >> 3) * NN_REC_WORDS * sizeof(float); }
+
+hipError_t launch_model_records(const void* Qs_soa, const float* boxes, const int32_t* perm, int m_pad, float* rec, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const long long pieces = (long long)(m_pad >> 3) * 10;
+    hipLaunchKernelGGL(model_records_kernel, dim3((unsigned int)((pieces + 255) / 256)), dim3(256), 0, st, (const float*)Qs_soa, boxes, perm, m_pad, rec);
+    return hipGetLastError();
+}
+
+}  // namespace icp

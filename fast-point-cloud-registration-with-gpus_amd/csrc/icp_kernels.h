@@ -1,4 +1,12 @@
-// icp_kernels.h -- host-callable launchers of the gfx950 kernels (icp_kernels.hip).
+// icp_kernels.h -- host-callable launchers of the gfx950 kernels.  The kernels live in one translation unit per family
+// (same flags, gfx950 only; shared device helpers in icp_device.h / icp_device_sparse.h):
+//   icp_k_sparse.hip  nn_match_sparse      rows of 128 points: shared rows (Bunny.csv), box hierarchy (configs[4])
+//   icp_k_row64.hip   nn_match_row64       rows of 64 points: the hall scan and everything up to 32 768 points
+//   icp_k_f64.hip     nn_match_row64_f64   the CPU path's precision on the same structure
+//   icp_k_dense.hip   nn_match_kernel / nn_match_f32_v2 (every pair), merge, moments, transform + error, finalize, layout
+//   icp_k_plane.hip   kNN(4) + normals, OS1 decode + conversion
+//   icp_k_setup.hip   duplicates, spatial order, boxes / samples / records, row order + roles, the control block of a pass
+//   icp_launch.hip    the plan (nn_plan) and the dispatch (launch_nn): host code only
 // Internal to libicp_mi355x.so; the public surface is include/icp_mi355x.h.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -39,13 +47,39 @@ struct NNPlan {
 };
 int nn_block_threads(const NNPlan& pl);
 
+// Every switch the plan and the launchers look at, read ONCE per context (icp_create -> nn_tuning_from_env): nothing on the
+// launch path scans the environment (the advisor's finding on round 3), and a test that wants another form creates another
+// context.  Defaults = production.  All of these select among forms that give the same bits (INTEGRATION.md lists them).
+struct NNTuning {
+    int sparse = 1;          // ICP_NN_SPARSE=0: the dense packed kernel (every pair executed; no boxes, no hierarchy)
+    int cull = 1;            // ICP_NN_CULL=0: ... without its seeded early-out
+    int row = 0;             // ICP_NN_ROW=64 / 128: force the row size of the sparse kernels
+    int waves64 = 0;         // ICP_NN_WAVES=16: rows of 64 points as 16-wave blocks (what icp_set_exclusive selects)
+    int waves128 = 0;        // ICP_NN_WAVES128=4 / 8 / 16: waves per block of the rows of 128
+    int cold8 = 1;           // ICP_NN_COLD8=0: a plan of 4-wave blocks runs its cold launches on 4 waves too
+    int hier = -1;           // ICP_NN_HIER=0 / 1: box hierarchy never / always (-1: by the model's size)
+    int order = 1;           // ICP_NN_ORDER=0 / 2: rows in index order / heaviest first also where the rows are few
+    int share = 1;           // ICP_NN_SHARE=0: no shared rows
+    int share_resident = 1;  // ICP_NN_SHARE_RESIDENT=0: a resident launch keeps one block per row
+    int speculate = 1;       // ICP_NN_SPECULATE=0: resident launches without their speculative hit list
+    int f64_sparse = 1;      // ICP_F64_SPARSE=0: ICP_F64 clouds on the dense thread-per-point kernel
+    int sort = -1;           // ICP_SORT=0 / 1: spatially sorted views never / always (-1: by the extent test)
+    // ICP_NN_PHASES=file[:pass[:slots[:wipe]]] -- per-wave phase stamps of the matching kernels (tools/phase_report.py); the
+    // context owns the log
+    long long* phase_log = nullptr;
+    long long phase_cap = 0;
+    int phase_pass = -1;
+    int phase_wipe = 0;
+};
+NNTuning nn_tuning_from_env();
+
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 inline int pad_moving(int n) { return n <= 0 ? 0 : round_up(n, NN_POINT_ALIGN); }
 inline int pad_model(int m) { return m <= 0 ? 0 : round_up(m, NN_CHUNK); }
 
 // Choose the launch geometry.  `num_cus` comes from hipDeviceProp_t::multiProcessorCount.
 // force_dense != 0: the geometry of the dense packed kernel (every pair executed) even where the sparse kernel would run
-NNPlan nn_plan(int n, int m, int precision, int num_cus, int force_dense = 0);
+NNPlan nn_plan(int n, int m, int precision, int num_cus, const NNTuning& tune, int force_dense = 0);
 
 size_t elem_size(int precision);
 
@@ -87,7 +121,6 @@ enum { ICP_MB64_CMD = 6 };   // (within each part; tags: word 7 of each part)
 // the contract (icp_api.cpp, kMailLeaseS) never posts a message a block might no longer be waiting for.
 #define ICP_MAILBOX_BUDGET_S 4
 constexpr long long ICP_MAILBOX_BUDGET_TICKS = (long long)ICP_MAILBOX_BUDGET_S * 100000000ll;
-hipError_t launch_mailbox_selftest(const NNMailbox* mb, double* ack, hipStream_t st);
 struct NNFusedTransform {
     const double* R9;  // NULL with a mailbox
     const double* t3;
@@ -116,7 +149,7 @@ struct NNCullInputs {
     const void* boxes;  // per 8-point chunk of Q_scan: {lo.xyz, hi.xyz, 0, 0} floats (launch_model_boxes), or NULL
     const void* samples = nullptr;  // one point per chunk of Q_scan (launch_model_samples): the sparse kernel's cold start
     int waves64 = 0;                // rows of 64 points: 16 = sixteen waves per block where every row has a CU to itself (icp_set_exclusive)
-    float sample_spacing2 = 0.f;    // ... the squared spacing of the (<= 2048) samples a round uses, from the model's extent (0: unknown)
+    const NNTuning* tune = nullptr; // the context's switches (NULL: the defaults)
     // sparse kernel only: when the model's own order has no locality its scan copy is kept in Morton order instead
     // (boxes and samples then describe THAT copy) with q_perm[sorted j] = model index; likewise the moving points are
     // dealt to the blocks in Morton order of their initial positions, p_perm[slot] = point.  NULL = identity.
@@ -251,9 +284,6 @@ size_t model_boxes_f64_bytes(int m_pad);
 size_t model_samples_f64_bytes(int m_pad);
 hipError_t launch_model_tables_f64(const void* Q_soa, int m_pad, void* boxes, void* samples, hipStream_t st);
 hipError_t launch_model_samples(const void* Qs_soa, int m_pad, float* samples, hipStream_t st);
-// diagnostic: per-wave phase stamps (s_memrealtime, 100 MHz) of the packed matching kernel, 10 slots per wave indexed
-// ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 10 + phase; NULL switches it off (the default)
-void set_phase_log(long long* dev, long long slots);
 // boxes: model_boxes_bytes(m_pad) -- the chunk boxes, followed by the boxes of every 64 of them and of every 64 of
 // those (the upper search levels of a large model)
 size_t model_boxes_bytes(int m_pad);

@@ -342,7 +342,7 @@ def test_fp64_loop_forms_are_bit_identical(pkg, orc, golden, monkeypatch):
     D, M = orc.synth_icp_cpu(48)
     Ph, Qh = orc.hall_clouds(golden)
     Ph, Qh = Ph.astype(np.float64), Qh.astype(np.float64)
-    forms = {"resident": {}, "resident_host_mailbox": {"ICP_MAILBOX": "host"}, "resident_plain_stores": {"ICP_MAILBOX_AVX": "0"},
+    forms = {"resident": {}, "resident_host_mailbox": {"ICP_MAILBOX": "host"}, "resident_plain_stores": {"ICP_MAILBOX": "plain"},
              "stepwise": {"ICP_RESIDENT": "0"}}
     def run(c):
         a = c.point_to_point(D, M, max_iter=200, tol=1e-5)
@@ -524,14 +524,14 @@ LOOP_FORMS = {
     "resident_forced": {"ICP_RESIDENT": "2"},           # (a plan with shared rows runs armed unless told otherwise)
     "resident_no_speculation": {"ICP_NN_SPECULATE": "0"},   # (cached per process: effective only in a run that starts with it)
     "resident_host_mailbox": {"ICP_MAILBOX": "host"},
-    "resident_plain_stores": {"ICP_MAILBOX_AVX": "0"},   # the mailbox line written word by word (a CPU without AVX)
+    "resident_plain_stores": {"ICP_MAILBOX": "plain"},   # the mailbox line written word by word (a CPU without AVX)
     "armed": {"ICP_RESIDENT": "0"},
     "stepwise": {"ICP_RESIDENT": "0", "ICP_ARMED": "0"},
 }
 
 
 def _run_form(pkg, monkeypatch, env, fn):
-    for k in ("ICP_MAILBOX", "ICP_MAILBOX_AVX", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_SPECULATE"):
+    for k in ("ICP_MAILBOX", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_SPECULATE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)           # read by icp_create
@@ -713,9 +713,9 @@ def test_two_ranks_one_node_local_communicator(pkg, orc, golden, resident):
     """two ranks with a shard of the hall scan each, both on cuda:0: both end with the same bits, and with the run of one rank
     holding the whole cloud up to the association of the fp64 sums.  Ranks that share a DEVICE run one launch per pass by
     default (two resident kernels need not fit the machine together: the circular wait of icp_api.cpp, can_reside);
-    ICP_SHARED_DEVICE_RESIDENT=1 -- two hall-sized shards do fit -- keeps each rank's resident kernel, the form two ranks on
+    ICP_DEBUG=shared_resident -- two hall-sized shards do fit -- keeps each rank's resident kernel, the form two ranks on
     two devices run"""
-    got = _two_ranks_on_one_device(pkg, golden, pkg.ICP_POINT_TO_POINT, np.float32, {"ICP_SHARED_DEVICE_RESIDENT": "1"} if resident else None)
+    got = _two_ranks_on_one_device(pkg, golden, pkg.ICP_POINT_TO_POINT, np.float32, {"ICP_DEBUG": "shared_resident"} if resident else None)
     P, Q = orc.hall_clouds(golden)
     want = orc.icp_p2p_f32x(P, Q, 100, 1e-6)
     assert_same_run(got[0]["it"], np.array(got[0]["err"]), np.array(got[0]["T"]), want, 1e-6, fp32=True)

@@ -86,12 +86,12 @@ print(json.dumps(dict(it=r.iterations, T=r.T.tolist(), err=r.err.tolist(), sec=r
 @pytest.mark.parametrize("form", ["resident", "armed"])
 @pytest.mark.parametrize("stall", ["3:1.7", "5:4.6"])
 def test_late_host_withdraws_and_resumes(form, stall):
-    """ICP_DEBUG_STALL makes the host sleep before it publishes one pass's message: 1.7 s is past the host's lease (it
+    """ICP_DEBUG=stall=pass:seconds makes the host sleep before it publishes one pass's message: 1.7 s is past the host's lease (it
     withdraws the kernel itself), 4.6 s is past the kernel's own wall-clock budget (every block has given up).  Either
     way no block may act on a message another block missed: the run must end with exactly the bits of an undisturbed one."""
     env = {"ICP_RESIDENT": "0"} if form == "armed" else {}
     ref = _child(STALL_CODE, env)
-    got = _child(STALL_CODE, dict(env, ICP_DEBUG_STALL=stall))
+    got = _child(STALL_CODE, dict(env, ICP_DEBUG="stall=" + stall))
     assert got["sec"] > float(stall.split(":")[1]) - 0.2            # (the stall really happened)
     for k in ("it", "T", "err", "idx", "moved"):
         assert got[k] == ref[k], k
@@ -115,13 +115,13 @@ print(json.dumps(dict(it=r.iterations, T=r.T.tolist(), err=r.err.tolist(), sec=r
 
 @pytest.mark.parametrize("form", ["resident", "armed"])
 def test_a_pass_that_never_delivers_is_finished_step_wise(form):
-    """ICP_DEBUG_LOSE_MESSAGE: the message of one pass is never posted -- what a block that never sees its message, or blocks
+    """ICP_DEBUG=lose=pass: the message of one pass is never posted -- what a block that never sees its message, or blocks
     kept off the machine, look like from the host.  Round 2 returned ICP_ERR_HIP there.  Now the waiting kernel is withdrawn
     (its own wall-clock budget ends it) and the registration is run again from the uploaded cloud with plain launches: the
     caller gets the bits of an undisturbed run, icp_recoveries counts it, and the context keeps working at full speed."""
     env = {"ICP_RESIDENT": "0"} if form == "armed" else {}
     ref = _child(LOST_CODE, env)
-    got = _child(LOST_CODE, dict(env, ICP_DEBUG_LOSE_MESSAGE="3"))
+    got = _child(LOST_CODE, dict(env, ICP_DEBUG="lose=3"))
     assert ref["rec"] == 0 and got["rec"] == 1 and got["rec2"] == 1
     assert got["sec"] > 1.5                                          # (the pass really went missing: the row poll's 2 s)
     assert got["sec2"] < 0.1 and got["T2"] == ref["T"]

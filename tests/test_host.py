@@ -35,9 +35,10 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_matching_isa_has_no_fused_multiply_add():
     """bit-exact correspondences need separately rounded sub/mul/add: the ISA of every nn_match / knn
     kernel must not contain fp fma/mad/fmac (integer mad for addressing is fine)."""
-    asm = os.path.join(ROOT, "fast-point-cloud-registration-with-gpus_amd", "csrc", "build", "icp_kernels.s")
-    assert os.path.exists(asm), "run `python __graft_entry__.py build` first"
-    text = open(asm).read()
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "fast-point-cloud-registration-with-gpus_amd", "csrc", "build", "icp_k_*.s")))
+    assert len(files) == 6, "run `python __graft_entry__.py build` first"   # one translation unit per kernel family (csrc/Makefile)
+    text = "".join(open(f).read() for f in files)
     kernels = re.findall(r"^(_ZN3icp\w*(?:nn_match|knn4)\w*):[^\n]*\n(.*?)\.Lfunc_end", text, flags=re.S | re.M)
     assert len(kernels) >= 6
     bad = re.compile(r"\bv_(?:pk_)?(?:fma|fmac|mad|mac)_(?:f32|f64|legacy_f32)")

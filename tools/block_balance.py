@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """From an ICP_NN_PHASES dump of a resident hall pass: how evenly a block's waves share its scan.
-   ICP_NN_WAVES=16 ICP_NN_PHASE_PASS=6 ICP_NN_PHASES=ph.bin python3 tools/phase_run.py 9; python3 tools/block_balance.py ph.bin 16"""
+   ICP_NN_WAVES=16 ICP_NN_PHASES=ph.bin:6 python3 tools/phase_run.py 9; python3 tools/block_balance.py ph.bin 16"""
 import sys, numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.int64)
 nw = int(sys.argv[2]) if len(sys.argv) > 2 else 8

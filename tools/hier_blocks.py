@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase log of a launch of the hierarchical 16-wave kernel (ICP_NN_PHASES, ICP_NN_PHASE_SLOTS large enough for every block):
+"""Phase log of a launch of the hierarchical 16-wave kernel (ICP_NN_PHASES=file:pass:slots:wipe, slots large enough for every block):
 how long the blocks took, what that adds up to per CU, and how long the launch lasted -- the difference is imbalance.
 usage: hier_blocks.py ph.bin [cus=256] [waves per block=16] [blocks of the launch: the log is not wiped between launches, and
 an earlier launch of more or larger blocks leaves its stamps behind the last one's]"""
@@ -8,7 +8,7 @@ NW = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 a = np.fromfile(sys.argv[1], dtype=np.int64); a = a[: len(a) // (NW * 10) * (NW * 10)].reshape(-1, NW, 10)
 cus = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 if len(sys.argv) > 4: a = a[: int(sys.argv[4])]
-# (run with ICP_NN_PHASE_WIPE=1: the log then holds the last launch only.  A spare block leaves nothing; a part of a split row
+# (run with wipe = 1 in the ICP_NN_PHASES spec: the log then holds the last launch only.  A spare block leaves nothing; a part of a split row
 # that does not close it ends at its ticket, phase 7; the closing block at phase 9)
 live = a[:, 0, 0] > 0
 a = a[live]

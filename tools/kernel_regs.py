@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""register / scratch / LDS use of every kernel in build/icp_kernels.s (optionally filtered by a substring)"""
+"""register / scratch / LDS use of every kernel in build/icp_k_*.s (optionally filtered by a substring)"""
 import re
 import subprocess
 import sys
 
-path = "fast-point-cloud-registration-with-gpus_amd/csrc/build/icp_kernels.s"
+import glob
+paths = sorted(glob.glob("fast-point-cloud-registration-with-gpus_amd/csrc/build/icp_k_*.s"))
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-s = open(path).read()
+s = "".join(open(p).read() for p in paths)
 rows = []
 for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
     name, body = m.group(1), m.group(2)

@@ -5,7 +5,7 @@
 
 Stamps are s_memrealtime ticks (100 MHz -> 10 ns).  Phases: 0 entry, 1 points loaded (+ message received, fused
 transform/error), 2 bounds seeded, 3 scan done, 4 results handed in, 5 block met, 6 results merged (or keys merged, atomics
-drained), 7 moments accumulated (or ticket drawn), 8 row stores issued, 9 drained + tagged (closing wave only).  With ICP_NN_PHASE_PASS=p only pass p of a
+drained), 7 moments accumulated (or ticket drawn), 8 row stores issued, 9 drained + tagged (closing wave only).  With ICP_NN_PHASES=file:p only pass p of a
 resident launch is stamped (phase 0 then belongs to the launch, not to the pass)."""
 import sys
 import numpy as np

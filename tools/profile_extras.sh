@@ -19,7 +19,7 @@ tail -2 $O/*.err
   done
 } > $O/${T}_reg_time.txt 2>&1
 for w in 8 16; do
-  ICP_NN_WAVES=$w ICP_NN_PHASE_PASS=6 ICP_NN_PHASES=$O/ph.bin python3 tools/phase_run.py 9 > /dev/null 2>&1 && python3 tools/phase_report.py $O/ph.bin $w > $O/${T}_phase_log_resident_pass_${w}_waves.txt
+  ICP_NN_WAVES=$w ICP_NN_PHASES=$O/ph.bin:6 python3 tools/phase_run.py 9 > /dev/null 2>&1 && python3 tools/phase_report.py $O/ph.bin $w > $O/${T}_phase_log_resident_pass_${w}_waves.txt
   rm -f $O/ph.bin
 done
 python3 tools/bunny_first.py > $O/${T}_bunny_first_registration.txt 2>&1

@@ -9,7 +9,7 @@ against the kernel that executes every pair, and a short registration."""
 import os, sys, time, numpy as np
 DENSE = "--dense" in sys.argv   # the kernel choice is read once per process: the dense comparison is a run of its own
 if DENSE:
-    os.environ["ICP_NN_SPARSE"] = "0"; os.environ["ICP_NN_BOXES"] = "0"
+    os.environ["ICP_NN_SPARSE"] = "0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package

@@ -32,7 +32,7 @@ o = np.argsort(-scan)[:12]
 for k in o:
     print(f"  block row {row[k]:4d} part {part[k]:2d}/{parts[k]:2d}  hits {hits[k]:5d}  (the row last time: {prev[k]:5d}, target per block {T[k]:4d})  scan {scan[k]:6.2f} us  scan done at {end[k]:6.2f} us")
 c = np.corrcoef(hits, scan)[0, 1]
-ok_ = np.isfinite(hits) & np.isfinite(scan) & (np.abs(scan) < 1e6)   # (stamps of an older launch among the last one's: ICP_NN_PHASE_WIPE=1 avoids them)
+ok_ = np.isfinite(hits) & np.isfinite(scan) & (np.abs(scan) < 1e6)   # (stamps of an older launch among the last one's: wipe = 1 in the ICP_NN_PHASES spec avoids them)
 fit = np.polyfit(hits[ok_], scan[ok_], 1) if ok_.sum() > 2 else (float('nan'), float('nan'))
 print(f"scan time vs hits: {fit[1]:.2f} us + {1e3 * fit[0]:.1f} ns per hit (correlation {c:.2f})")
 first = part == 0
