@@ -227,6 +227,7 @@ struct LoopState {
     bool timed_nn = false;
     bool numeric_failure = false;  // the minimisation refused the last pass's moments: the loop is over, its state stays readable
     bool host_reduce = false;  // how the pending enqueue's partial rows are being reduced
+    bool final_poll = false;   // ... inside the launch itself, which leaves the vector and the pass's tag in c->h_final (the host polls ONE tag)
     bool matched = false;      // a matching pass of THIS loop has filled idx[cur]
     bool rows_have_err = false; // slot 0 of the pending moment rows carries the error shares (fused tail)
     bool rows_compact = false;  // the pending rows are compact (NN_CROW doubles; slot 0 = error share with the tag in its low mantissa bits)
@@ -296,6 +297,8 @@ struct icp_ctx {
     DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
     struct PrepSmall { float box[4]; double totals[4]; int voided; int pad_; };
     DevBuf fin_scratch;      // finalize in two stages (many rows): 256 x ICP_NMOM doubles
+    DevBuf fin_tickets;      // rows added up inside the matching launch (NNTail::fin_*): NN_FIN_GROUPS + 1 tickets, zero between launches
+    double* h_final = nullptr;   // ... and where the launch leaves its ICP_NMOM vector for the host: pinned, coherent; the pass's tag in the last slot
     DevBuf work;             // icp_set_work_counting: NN_WORK_SLOTS counters of the work the sparse kernel executes
     bool count_work = false;
     DevBuf phase_log;        // ICP_NN_PHASES diagnostic
@@ -375,7 +378,10 @@ struct icp_ctx {
     // resident launches need) -- or, for clouds of more than kHostRowsMax rows, the device (two-stage finalize, 256 bytes come
     // back): 78 125 rows of the 10 M-point cloud are 20 MB over PCIe and a pass through them on one core per iteration,
     // 0.7 ms of 13 (profiles/r3: the library-issued RCCL route, which reduces on the device, was FASTER than the default).
-    static constexpr int kHostRowsMax = 16384;
+    // Round 4: from 1 025 rows up (beyond what the host's sweep takes) the sparse kernels add their rows up INSIDE the launch (two
+    // levels of tickets, NNTail::fin_*) and leave the vector with the pass's tag in pinned memory: no finalize launches, no copy, no
+    // synchronisation, and such a pass can be armed ahead like any other.
+    static constexpr int kHostRowsMax = 1024;
     bool host_reduce() const { return !comm && mom_dev == (double*)mom_own.p && h_mom_partials != nullptr && (plan.blocks_x <= host_rows_max || plan.n == 0); }
     int host_rows_max = kHostRowsMax;   // (ICP_HOST_ROWS_MAX: A/B runs)
     icp::NNPlan plan{};
@@ -453,6 +459,14 @@ int ensure_work_buffers(icp_ctx* c)
             c->share_cold_seq = 0;
         }
         HIP_TRY(c->seed_pub.ensure((size_t)pl.blocks_x * 384 * sizeof(float)));
+    }
+    if (pl.sparse && pl.version == 2 && pl.row != 64 && pl.blocks_x > c->host_rows_max && icp::nn_can_fuse_tail(pl)) {
+        // rows added up inside the launch
+        if (c->fin_tickets.cap == 0) {
+            HIP_TRY(c->fin_tickets.ensure((icp::NN_FIN_GROUPS + 1) * sizeof(unsigned int)));
+            HIP_TRY(hipMemsetAsync(c->fin_tickets.p, 0, c->fin_tickets.cap, c->stream));
+        }
+        HIP_TRY(c->fin_scratch.ensure((size_t)icp::NN_FIN_GROUPS * ICP_NMOM * sizeof(double)));
     }
     c->row_order = nullptr;
     if (pl.order) {
@@ -683,6 +697,8 @@ int icp_create(int device, icp_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mom, ICP_NMOM * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_nonfinite, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_final, ICP_NMOM * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) std::memset(c->h_final, 0, ICP_NMOM * sizeof(double));
     if (e == hipSuccess) {
         // mailbox: fine-grained device memory written through the PCIe BAR when the machine allows it (every block
         // polls its own memory), else pinned host memory polled by block 0 and relayed (ICP_MAILBOX=host forces that)
@@ -776,11 +792,12 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->work, &c->fin_scratch, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->order_roles, &c->order_totals, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qrec, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->work, &c->fin_scratch, &c->fin_tickets, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->order_roles, &c->order_totals, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qrec, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
     if (c->h_nonfinite) (void)hipHostFree(c->h_nonfinite);
+    if (c->h_final) (void)hipHostFree(c->h_final);
     if (c->h_mail) { if (c->mail_in_bar) (void)hipFree(c->h_mail); else (void)hipHostFree(c->h_mail); }
     if (c->relay) (void)hipFree(c->relay);
     if (c->h_mom_partials) (void)hipHostFree(c->h_mom_partials);
@@ -1100,6 +1117,26 @@ int icp_set_model_normals(icp_ctx* c, const void* nxyz, int m)
     return ICP_OK;
 }
 
+// Rows added up inside the matching launch (NNTail::fin_*, icp_device.h): the sparse kernels with rows of 128 points, a fused tail,
+// and more rows than the host takes (host_rows_max).  to_host: the vector lands in pinned memory with the pass's tag (the host
+// polls it) -- else in the device vector a collective, or the caller, goes on from.
+static bool fin_in_launch(const icp_ctx* c, const icp::NNPlan& pl)
+{
+    return c->fused_tail && pl.sparse && pl.version == 2 && pl.row != 64 && icp::nn_can_fuse_tail(pl) && pl.blocks_x > c->host_rows_max &&
+           c->fin_tickets.p != nullptr && c->fin_scratch.p != nullptr && c->h_final != nullptr;
+}
+static bool fin_to_host(const icp_ctx* c) { return !c->comm && c->mom_dev == (double*)c->mom_own.p; }
+static void fill_fin(const icp_ctx* c, icp::NNTailArgs& ta)
+{
+    ta.rows = (double*)c->mom_partials.p;
+    ta.rows_on_device = 1;
+    ta.compact = 0;
+    ta.fin_tickets = (unsigned int*)c->fin_tickets.p;
+    ta.fin_scratch = (double*)c->fin_scratch.p;
+    ta.fin_host = fin_to_host(c) ? 1 : 0;
+    ta.fin_out = ta.fin_host ? c->h_final : c->mom_dev;
+}
+
 // rows the host itself adds up (single GPU, or ranks meeting in host memory) leave the sparse point-to-point kernels in
 // the compact two-cache-line form (icp_kernels.h, NNTailArgs)
 static bool use_compact_rows(const icp_ctx* c, const icp::NNPlan& pl, int metric, const double* rows)
@@ -1405,6 +1442,8 @@ int icp_loop_begin(icp_ctx* c, const icp_params* prm)
     LoopState& L = c->loop;
     L = LoopState();
     if (c->order_launches > 0) { c->order_regs++; c->order_launches = 0; }   // (the loop before left its rows' counters: history for this one's cold pass)
+    // (the tickets of the in-launch finalize are zero between launches; a loop that was abandoned in mid-pass may have left some drawn)
+    if (c->fin_tickets.p != nullptr && fin_in_launch(c, c->plan)) HIP_TRY(hipMemsetAsync(c->fin_tickets.p, 0, c->fin_tickets.cap, c->stream));
     if (int rc = L.H.begin(*prm)) return fail(rc, "bad loop parameters");
     L.active = true;
     L.from_pristine = c->moving_untouched;
@@ -1449,7 +1488,9 @@ static int loop_enqueue_body(icp_ctx* c)
         L.H.note_applied();
     }
     L.timed_nn = false;
+    L.final_poll = false;
     bool slots_written = false;
+    bool fin = false;   // this pass's rows are added up inside its launch
     if (!final_only) {
         // the previous pass's matches seed the early-out bound (any valid index would do)
         if (c->fused_tail && icp::nn_can_fuse_tail(pl)) { if (int rc = prepare_row_order(c)) return rc; } else c->row_order = nullptr;
@@ -1474,6 +1515,7 @@ static int loop_enqueue_body(icp_ctx* c)
             ta.tag = (double)take_tags(c, 1);
             ta.compact = use_compact_rows(c, pl, ta.metric, mom_rows) ? 1 : 0;
             ta.rows_on_device = host_reduce ? 0 : 1;
+            if (!host_reduce && fin_in_launch(c, pl)) { fill_fin(c, ta); fin = true; }
         }
         L.rows_compact = tail && ta.compact != 0;
         if (host_reduce) prepare_rows_format(c, L.rows_compact);   // (also the two-kernel form: launch_moments writes full rows)
@@ -1508,15 +1550,18 @@ static int loop_enqueue_body(icp_ctx* c)
         }
     }
     if (!host_reduce) {
-        if (L.mom_blocks > 2048) HIP_TRY(c->fin_scratch.ensure(256 * ICP_NMOM * sizeof(double)));
-        HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
-                                     (const double*)c->err_partials.p, L.err_blocks, L.rows_have_err ? 1 : 0, c->stream, (double*)c->fin_scratch.p));
+        if (!fin) {
+            if (L.mom_blocks > 2048) HIP_TRY(c->fin_scratch.ensure(256 * ICP_NMOM * sizeof(double)));
+            HIP_TRY(icp::launch_finalize(c->mom_dev, (const double*)c->mom_partials.p, L.mom_blocks,
+                                         (const double*)c->err_partials.p, L.err_blocks, L.rows_have_err ? 1 : 0, c->stream, (double*)c->fin_scratch.p));
+        }
         if (c->comm) {  // the iteration's one collective: 32 doubles, in place, on the loop's stream
             std::string err;
             if (int rc = icp::comm_allreduce_sum_f64(c->comm, c->mom_dev, ICP_NMOM, c->stream, err)) return fail(rc, err);
         }
     }
     L.host_reduce = host_reduce;
+    L.final_poll = fin && fin_to_host(c);
     L.wait_tag = (double)c->tag_seq;
     L.pending = true;
     L.slot_written = slots_written;   // (a fused pass of the sparse kernels left its points and matches in slot order)
@@ -1708,6 +1753,32 @@ static int loop_complete_body(icp_ctx* c, int* done)
             start_sum();
             for (int b = 0; b < L.mom_blocks; ++b) add_row(b);
         }
+    } else if (L.final_poll) {
+        // the launch itself added its rows up and leaves the vector in pinned memory, the pass's tag in its last slot
+        const volatile double* fin = c->h_final;
+        bool there = false;
+        if (!L.timed_nn && c->poll) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 1; !(there = fin[ICP_NMOM - 1] == L.wait_tag); ++spins)
+                if ((spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kRowPollS) break;
+            c->rows_done_at = std::chrono::steady_clock::now();
+        }
+        if (!there) {
+            // (a timed pass is completed with a synchronisation; so is one whose tag never came: the runtime says what happened)
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (fin[ICP_NMOM - 1] != L.wait_tag) {
+                L.pending = false;
+                char msg[200];
+                std::snprintf(msg, sizeof msg, "a matching pass ended without leaving its sums: the vector carries tag %.0f, expected %.0f (armed launch timed out?)",
+                              fin[ICP_NMOM - 1], L.wait_tag);
+                c->rows_timed_out = true;
+                return fail(ICP_ERR_HIP, msg);
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int k = 0; k < ICP_NMOM - 1; ++k) c->h_mom[k] = fin[k];
+        c->h_mom[ICP_NMOM - 1] = 0.0;
+        tr1 = std::chrono::steady_clock::now();
     } else {
         HIP_TRY(hipMemcpyAsync(c->h_mom, c->mom_dev, ICP_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1782,7 +1853,7 @@ bool can_arm(icp_ctx* c)
 {
     const LoopState& L = c->loop;
     const icp::NNPlan& pl = c->plan;
-    return c->arm && !c->shares_device && !share_wants_resident(c) && c->prec == ICP_F32 && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && c->host_reduce() && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
+    return c->arm && !c->shares_device && !share_wants_resident(c) && c->prec == ICP_F32 && c->h_mail && (c->relay || c->mail_in_bar) && c->poll && (c->host_reduce() || (fin_in_launch(c, pl) && fin_to_host(c))) && c->fused_tail && pl.sparse && icp::nn_can_fuse_tail(pl) &&
            icp::nn_can_fuse_transform(pl) && c->have_scan_copy && c->use_boxes && L.active && L.pending && !L.armed &&
            L.matched && !L.H.done && !L.H.have_rt &&
            !L.timed_nn &&  // a timed pass is completed with a stream synchronisation: nothing may wait behind it
@@ -1811,8 +1882,10 @@ int loop_arm(icp_ctx* c)
     ta.rows = c->h_mom_partials;
     ta.tag = tag;
     ta.compact = use_compact_rows(c, pl, ta.metric, ta.rows) ? 1 : 0;
+    const bool fin = !c->host_reduce();   // (can_arm: then the rows are added up inside the launch, the vector comes back in pinned memory)
+    if (fin) fill_fin(c, ta);
     L.armed_compact = ta.compact != 0;
-    prepare_rows_format(c, L.armed_compact);
+    if (!fin) prepare_rows_format(c, L.armed_compact);
     icp::NNFusedTransform ft{nullptr, nullptr, (const int32_t*)c->idx[prev_cur].p, c->P2.p, (double*)c->err_partials.p, mb, c->mail_in_bar ? nullptr : c->relay, tag};
     // every armed pass leaves its points and matches in slot order; the next one starts from them (one level of
     // coalesced loads instead of slot -> point -> seed -> model point) if the pass before it was such a pass
@@ -1846,7 +1919,8 @@ void loop_release_armed(icp_ctx* c)
     L.err_blocks = 0;
     L.rows_have_err = true;
     L.rows_compact = L.armed_compact;
-    L.host_reduce = true;
+    L.host_reduce = c->host_reduce();
+    L.final_poll = !L.host_reduce;
     L.timed_nn = false;
     L.wait_tag = L.armed_tag;
     L.pending = true;

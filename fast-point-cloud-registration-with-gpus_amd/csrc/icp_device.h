@@ -284,6 +284,17 @@ struct NNTail {
     int row;                   // the row this block closes, or -1: blockIdx.x (shared rows: a block's row is not its index)
     int idx_through;           // the correspondences leave as agent-scope (write-through) stores: a resident launch whose rows are closed now by one
                                // block, now by another -- two XCDs' L2s holding dirty copies of one line would write them back in no order
+    // Rows added up INSIDE the launch (round 4; clouds of more than 1024 rows, nn_match_sparse): the rows stay in device memory, are
+    // grouped into <= NN_FIN_GROUPS contiguous ranges, and whoever closes the LAST row of a range (a ticket per range) adds the
+    // range's rows in index order into fin_scratch; whoever closes the last RANGE (one more ticket) adds the ranges in order and
+    // leaves the launch's ICP_NMOM vector in fin_out -- pinned host memory with the pass's tag in its last slot (the host polls ONE
+    // tag instead of walking thousands of rows; no finalize kernels, no copy back, no synchronisation), or the device vector a
+    // collective follows on.  Fixed ranges, fixed order: the same bits whatever order the blocks ran in.  NULL: not used.
+    unsigned int* fin_tickets; // [NN_FIN_GROUPS + 1], zero between launches (the closers reset them)
+    double* fin_scratch;       // [NN_FIN_GROUPS][ICP_NMOM]
+    double* fin_out;           // [ICP_NMOM]
+    int fin_rows, fin_per, fin_groups;
+    int fin_host;              // fin_out is host memory: system-scope stores, the tag last
 };
 __device__ __forceinline__ double crow_pack(double err, unsigned int tag_lo)
 {
@@ -359,6 +370,7 @@ struct NNFuse {
     const int32_t* row_order;  // ordered rows: block b works on row row_order[b] (heaviest first) -- or NULL
     unsigned int* row_hits;    // ... and adds the hits of its lists to row_hits[row]
     int refine_min, refine_cnt; // hierarchical search: a pass that lists at least refine_min super boxes takes a refinement round over <= refine_cnt of their chunk samples (0: never)
+    int refine_rounds;         // ... and up to this many of them: a later round re-lists the super boxes with the bound the one before has left
     int round_supers;          // hierarchical search: super boxes per round of the chunk find (<= 64: the hit list holds their chunks)
     const float* records;      // hierarchical search: one 160-byte record per chunk (model_records_kernel) -- a hit is fetched from it -- or NULL
     float* seed_pub;           // resident launch with shared rows: [rows][3][128] -- whichever block closes a split row leaves the matches' coordinates

@@ -152,6 +152,53 @@ __device__ __forceinline__ void scan8_min(const float4 qx0, const float4 qx1, co
 template <int TAIL, bool phase_diag_, int NWP, bool ROWARG = false>
 __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, const NNFuse& fuse, const NNTail& tail, double err_row, int phase_pass_);
 
+// The in-launch finalize (NNTail::fin_*): called by the wave that has just stored row `rowi` (agent-scope stores, drained).  Lane
+// (part, k) = (lane >> 5, lane & 31) adds slot k of every second row / range, eight loads in flight; part 0 + part 1 at the end.
+__device__ __forceinline__ void fin_close(const NNTail& tail, unsigned int rowi, int lane)
+{
+    const int per = tail.fin_per, g = (int)rowi / per, b0 = g * per;
+    const int cnt = min(per, tail.fin_rows - b0);
+    unsigned int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(&tail.fin_tickets[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+    if (t != (unsigned int)(cnt - 1)) return;
+    const int k = lane & 31, part = lane >> 5;
+    auto add_in_order = [&](const double* src, int count) {   // src[r * ICP_NMOM + k], r = part, part + 2, ...
+        double s = 0.0;
+        if (k != ICP_NMOM - 1)                                  // (the rows' tag slot is not a moment)
+            for (int r0 = part; r0 < count; r0 += 16) {
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = r0 + 2 * j;
+                    v[j] = r < count ? __hip_atomic_load(&src[(size_t)r * ICP_NMOM + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j];
+            }
+        const double o = __shfl_xor(s, 32, 64);
+        return part == 0 ? s + o : o + s;                       // even rows + odd rows, in both halves of the wave
+    };
+    const double tot = add_in_order(tail.rows + (size_t)b0 * ICP_NMOM, cnt);
+    if (lane == 0) __hip_atomic_store(&tail.fin_tickets[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (lane < ICP_NMOM) __hip_atomic_store(&tail.fin_scratch[(size_t)g * ICP_NMOM + lane], lane == ICP_NMOM - 1 ? 0.0 : tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int t2 = 0;
+    if (lane == 0) t2 = __hip_atomic_fetch_add(&tail.fin_tickets[NN_FIN_GROUPS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)t2);
+    if (t2 != (unsigned int)(tail.fin_groups - 1)) return;
+    const double all = add_in_order(tail.fin_scratch, tail.fin_groups);
+    if (lane == 0) __hip_atomic_store(&tail.fin_tickets[NN_FIN_GROUPS], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tail.fin_host != 0) {
+        // the host polls the tag in the vector's last slot: the sums first, drained, then the tag (as a row's)
+        if (lane < ICP_NMOM - 1) __hip_atomic_store(&tail.fin_out[lane], all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&tail.fin_out[ICP_NMOM - 1], tail.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (lane < ICP_NMOM - 1) {
+        __hip_atomic_store(&tail.fin_out[lane], all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by what follows on the stream)
+    }
+}
+
 // moment row of one row of 128 moving points, by ONE wave holding them two per lane (px.x = point lane,
 // px.y = point lane + 64) with their final correspondences j[]: stores idx, gathers q (and the normal),
 // accumulates in fp64, reduces through LDS in lane order and writes the row + completion tag.
@@ -292,6 +339,22 @@ __device__ __forceinline__ void tail_reduce_store(double (*tr)[65], int lane, co
     // sake of 19 doubles; the other outputs of the pass are for later kernels and become visible at kernel end.)
     const bool compact = TAIL == 1 && tail.compact != 0;
     if (compact) row = tail.rows + (size_t)rowi * NN_CROW;
+    if constexpr (ROWARG) {
+        if (tail.rows_on_device != 0 && tail.fin_tickets != nullptr) {
+            // (round 4: the rows are added up inside this launch -- agent-scope stores, drained, then the tickets: fin_close)
+            if (lane < NACC) {
+                double sum = tp[lane];
+#pragma unroll
+                for (int q = 1; q < PARTS; ++q) sum += tp[q * NACC + lane];
+                __hip_atomic_store(&row[1 + lane], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) __hip_atomic_store(&row[ICP_MOM_ERR], err_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ICP_PHASE(8)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fin_close(tail, rowi, lane);
+            return;
+        }
+    }
     if (tail.rows_on_device != 0) {
         // (round 3: rows that a later kernel adds up -- finalize, clouds of many rows or a device communicator -- need neither
         // write-through stores nor the wait for them nor a tag: the kernel boundary orders them)

@@ -356,6 +356,129 @@ __global__ __launch_bounds__(1024) void row_roles_kernel(const unsigned int* __r
     }
 }
 
+// ONE launch instead of nine (round 4; up to NN_CONTROL_MAX_ROWS rows -- the share of one rank of eight of configs[4] has 9 768): the
+// counters of the launch before are read and zeroed, sorted and dealt as roles by a single workgroup.  The order need not be exact --
+// any order is exact for the RESULT; what it decides is how even the load is -- so the 20-bit counts are quantised to 10 bits (exact
+// below 128, then 6 bits of mantissa per power of two: 1.6 % resolution) and sorted by three stable 4-bit counting passes in LDS:
+// thread t owns 16 consecutive entries, counts them per digit in its own column of cnt[digit][thread], one block-wide exclusive scan
+// over the 16 x 1024 counters gives every (digit, thread) its first output slot.  Ties keep the row order: the same roles every run.
+// The split of the heaviest rows follows row_roles_kernel statement by statement (on the exact counts).
+constexpr int NN_CONTROL_MAX_ROWS = 16384;
+__global__ __launch_bounds__(1024) void pass_control_kernel(unsigned int* __restrict__ hits, int rows, unsigned int* __restrict__ exact, int min_part, int total_div,
+                                                            int32_t* __restrict__ roles)
+{
+    __shared__ unsigned short key[NN_CONTROL_MAX_ROWS];        // quantised count, inverted: ascending = heaviest first
+    __shared__ unsigned short ids[2][NN_CONTROL_MAX_ROWS];     // ping-pong: the order so far
+    __shared__ unsigned short cnt[16 * 1024];                  // [digit][thread]
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    auto block_sum = [&](int v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        __syncthreads();   // (the words are free again)
+        if (lane == 0) wsum[w] = v;
+        __syncthreads();
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += wsum[k];
+        return s;
+    };
+    // ---- read + zero the counters, quantise ----
+    unsigned long long mine = 0ull;
+    for (int r = t; r < NN_CONTROL_MAX_ROWS; r += 1024) {
+        unsigned int h = 0u;
+        if (r < rows) {
+            h = hits[r];
+            hits[r] = 0u;                                          // (the next launch counts afresh)
+            h = h > 0xfffffu ? 0xfffffu : h;
+            exact[r] = h;
+            mine += h;
+        }
+        unsigned int q = h;
+        if (h >= 128u) { const int e = 31 - __builtin_clz(h); q = 128u + (unsigned int)(e - 7) * 64u + ((h >> (e - 6)) & 63u); }   // <= 959
+        key[r] = (unsigned short)(r < rows ? 1023u - q : 1023u);   // (rows beyond the cloud sort behind everything; they are never dealt)
+        ids[0][r] = (unsigned short)r;
+    }
+    // (the sum of the counters: at most 16 384 x 2^20 = 2^34 -- in two 20-bit halves through the int reduction)
+    const unsigned long long total = ((unsigned long long)(unsigned int)block_sum((int)(mine >> 17)) << 17) + (unsigned long long)(unsigned int)block_sum((int)(mine & 0x1ffffull));
+    __syncthreads();
+    // ---- three stable counting passes of 4 bits ----
+    int cur = 0;
+    for (int shift = 0; shift < 12; shift += 4) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[d * 1024 + t] = 0;
+        // (own column: no atomics)
+        for (int e = 0; e < 16; ++e) { const int d = (key[ids[cur][t * 16 + e]] >> shift) & 15; cnt[d * 1024 + t] = (unsigned short)(cnt[d * 1024 + t] + 1); }
+        __syncthreads();
+        // exclusive scan of the 16 384 counters in (digit, thread) order: thread t scans entries [16 t, 16 t + 16)
+        int loc[16], run = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { loc[e] = run; run += cnt[t * 16 + e]; }
+        int v = run;   // inclusive scan of the threads' sums
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); v += lane >= o ? u : 0; }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) base += k < w ? wsum[k] : 0;
+        const int excl = base + v - run;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cnt[t * 16 + e] = (unsigned short)(excl + loc[e]);   // (< 16 384: fits)
+        __syncthreads();
+        for (int e = 0; e < 16; ++e) {
+            const unsigned short id = ids[cur][t * 16 + e];
+            const int d = (key[id] >> shift) & 15;
+            const unsigned short pos = cnt[d * 1024 + t];
+            cnt[d * 1024 + t] = (unsigned short)(pos + 1);
+            ids[cur ^ 1][pos] = id;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const unsigned short* order = ids[cur];   // order[k] = the k-th heaviest row
+    // ---- the roles (row_roles_kernel, on the exact counts of the head) ----
+    const int head = rows < NN_ORDER_HEAD ? rows : NN_ORDER_HEAD;
+    const unsigned int h = t < head ? exact[order[t]] : 0u;   // (written by this block above; the barriers order it)
+    unsigned long long T = total / (unsigned long long)(total_div > 0 ? total_div : 1024);
+    if (T < (unsigned long long)min_part) T = (unsigned long long)min_part;
+    int parts = t < head ? 1 : 0, E = head;
+    if (min_part > 0) {
+        for (int it = 0; it < 24; ++it) {   // (the target doubles until the parts fit the spare blocks)
+            unsigned int p = 1u;
+            if ((unsigned long long)h > T) {
+                const unsigned long long want = ((unsigned long long)h + T - 1ull) / T;   // >= 2
+                p = want >= 64ull ? 64u : 1u << (32 - __builtin_clz((unsigned int)want - 1u));
+            }
+            parts = t < head ? (int)p : 0;
+            E = block_sum(parts);
+            if (E - head <= NN_ORDER_EXTRA) break;
+            T *= 2ull;
+            parts = t < head ? 1 : 0;
+            E = head;
+        }
+    }
+    int v = parts;   // inclusive running sum within the wave, then across the waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); v += lane >= o ? u : 0; }
+    __syncthreads();
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) base += k < w ? wsum[k] : 0;
+    const int excl = base + v - parts;
+    if (t < head) {
+        const int row = order[t];
+        const int lg = 31 - __builtin_clz((unsigned int)parts);
+        for (int p = 0; p < parts; ++p) roles[excl + p] = row | (p << NN_ROLE_ROW_BITS) | (lg << (NN_ROLE_ROW_BITS + NN_ROLE_PART_BITS));
+    }
+    for (int j = E + t; j < rows + NN_ORDER_EXTRA; j += 1024) {   // the roles behind the head: one block each, in the sorted order
+        const int src = head + (j - E);
+        roles[j] = src < rows ? (int)order[src] : -1;
+    }
+}
+
 size_t row_order_temp_bytes(int rows)
 {
     size_t bytes = 0;
@@ -367,6 +490,12 @@ size_t row_order_temp_bytes(int rows)
 hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int rows, const int32_t** roles_out, hipStream_t st)
 {
     if (rows <= 0 || rows >= (1 << NN_ROLE_ROW_BITS) || b.roles == nullptr || b.totals == nullptr) return hipErrorInvalidValue;
+    if (rows <= NN_CONTROL_MAX_ROWS && b.control) {
+        // one workgroup does it all (the exact counts go through keys[0], which the sort below would use)
+        hipLaunchKernelGGL(pass_control_kernel, dim3(1), dim3(1024), 0, st, hits, rows, b.keys[0], b.min_part, b.total_div, b.roles);
+        *roles_out = b.roles;
+        return hipGetLastError();
+    }
     unsigned long long* tot = b.totals + (b.seq & 1ull);
     hipLaunchKernelGGL(row_order_keys_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, hits, rows, b.keys[0], b.vals[0], tot, b.totals + ((b.seq + 1ull) & 1ull));
     hipError_t e = hipGetLastError();

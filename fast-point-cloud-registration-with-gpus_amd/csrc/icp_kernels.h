@@ -64,6 +64,7 @@ struct NNTuning {
     int speculate = 1;       // ICP_NN_SPECULATE=0: resident launches without their speculative hit list
     int f64_sparse = 1;      // ICP_F64_SPARSE=0: ICP_F64 clouds on the dense thread-per-point kernel
     int sort = -1;           // ICP_SORT=0 / 1: spatially sorted views never / always (-1: by the extent test)
+    int refine_rounds = 2;   // ICP_NN_REFINE_ROUNDS=1: the hierarchical search takes ONE refinement round (round 3's form; A/B runs)
     // ICP_NN_PHASES=file[:pass[:slots[:wipe]]] -- per-wave phase stamps of the matching kernels (tools/phase_report.py); the
     // context owns the log
     long long* phase_log = nullptr;
@@ -254,6 +255,7 @@ struct RowOrderBuffers {
     unsigned long long seq;  // launches so far (the caller counts)
     int min_part;            // no part is meant to be smaller than this many hits (0: no row is split)
     int total_div;           // the target: the sum of the counters over this (4 x the blocks the machine holds at once)
+    int control = 1;         // up to 16 384 rows: ONE single-workgroup launch (LDS counting sort + roles) instead of keys + rocPRIM sort + roles
 };
 size_t row_order_temp_bytes(int rows);
 // reads AND zeroes hits[rows] (the next launch counts afresh); *roles_out = the roles of rows + NN_ORDER_EXTRA blocks (device pointer)
@@ -306,7 +308,14 @@ struct NNTailArgs {
     // sum q p^T} -- see NNTail in icp_kernels.hip
     int compact = 0;
     int rows_on_device = 0;     // the rows stay in device memory for a later kernel (finalize): no drain, no tag to wait for
+    // rows_on_device, nn_match_sparse: the rows are added up inside the launch (NNTail::fin_*, icp_device.h) into fin_out -- pinned
+    // host memory (fin_host: the pass's tag lands in its last slot) or a device vector; NULL: a finalize launch follows
+    unsigned int* fin_tickets = nullptr;   // [NN_FIN_GROUPS + 1], zero before the first launch
+    double* fin_scratch = nullptr;         // [NN_FIN_GROUPS][ICP_NMOM]
+    double* fin_out = nullptr;             // [ICP_NMOM]
+    int fin_host = 0;
 };
+constexpr int NN_FIN_GROUPS = 256;     // ranges of rows of an in-launch finalize, at most
 constexpr int NN_CROW = 16;            // doubles per compact row
 constexpr int NN_CROW_TAG_BITS = 16;   // low mantissa bits of slot 0 that carry the row's tag (mod 2^16)
 bool nn_can_fuse_tail(const NNPlan& pl);

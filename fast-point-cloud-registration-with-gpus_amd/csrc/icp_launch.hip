@@ -49,6 +49,7 @@ NNTuning nn_tuning_from_env()
     t.speculate = env_int("ICP_NN_SPECULATE", 1) ? 1 : 0;
     t.f64_sparse = env_int("ICP_F64_SPARSE", 1) ? 1 : 0;
     t.sort = env_int("ICP_SORT", -1);
+    t.refine_rounds = env_int("ICP_NN_REFINE_ROUNDS", t.refine_rounds);
     return t;
 }
 
@@ -314,6 +315,21 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
         tail.tag_lo = (unsigned int)(unsigned long long)ta->tag;
         tail.compact = (ta->compact && pl.sparse && ta->metric == ICP_POINT_TO_POINT) ? 1 : 0;
         tail.rows_on_device = (ta->rows_on_device && !tail.compact) ? 1 : 0;
+        if (tail.rows_on_device && ta->fin_tickets != nullptr && ta->fin_scratch != nullptr && ta->fin_out != nullptr && pl.sparse && pl.row != 64) {
+            // rows added up inside the launch: ~sqrt(rows) ranges of rows (at most NN_FIN_GROUPS), so that the sum of a range and the
+            // sum of the ranges are equally short
+            const int rows = pl.blocks_x;
+            int groups = (int)ceil(sqrt((double)rows));
+            groups = groups < 1 ? 1 : groups > NN_FIN_GROUPS ? NN_FIN_GROUPS : groups;
+            const int per = (rows + groups - 1) / groups;
+            tail.fin_tickets = ta->fin_tickets;
+            tail.fin_scratch = ta->fin_scratch;
+            tail.fin_out = ta->fin_out;
+            tail.fin_host = ta->fin_host;
+            tail.fin_rows = rows;
+            tail.fin_per = per;
+            tail.fin_groups = (rows + per - 1) / per;
+        }
     }
     if (pl.sparse) {
         // the plan's geometry is the sparse kernel's: it needs the scan copy and its chunk boxes
@@ -424,6 +440,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             // The switches of those A/B runs are gone with round 4.)
             fuse.refine_min = 12;
             fuse.refine_cnt = 256;
+            fuse.refine_rounds = tune.refine_rounds;
             fuse.round_supers = 16;
             if (hier && fuse.records == nullptr) return hipErrorInvalidValue;   // (the hierarchical search fetches its hits from the records)
             if (pl.order && ta && !fuse.resident && opt->row_order != nullptr && opt->row_hits != nullptr) {

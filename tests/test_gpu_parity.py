@@ -756,9 +756,11 @@ def test_two_ranks_point_to_plane(pkg, orc, golden):
 
 
 def test_rows_added_on_the_device_give_the_same_registration(pkg, orc, monkeypatch):
-    """a cloud of more than ICP_HOST_ROWS_MAX rows (16 384 by default: 2 M points) has its moment rows added on the device -- 256
-    blocks add contiguous ranges of rows in fixed order, one block adds those, 32 doubles come back -- instead of by the host as
-    they arrive: another association of the same fp64 sums.  Forced here on a 36 864-point grid (288 rows, limit 64)"""
+    """a cloud of more than ICP_HOST_ROWS_MAX rows (round 4: 1 024 by default, 131 072 points) has its moment rows added on the
+    device, INSIDE the matching launch -- whoever closes the last row of a range adds the range in index order, whoever closes the
+    last range adds the ranges, the vector and the pass's tag land in pinned memory -- instead of by the host as the rows arrive:
+    another association of the same fp64 sums.  Forced here on a 36 864-point grid (288 rows, limit 64: armed launches with shared
+    rows, every range closed by whichever block happens to be last)"""
     D = pkg.datasets.synthetic_grid(192, np.float32)
     M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
     with pkg.Context(0) as c:

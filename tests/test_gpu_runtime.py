@@ -285,10 +285,10 @@ def test_bench_sharded_cloud_two_ranks_on_one_device():
     rehearsed with both ranks on the one GPU: the library sees that two ranks of its node communicator share a device and arms
     no pass ahead of its transform -- the waiting blocks of one rank would keep the other's pass off the CUs, and with the
     exchange between the ranks that is a circular wait (a pass missing its last rows, found with exactly this command).
-    Run twice: with the rows added up by the host as they arrive, and (ICP_HOST_ROWS_MAX: a cloud of more than 16 384 rows by
-    default) by the device's two-stage finalize with 256 bytes coming back -- the same registration either way."""
+    Run twice: with the rows added up inside the matching launch (round 4's default from 1 025 rows up: 4 688 here) and
+    (ICP_HOST_ROWS_MAX=16384) by the host as they arrive -- the same registration either way."""
     errs = []
-    for rows_max in (None, "1024"):
+    for rows_max in (None, "16384"):
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         env["ICP_BENCH_ONE_DEVICE"] = "1"
         if rows_max:
