@@ -100,6 +100,7 @@ SIGNATURES = {
     "icp_host_loop_state": (_i, [_vp, _pi, _pi, _pd, _i, _pd]),
     "icp_shard_range": (_i, [C.c_int64, _i, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "icp_share_rows_plan": (_i, [_pu32, _i, _i, _i, _i, _pi32, _pu32]),
+    "icp_diag_row_roles": (_i, [_vp, _pu32, _i, _i, _i, _i, _pi32]),
     "icp_eigh3": (_i, [_pd, _pd, _pd]),
     "icp_synthetic_grid_f32": (_i, [_i, C.c_float, C.c_float, _vp]),
     "icp_synthetic_grid_f64": (_i, [_i, C.c_double, C.c_double, _vp]),

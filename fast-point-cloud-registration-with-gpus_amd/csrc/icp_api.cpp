@@ -295,7 +295,16 @@ struct icp_ctx {
     bool model_sorted = false, moving_sorted = false;
     // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
     DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
-    struct PrepSmall { float box[4]; double totals[4]; int voided; int pad_; };
+    struct PrepSmall { float box[4]; double totals[4]; int voided; int pad_; unsigned int enc[6]; unsigned int pad2_[2]; unsigned long long fixed[4]; };
+    // round 4, the short set-up of clouds of up to kPrepSmallMax points: exact duplicates by hashing (a table that is never cleared:
+    // entries carry the upload's generation), and the spatial-order decision remembered per (cloud kind, size, group) -- a sensor's next
+    // scan has the order of the one before: while the given order's summed group extent stays within a quarter of the remembered one
+    // and the remembered decision was "own order", the curve sort that only served to confirm it is not run (ICP_SORT overrides)
+    static constexpr int kPrepSmallMax = 65536;
+    DevBuf dup_table;
+    unsigned int dup_gen = 0;
+    struct OrderMemo { bool valid = false; int count = 0, group = 0; bool sorted = false; double given_rel = 0.0; };
+    OrderMemo memo_model, memo_moving;
     DevBuf fin_scratch;      // finalize in two stages (many rows): 256 x ICP_NMOM doubles
     DevBuf fin_tickets;      // rows added up inside the matching launch (NNTail::fin_*): NN_FIN_GROUPS + 1 tickets, zero between launches
     double* h_final = nullptr;   // ... and where the launch leaves its ICP_NMOM vector for the host: pinned, coherent; the pass's tag in the last slot
@@ -388,7 +397,7 @@ struct icp_ctx {
     LoopState loop;
 };
 
-extern "C++" __attribute__((visibility("hidden"))) int decide_moving_order(icp_ctx* c, const void* P_soa, int grp);   // (below: it needs the prep helpers)
+extern "C++" __attribute__((visibility("hidden"))) int decide_moving_order(icp_ctx* c, const void* P_soa, int grp, bool have_enc = false);   // (below: it needs the prep helpers)
 
 namespace {
 
@@ -508,7 +517,11 @@ int ensure_work_buffers(icp_ctx* c)
 }
 
 // upload a host AoS cloud and convert it to the padded SoA layout
-int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision, DevBuf& dst)
+static int check_nonfinite(icp_ctx* c, int count);
+
+// deferred: no synchronisation here -- the caller synchronises once, at the end of its set-up, and asks check_nonfinite then
+// (soa2: a second copy of the converted cloud; enc: the bounding cube's six words, see launch_aos_to_soa)
+int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision, DevBuf& dst, bool deferred = false, void* soa2 = nullptr, unsigned int* enc = nullptr)
 {
     const size_t es = icp::elem_size(precision);
     HIP_TRY(dst.ensure(3 * (size_t)pad * es));
@@ -516,10 +529,16 @@ int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision,
     HIP_TRY(c->stage.ensure(3 * (size_t)count * es));
     HIP_TRY(hipMemcpyAsync(c->stage.p, aos, 3 * (size_t)count * es, hipMemcpyHostToDevice, c->stream));
     *(volatile unsigned int*)c->h_nonfinite = 0u;
-    HIP_TRY(icp::launch_aos_to_soa(precision, c->stage.p, count, pad, dst.p, c->stream, c->h_nonfinite));
+    HIP_TRY(icp::launch_aos_to_soa(precision, c->stage.p, count, pad, dst.p, c->stream, c->h_nonfinite, soa2, enc));
+    if (deferred) return ICP_OK;
     // the staging buffer is reused by the next upload: order them on the stream, and make sure the
     // pageable host source has been consumed before returning
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return check_nonfinite(c, count);
+}
+
+static int check_nonfinite(icp_ctx* c, int count)
+{
     // Non-finite coordinates are refused (include/icp_mi355x.h, "non-finite input": a deliberate deviation).  The reference
     // does not look at its input: the match of such a point is whatever cblas_idamin (src/ICP_CPU.c:232) answers for a vector
     // that holds NaN -- MKL documents nothing -- and the centroid sums (:342-366) then turn the whole transform into NaN:
@@ -586,6 +605,55 @@ static int morton_decision(icp_ctx* c, int count, int group, int group2, bool* u
         if (group2 > 0) std::fprintf(stderr, "; groups of %d: %.4g, %.4g", group2, h.totals[2], h.totals[3]);
         std::fprintf(stderr, " -> %s; %d exact duplicates voided\n", *use_sorted ? "Morton view" : "own order", h.voided);
     }
+    return ICP_OK;
+}
+
+// The order decision of a small cloud (<= kPrepSmallMax points) with ONE synchronisation: summed group extents of the given order
+// and -- unless the remembered decision says it is not needed -- of the Hilbert-curve order, in fixed point relative to the bounding
+// cube the layout kernel left in PrepSmall::enc.  Ends the deferred upload: the non-finite count is checked here.
+static int decide_order_small(icp_ctx* c, const icp::PrepBuffers& pb, const void* X_soa, int count, int pad, int group, icp_ctx::OrderMemo& memo, bool* use_sorted,
+                              int* voided_out, const char* what)
+{
+    icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
+    const int force = c->tune.sort;
+    const bool trivial = count <= group || force == 0;                       // never sorted: nothing to measure
+    const bool fast = !trivial && force < 0 && memo.valid && memo.count == count && memo.group == group && !memo.sorted;
+    bool have_sorted = false;
+    auto sorted_extents = [&](int which) -> int {
+        HIP_TRY(icp::launch_curve_order_small(pb, (const float*)X_soa, count, pad, small->enc, (int32_t*)c->prep_perm.p, c->stream));
+        HIP_TRY(icp::launch_extents_fixed((const float*)X_soa, count, pad, (const int32_t*)c->prep_perm.p, group, small->enc, small->fixed, which, c->stream));
+        have_sorted = true;
+        return ICP_OK;
+    };
+    if (!trivial) {
+        if (fast) HIP_TRY(icp::launch_extents_fixed((const float*)X_soa, count, pad, nullptr, group, small->enc, small->fixed, 0, c->stream));
+        else if (int rc = sorted_extents(0)) return rc;
+    }
+    icp_ctx::PrepSmall h{};
+    HIP_TRY(hipMemcpyAsync(&h, c->prep_small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = check_nonfinite(c, count)) return rc;
+    constexpr double kFix = 1.0 / 68719476736.0;   // 2^-36
+    double given = (double)h.fixed[0] * kFix, sorted = (double)h.fixed[1] * kFix;
+    if (fast && !(given <= 1.25 * memo.given_rel)) {
+        // the cloud is not what the one before was: measure the curve order after all (a second short round trip, once)
+        if (int rc = sorted_extents(1)) return rc;
+        HIP_TRY(hipMemcpyAsync(&h, c->prep_small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        given = (double)h.fixed[2] * kFix;
+        sorted = (double)h.fixed[3] * kFix;
+    }
+    if (voided_out) *voided_out = h.voided;
+    if (trivial) *use_sorted = false;
+    else if (force == 1) *use_sorted = true;
+    else if (!have_sorted) *use_sorted = false;                              // (remembered: own order, and the cloud still looks the same)
+    else *use_sorted = 3.0 * sorted < given;
+    if (c->trace) {
+        std::fprintf(stderr, "[icp trace] %s: %d points, groups of %d: extent %.4g of the bounding cube's edge in the given order", what, count, group, given);
+        if (have_sorted) std::fprintf(stderr, ", %.4g along the Hilbert curve", sorted); else std::fprintf(stderr, " (curve order not measured: %s)", trivial ? "not applicable" : "as the cloud before");
+        std::fprintf(stderr, " -> %s; %d exact duplicates voided\n", *use_sorted ? "sorted view" : "own order", h.voided);
+    }
+    if (!trivial && force < 0) { memo.valid = true; memo.count = count; memo.group = group; memo.sorted = *use_sorted; if (have_sorted || !memo.given_rel) memo.given_rel = given; }
     return ICP_OK;
 }
 
@@ -792,7 +860,7 @@ void icp_destroy(icp_ctx* c)
         }
         c->phase_log.release();
     }
-    DevBuf* bufs[] = {&c->work, &c->fin_scratch, &c->fin_tickets, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->order_roles, &c->order_totals, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qrec, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
+    DevBuf* bufs[] = {&c->work, &c->fin_scratch, &c->fin_tickets, &c->dup_table, &c->slot_state, &c->share_counts, &c->seed_pub, &c->row_hits, &c->order_keys[0], &c->order_keys[1], &c->order_vals[0], &c->order_vals[1], &c->order_tmp, &c->order_roles, &c->order_totals, &c->P0, &c->P, &c->P2, &c->Q, &c->Qs, &c->Qbox, &c->Qrec, &c->Qsamp, &c->Qss, &c->Qperm, &c->Pperm, &c->prep_keys[0], &c->prep_keys[1], &c->prep_vals[0], &c->prep_vals[1], &c->prep_tmp, &c->prep_small, &c->prep_ext, &c->prep_voided, &c->prep_perm, &c->Nrm, &c->stage, &c->part_d, &c->part_idx, &c->idx[0], &c->idx[1],
                       &c->mom_partials, &c->err_partials, &c->mom_own, &c->nbr, &c->keys, &c->tickets};
     for (DevBuf* b : bufs) b->release();
     if (c->h_mom) (void)hipHostFree(c->h_mom);
@@ -985,21 +1053,48 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
     c->have_model = false;     // (until the upload has been accepted)
     c->have_scan_copy = false;
     c->have_records = false;
-    if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q)) return rc;
+    const int group2 = (precision == ICP_F32 && m > 0 && icp::nn_plan(128, m, precision, c->num_cus, c->tune).hier) ? 512 : 0;   // (the model's size decides the search form)
+    const bool short_setup = precision == ICP_F32 && m > 0 && m <= icp_ctx::kPrepSmallMax && group2 == 0;
+    icp::PrepBuffers pb{};
+    if (short_setup) {
+        // (round 4: upload, layout and bounding cube without a synchronisation of their own; see decide_order_small)
+        if (int rc = prep_buffers(c, m, pb)) return rc;
+        icp_ctx::PrepSmall* small0 = (icp_ctx::PrepSmall*)c->prep_small.p;
+        if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q, true, nullptr, small0->enc)) return rc;
+    } else if (int rc = upload_cloud(c, xyz, m, icp::pad_model(m), precision, c->Q)) return rc;
     if (precision == ICP_F32 && m > 0) {
         // scan copy for the early-out matching kernels: exact duplicates of a lower-index point (and the padding)
         // voided to +inf -- they can never be the lowest-index minimum (see NNCullInputs).  Flags, Morton order and
         // the extent test are computed on the device from the uploaded cloud.
         const int m_pad = icp::pad_model(m);
-        icp::PrepBuffers pb{};
-        if (int rc = prep_buffers(c, m, pb)) return rc;
+        if (!short_setup) if (int rc = prep_buffers(c, m, pb)) return rc;
         icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
         HIP_TRY(c->Qs.ensure(3 * (size_t)m_pad * sizeof(float)));
-        HIP_TRY(icp::launch_duplicates_and_scan_copy(pb, (const float*)c->Q.p, m, m_pad, (unsigned char*)c->prep_voided.p, &small->voided,
-                                                     (float*)c->Qs.p, c->stream));
-        const int group2 = icp::nn_plan(128, m, precision, c->num_cus, c->tune).hier ? 512 : 0;   // (the model's size decides the search form)
-        HIP_TRY(icp::launch_morton_order(pb, (const float*)c->Q.p, m, m_pad, 8, group2, (int32_t*)c->prep_perm.p, small->totals, c->stream));
-        if (int rc = morton_decision(c, m, 8, group2, &c->model_sorted, &c->voided)) return rc;
+        if (m <= (1 << 21)) {
+            // exact duplicates by hashing: two launches instead of three radix sorts (icp_k_setup.hip)
+            unsigned int entries = 1024u;
+            while (entries < 2u * (unsigned int)m) entries <<= 1;
+            if ((size_t)entries * sizeof(unsigned int) > c->dup_table.cap) {
+                HIP_TRY(c->dup_table.ensure((size_t)entries * sizeof(unsigned int)));
+                HIP_TRY(hipMemsetAsync(c->dup_table.p, 0, c->dup_table.cap, c->stream));
+                c->dup_gen = 0;
+            }
+            if (++c->dup_gen > 255u) {   // (generation 0 is "never written")
+                HIP_TRY(hipMemsetAsync(c->dup_table.p, 0, c->dup_table.cap, c->stream));
+                c->dup_gen = 1;
+            }
+            HIP_TRY(icp::launch_duplicates_hashed((const float*)c->Q.p, m, m_pad, (unsigned int*)c->dup_table.p, entries, c->dup_gen, (unsigned char*)c->prep_voided.p,
+                                                  &small->voided, (float*)c->Qs.p, c->stream));
+        } else {
+            HIP_TRY(icp::launch_duplicates_and_scan_copy(pb, (const float*)c->Q.p, m, m_pad, (unsigned char*)c->prep_voided.p, &small->voided,
+                                                         (float*)c->Qs.p, c->stream));
+        }
+        if (short_setup) {
+            if (int rc = decide_order_small(c, pb, c->Q.p, m, m_pad, 8, c->memo_model, &c->model_sorted, &c->voided, "model")) return rc;
+        } else {
+            HIP_TRY(icp::launch_morton_order(pb, (const float*)c->Q.p, m, m_pad, 8, group2, (int32_t*)c->prep_perm.p, small->totals, c->stream));
+            if (int rc = morton_decision(c, m, 8, group2, &c->model_sorted, &c->voided)) return rc;
+        }
         // the sparse kernel's view: the same voided copy, in Morton order if the model's own order has no locality
         const void* view = c->Qs.p;
         if (c->model_sorted) {
@@ -1011,9 +1106,13 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
         }
         // bounding boxes of its 8-point chunks (the first, cheapest level of the early-out) and one point per chunk
         HIP_TRY(c->Qbox.ensure(icp::model_boxes_bytes(m_pad)));
-        HIP_TRY(icp::launch_model_boxes(view, m_pad, (float*)c->Qbox.p, c->stream));
         HIP_TRY(c->Qsamp.ensure(icp::model_samples_bytes(m_pad)));
-        HIP_TRY(icp::launch_model_samples(view, m_pad, (float*)c->Qsamp.p, c->stream));
+        if (group2 == 0) {   // (searched flat: the upper box levels are never read -- one launch for boxes and samples)
+            HIP_TRY(icp::launch_model_boxes_samples(view, m_pad, (float*)c->Qbox.p, (float*)c->Qsamp.p, c->stream));
+        } else {
+            HIP_TRY(icp::launch_model_boxes(view, m_pad, (float*)c->Qbox.p, c->stream));
+            HIP_TRY(icp::launch_model_samples(view, m_pad, (float*)c->Qsamp.p, c->stream));
+        }
         c->have_records = false;
         if (group2 > 0) {   // a model searched through the box hierarchy: the hits are fetched from per-chunk records
             HIP_TRY(c->Qrec.ensure(icp::model_records_bytes(m_pad)));
@@ -1057,19 +1156,22 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
     c->loop.active = false;
     c->idx_valid = false;
     c->have_moving = false;    // (until the upload has been accepted)
-    if (int rc = upload_cloud(c, xyz, n, icp::pad_moving(n), precision, c->P)) return rc;
-    if (n > 0) {
-        const size_t bytes = 3 * (size_t)icp::pad_moving(n) * icp::elem_size(precision);
-        HIP_TRY(c->P0.ensure(bytes));
-        HIP_TRY(hipMemcpyAsync(c->P0.p, c->P.p, bytes, hipMemcpyDeviceToDevice, c->stream));
-    }
+    const bool judged = precision == ICP_F32 && n > 128;
+    const bool short_setup = judged && n <= icp_ctx::kPrepSmallMax;
+    if (n > 0) HIP_TRY(c->P0.ensure(3 * (size_t)icp::pad_moving(n) * icp::elem_size(precision)));
+    if (short_setup) {
+        // (round 4: one layout launch writes the cloud, its pristine copy and the bounding cube; no synchronisation until the order is decided)
+        icp::PrepBuffers pb{};
+        if (int rc = prep_buffers(c, n, pb)) return rc;
+        if (int rc = upload_cloud(c, xyz, n, icp::pad_moving(n), precision, c->P, true, c->P0.p, ((icp_ctx::PrepSmall*)c->prep_small.p)->enc)) return rc;
+    } else if (int rc = upload_cloud(c, xyz, n, icp::pad_moving(n), precision, c->P, false, n > 0 ? c->P0.p : nullptr)) return rc;
     c->moving_sorted = false;
     c->moving_group = 0;
-    if (precision == ICP_F32 && n > 128) {
+    if (judged) {
         // judged on the groups the matching kernel will work on (rows of 64 or of 128 points: nn_plan's rule, overrides
         // included); with no model resident yet the plan assumes one of the moving cloud's size -- ensure_work_buffers looks again
         const icp::NNPlan guess = icp::nn_plan(n, c->have_model && c->m > 0 ? c->m : n, precision, c->num_cus, c->tune);
-        if (int rc = decide_moving_order(c, c->P.p, (guess.sparse && guess.row == 64) ? 64 : 128)) return rc;
+        if (int rc = decide_moving_order(c, c->P.p, (guess.sparse && guess.row == 64) ? 64 : 128, short_setup)) return rc;
     }
     c->have_moving = true;
     c->moving_is_pristine = false;
@@ -1078,14 +1180,23 @@ int icp_set_moving(icp_ctx* c, const void* xyz, int n, int precision)
 }
 
 // Morton order or the given one for the moving cloud's slots ("spatial order"): decided on groups of `grp`
-extern "C++" int decide_moving_order(icp_ctx* c, const void* P_soa, int grp)
+extern "C++" int decide_moving_order(icp_ctx* c, const void* P_soa, int grp, bool have_enc)
 {
     const int n = c->n, n_pad = icp::pad_moving(n);
     icp::PrepBuffers pb{};
+    if (have_enc) {
+        // (the upload has prepared the buffers and left the bounding cube: the short form, which also ends the deferred upload)
+        pb.keys[0] = (unsigned int*)c->prep_keys[0].p; pb.keys[1] = (unsigned int*)c->prep_keys[1].p;
+        pb.vals[0] = (int32_t*)c->prep_vals[0].p; pb.vals[1] = (int32_t*)c->prep_vals[1].p;
+        pb.temp = c->prep_tmp.p; pb.temp_bytes = icp::prep_sort_temp_bytes(n);
+        pb.box = (float*)c->prep_small.p; pb.ext = (double*)c->prep_ext.p;
+        if (int rc = decide_order_small(c, pb, P_soa, n, n_pad, grp, c->memo_moving, &c->moving_sorted, nullptr, "moving cloud")) return rc;
+    } else {
     if (int rc = prep_buffers(c, n, pb)) return rc;
     icp_ctx::PrepSmall* small = (icp_ctx::PrepSmall*)c->prep_small.p;
     HIP_TRY(icp::launch_morton_order(pb, (const float*)P_soa, n, n_pad, grp, 0, (int32_t*)c->prep_perm.p, small->totals, c->stream));
     if (int rc = morton_decision(c, n, grp, 0, &c->moving_sorted, nullptr)) return rc;
+    }
     if (c->moving_sorted) {
         HIP_TRY(c->Pperm.ensure((size_t)n_pad * sizeof(int32_t)));
         HIP_TRY(icp::launch_slot_map((const int32_t*)c->prep_perm.p, n, n_pad, (int32_t*)c->Pperm.p, c->stream));
@@ -1339,6 +1450,38 @@ int icp_share_rows_plan(const uint32_t* hits, int rows, int blocks, int model_po
     const unsigned int T = icp::share_rows_plan(hits, rows, blocks, icp::pad_model(model_points), min_hits, parts);
     if (target) *target = T;
     return ICP_OK;
+}
+
+int icp_diag_row_roles(icp_ctx* c, uint32_t* hits_io, int rows, int min_part, int total_div, int control, int32_t* roles_out)
+{
+    if (int rc = use(c)) return rc;
+    if (!hits_io || !roles_out || rows < 1 || rows >= (1 << icp::NN_ROLE_ROW_BITS)) return fail(ICP_ERR_INVALID, "icp_diag_row_roles: bad arguments");
+    static_assert(ICP_ROLES_EXTRA == icp::NN_ORDER_EXTRA, "the header's constant is the kernels'");
+    DevBuf hits, keys[2], vals[2], tmp, roles, totals;
+    const size_t rb = (size_t)rows * sizeof(unsigned int);
+    auto body = [&]() -> int {
+        HIP_TRY(hits.ensure(rb));
+        for (int k = 0; k < 2; ++k) { HIP_TRY(keys[k].ensure(rb)); HIP_TRY(vals[k].ensure(rb)); }
+        HIP_TRY(tmp.ensure(icp::row_order_temp_bytes(rows)));
+        HIP_TRY(roles.ensure(((size_t)rows + icp::NN_ORDER_EXTRA) * sizeof(int32_t)));
+        HIP_TRY(totals.ensure(2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(totals.p, 0, totals.cap, c->stream));
+        HIP_TRY(hipMemcpyAsync(hits.p, hits_io, rb, hipMemcpyHostToDevice, c->stream));
+        icp::RowOrderBuffers b{};
+        for (int k = 0; k < 2; ++k) { b.keys[k] = (unsigned int*)keys[k].p; b.vals[k] = (int32_t*)vals[k].p; }
+        b.temp = tmp.p; b.temp_bytes = tmp.cap; b.roles = (int32_t*)roles.p; b.totals = (unsigned long long*)totals.p;
+        b.seq = 0; b.min_part = min_part; b.total_div = total_div; b.control = control;
+        const int32_t* out = nullptr;
+        HIP_TRY(icp::launch_row_order(b, (unsigned int*)hits.p, rows, &out, c->stream));
+        HIP_TRY(hipMemcpyAsync(roles_out, out, ((size_t)rows + icp::NN_ORDER_EXTRA) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(hits_io, hits.p, rb, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return ICP_OK;
+    };
+    const int rc = body();
+    DevBuf* all[] = {&hits, &keys[0], &keys[1], &vals[0], &vals[1], &tmp, &roles, &totals};
+    for (DevBuf* d : all) d->release();
+    return rc;
 }
 
 int icp_nn_launch_info_ex(icp_ctx* c, int dense, int* splits, int* blocks, int* threads, int* n_pad, int* m_pad)

@@ -370,7 +370,6 @@ struct NNFuse {
     const int32_t* row_order;  // ordered rows: block b works on row row_order[b] (heaviest first) -- or NULL
     unsigned int* row_hits;    // ... and adds the hits of its lists to row_hits[row]
     int refine_min, refine_cnt; // hierarchical search: a pass that lists at least refine_min super boxes takes a refinement round over <= refine_cnt of their chunk samples (0: never)
-    int refine_rounds;         // ... and up to this many of them: a later round re-lists the super boxes with the bound the one before has left
     int round_supers;          // hierarchical search: super boxes per round of the chunk find (<= 64: the hit list holds their chunks)
     const float* records;      // hierarchical search: one 160-byte record per chunk (model_records_kernel) -- a hit is fetched from it -- or NULL
     float* seed_pub;           // resident launch with shared rows: [rows][3][128] -- whichever block closes a split row leaves the matches' coordinates

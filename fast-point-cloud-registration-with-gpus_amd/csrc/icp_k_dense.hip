@@ -16,18 +16,46 @@ namespace icp {
 // `nonfinite` (pinned host memory, or NULL): counts the points with a NaN or an infinite coordinate -- icp_set_* refuse such a
 // cloud (include/icp_mi355x.h).  Written only when there is something to count.
 template <typename F>
-__global__ void aos_to_soa_kernel(const F* __restrict__ aos, int n, int n_pad, F* __restrict__ soa, unsigned int* nonfinite)
+__global__ void aos_to_soa_kernel(const F* __restrict__ aos, int n, int n_pad, F* __restrict__ soa, unsigned int* nonfinite, F* __restrict__ soa2, unsigned int* __restrict__ enc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
+    const bool in = i < n_pad;
     const int s = i < n ? i : n - 1;  // padding replicates the last real point
-    const F x = aos[3 * (size_t)s + 0], y = aos[3 * (size_t)s + 1], z = aos[3 * (size_t)s + 2];
-    soa[i] = x;
-    soa[(size_t)n_pad + i] = y;
-    soa[2 * (size_t)n_pad + i] = z;
+    F x = F(0), y = F(0), z = F(0);
+    if (in) {
+        x = aos[3 * (size_t)s + 0]; y = aos[3 * (size_t)s + 1]; z = aos[3 * (size_t)s + 2];
+        soa[i] = x;
+        soa[(size_t)n_pad + i] = y;
+        soa[2 * (size_t)n_pad + i] = z;
+        if (soa2 != nullptr) { soa2[i] = x; soa2[(size_t)n_pad + i] = y; soa2[2 * (size_t)n_pad + i] = z; }
+    }
     // (x - x is 0 for every finite x, NaN for NaN and for +-inf)
-    if (nonfinite != nullptr && i < n && !((x - x) == F(0) && (y - y) == F(0) && (z - z) == F(0)))
+    const bool finite = (x - x) == F(0) && (y - y) == F(0) && (z - z) == F(0);
+    if (in && nonfinite != nullptr && i < n && !finite)
         __hip_atomic_fetch_add(nonfinite, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if constexpr (sizeof(F) == 4) {
+        // the bounding cube of the finite points, for the spatial order: a wave's minima and maxima, then six ordered-integer atomics
+        if (enc != nullptr) {
+            const bool use = in && i < n && finite;
+            const float binf = __builtin_huge_valf();
+            float lo[3] = {use ? (float)x : binf, use ? (float)y : binf, use ? (float)z : binf};
+            float hi[3] = {use ? (float)x : -binf, use ? (float)y : -binf, use ? (float)z : -binf};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                for (int off = 32; off > 0; off >>= 1) {
+                    lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], off, 64));
+                    hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+                }
+            if ((threadIdx.x & 63) == 0 && hi[0] >= lo[0]) {
+                auto ord = [](float f) { const unsigned int b = __float_as_uint(f == 0.f ? 0.f : f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); };
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    atomicMax(&enc[a], ~ord(lo[a]));
+                    atomicMax(&enc[3 + a], ord(hi[a]));
+                }
+            }
+        }
+    }
 }
 
 template <typename F>
@@ -748,16 +776,16 @@ hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_
     return hipGetLastError();
 }
 
-hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st, unsigned int* nonfinite)
+hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st, unsigned int* nonfinite, void* soa2, unsigned int* enc)
 {
     if (n <= 0) return hipSuccess;
     const int blocks = (n_pad + 255) / 256;
     if (precision == ICP_F64)
         hipLaunchKernelGGL((aos_to_soa_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)aos, n, n_pad,
-                           (double*)soa, nonfinite);
+                           (double*)soa, nonfinite, (double*)soa2, (unsigned int*)nullptr);
     else
         hipLaunchKernelGGL((aos_to_soa_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)aos, n, n_pad,
-                           (float*)soa, nonfinite);
+                           (float*)soa, nonfinite, (float*)soa2, enc);
     return hipGetLastError();
 }
 

@@ -251,6 +251,183 @@ __global__ __launch_bounds__(256) void prep_sum_kernel(const double* __restrict_
     if (threadIdx.x == 0) out[which] = red[0];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the set-up of a cloud in a handful of launches (what a sensor's NEXT pair costs: the hall pair's set-up was ~60 launches
+// of 3-10 us -- five rocPRIM radix sorts in 25 of them -- 0.35 ms against a registration of 0.12 ms).
+//   * exact duplicates by HASHING instead of three stable radix sorts: every point looks up its coordinates' slot in an
+//     open-addressing table (one 32-bit word per slot: generation << 24 | index of the lowest-index point seen so far with these
+//     coordinates -- any member of a group serves to compare coordinates with, they are all the same); kernel 1 inserts (CAS on an
+//     empty or stale slot, atomicMin on a slot of its own coordinates), kernel 2 looks up: a point is voided iff the minimum of its
+//     slot is not itself -- and writes the scan copy in the same pass.  The answer is the unique minimum: deterministic.  The
+//     generation makes clearing the table unnecessary (an entry of another generation is empty; a stale entry that survives a
+//     wrap-around of the 8-bit counter names a point whose coordinates are compared like any other's: harmless).
+//   * the bounding cube comes out of the layout kernel (ordered-integer atomics), the group extents are summed in 2^-36 fixed point
+//     by 64-bit integer atomics (any order of additions gives the same bits: the decision must not change from run to run),
+//     given and sorted order in one launch.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ord_decode(unsigned int e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+// box[0..2] = lo, box[3] = the largest extent (-inf when the cloud has no finite point), from the layout kernel's six encodings
+// {~ord(min x), ~ord(min y), ~ord(min z), ord(max x), ord(max y), ord(max z)} (0 = nothing seen)
+__device__ __forceinline__ void box_from_enc(const unsigned int* __restrict__ enc, float (&box)[4])
+{
+    float ext = -inf_<float>();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const unsigned int el = enc[a], eh = enc[3 + a];
+        const float lo = el ? ord_decode(~el) : inf_<float>(), hi = eh ? ord_decode(eh) : -inf_<float>();
+        box[a] = lo;
+        ext = fmaxf(ext, hi - lo);
+    }
+    box[3] = (enc[0] && enc[3]) ? ext : -inf_<float>();
+}
+
+__device__ __forceinline__ unsigned int hash3(unsigned int a, unsigned int b, unsigned int c)
+{
+    unsigned int h = a * 0x9E3779B1u ^ b * 0x85EBCA77u ^ c * 0xC2B2AE3Du;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return h;
+}
+
+__global__ void prep_dup_insert_kernel(const float* __restrict__ X, int n, int n_pad, unsigned int* __restrict__ table, unsigned int mask, unsigned int gen)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = X[i], y = X[(size_t)n_pad + i], z = X[2 * (size_t)n_pad + i];
+    if (x != x || y != y || z != z) return;   // (NaN equals nothing; such a cloud is refused anyway)
+    const unsigned int bx = canon_bits(x), by = canon_bits(y), bz = canon_bits(z), me = (gen << 24) | (unsigned int)i;
+    unsigned int h = hash3(bx, by, bz) & mask;
+    for (unsigned int probes = 0; probes <= mask; ++probes) {
+        unsigned int v = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            if ((v >> 24) != gen) {   // empty (or another upload's): claim it
+                unsigned int expect = v;
+                if (__hip_atomic_compare_exchange_strong(&table[h], &expect, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+                v = expect;           // somebody else got there first: look at what is there now
+                continue;
+            }
+            break;
+        }
+        const int j = (int)(v & 0xffffffu);
+        if (canon_bits(X[j]) == bx && canon_bits(X[(size_t)n_pad + j]) == by && canon_bits(X[2 * (size_t)n_pad + j]) == bz) {
+            if (i < j) __hip_atomic_fetch_min(&table[h], me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (same generation: the index decides)
+            return;
+        }
+        h = (h + 1u) & mask;
+    }
+}
+
+// voided[j] = 1 for every point with an exact lower-index twin, *count += their number; and the scan copy (voided points and
+// the padding at +inf) in the same pass
+__global__ void prep_dup_lookup_kernel(const float* __restrict__ X, int n, int n_pad, const unsigned int* __restrict__ table, unsigned int mask, unsigned int gen,
+                                       unsigned char* __restrict__ voided, int* __restrict__ count, float* __restrict__ scan_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    bool v = false;
+    float x = inf_<float>(), y = x, z = x;
+    if (i < n) {
+        x = X[i]; y = X[(size_t)n_pad + i]; z = X[2 * (size_t)n_pad + i];
+        if (x == x && y == y && z == z) {
+            const unsigned int bx = canon_bits(x), by = canon_bits(y), bz = canon_bits(z);
+            unsigned int h = hash3(bx, by, bz) & mask;
+            for (unsigned int probes = 0; probes <= mask; ++probes) {
+                const unsigned int e = table[h];   // (written by the kernel before: the kernel boundary orders it)
+                if ((e >> 24) != gen) break;       // (cannot happen: every finite point was inserted)
+                const int j = (int)(e & 0xffffffu);
+                if (canon_bits(X[j]) == bx && canon_bits(X[(size_t)n_pad + j]) == by && canon_bits(X[2 * (size_t)n_pad + j]) == bz) { v = j != i; break; }
+                h = (h + 1u) & mask;
+            }
+        }
+        voided[i] = v ? 1 : 0;
+    }
+    const bool keep = i < n && !v;
+    scan_out[i] = keep ? x : inf_<float>();
+    scan_out[(size_t)n_pad + i] = keep ? y : inf_<float>();
+    scan_out[2 * (size_t)n_pad + i] = keep ? z : inf_<float>();
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
+    if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(count, (int)__builtin_popcountll(m));
+}
+
+hipError_t launch_duplicates_hashed(const float* X, int n, int n_pad, unsigned int* table, unsigned int table_entries, unsigned int gen, unsigned char* voided,
+                                    int* count_dev, float* scan_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    if (table_entries == 0 || (table_entries & (table_entries - 1)) != 0 || table_entries < 2u * (unsigned int)n || n >= (1 << 24)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(prep_dup_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, n, n_pad, table, table_entries - 1u, gen & 0xffu);
+    hipLaunchKernelGGL(prep_dup_lookup_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, X, n, n_pad, (const unsigned int*)table, table_entries - 1u, gen & 0xffu,
+                       voided, count_dev, scan_out);
+    return hipGetLastError();
+}
+
+// extent dx + dy + dz of every group of `group` consecutive entries of an order (blockIdx.y == 0: the cloud's own; 1: `order`),
+// relative to the cloud's largest extent, summed in 2^-36 fixed point into out[2 * which + blockIdx.y]: four groups (one wave
+// each) per block, one integer atomic per block
+__global__ __launch_bounds__(256) void prep_extent_fixed_kernel(const float* __restrict__ X, int n, int n_pad, const int32_t* __restrict__ order, int group, int groups,
+                                                                const unsigned int* __restrict__ enc, unsigned long long* __restrict__ out, int which)
+{
+    __shared__ unsigned long long part[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + w, g0 = g * group;
+    const bool sorted = blockIdx.y != 0;
+    float lo[3] = {inf_<float>(), inf_<float>(), inf_<float>()}, hi[3] = {-inf_<float>(), -inf_<float>(), -inf_<float>()};
+    if (g < groups)
+        for (int k = g0 + lane; k < min(n, g0 + group); k += 64) {
+            const int i = sorted ? order[k] : k;
+            const float p[3] = {X[i], X[(size_t)n_pad + i], X[2 * (size_t)n_pad + i]};
+            if (!finite3(p[0], p[1], p[2])) continue;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+        }
+    if (lane == 0) {
+        float box[4];
+        box_from_enc(enc, box);
+        const double e = hi[0] >= lo[0] ? (double)(hi[0] - lo[0]) + (double)(hi[1] - lo[1]) + (double)(hi[2] - lo[2]) : 0.0;
+        const double rel = box[3] > 0.f ? e / (double)box[3] : 0.0;   // <= 3
+        part[w] = (unsigned long long)(rel * 68719476736.0);          // 2^36
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t != 0ull) atomicAdd(&out[2 * which + (sorted ? 1 : 0)], t);
+    }
+}
+
+hipError_t launch_extents_fixed(const float* X, int n, int n_pad, const int32_t* order, int group, const unsigned int* enc, unsigned long long* out, int which, hipStream_t st)
+{
+    if (n <= 0 || group <= 0) return hipSuccess;
+    const int groups = (n + group - 1) / group;
+    hipLaunchKernelGGL(prep_extent_fixed_kernel, dim3((groups + 3) / 4, order ? 2 : 1), dim3(256), 0, st, X, n, n_pad, order, group, groups, enc, out, which);
+    return hipGetLastError();
+}
+
+// the space-filling-curve order of a small cloud: keys from the layout kernel's bounding cube, one radix sort; perm_out[k] = k-th point
+__global__ void prep_curve_keys_enc_kernel(const float* __restrict__ X, int n, int n_pad, const unsigned int* __restrict__ enc,
+                                           unsigned int* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float box[4];
+    box_from_enc(enc, box);
+    const float x = X[i], y = X[(size_t)n_pad + i], z = X[2 * (size_t)n_pad + i];
+    unsigned int code = 0x7fffffffu;
+    const float ext = box[3];
+    if (finite3(x, y, z) && ext >= 0.f) {
+        const double scale = ext > 0.f ? 1023.0 / (double)ext : 0.0;
+        const unsigned int qx = (unsigned int)fmin(1023.0, fmax(0.0, ((double)x - (double)box[0]) * scale));
+        const unsigned int qy = (unsigned int)fmin(1023.0, fmax(0.0, ((double)y - (double)box[1]) * scale));
+        const unsigned int qz = (unsigned int)fmin(1023.0, fmax(0.0, ((double)z - (double)box[2]) * scale));
+        code = hilbert30(qx, qy, qz);
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
 // Morton-ordered view of a scan copy + its permutation, padded (+inf / 0x7fffffff)
 __global__ void prep_gather_sorted_kernel(const float* __restrict__ Qs, int m, int m_pad, const int32_t* __restrict__ perm,
                                           float* __restrict__ out, int32_t* __restrict__ perm_pad)
@@ -358,18 +535,20 @@ __global__ __launch_bounds__(1024) void row_roles_kernel(const unsigned int* __r
 
 // ONE launch instead of nine (round 4; up to NN_CONTROL_MAX_ROWS rows -- the share of one rank of eight of configs[4] has 9 768): the
 // counters of the launch before are read and zeroed, sorted and dealt as roles by a single workgroup.  The order need not be exact --
-// any order is exact for the RESULT; what it decides is how even the load is -- so the 20-bit counts are quantised to 10 bits (exact
-// below 128, then 6 bits of mantissa per power of two: 1.6 % resolution) and sorted by three stable 4-bit counting passes in LDS:
-// thread t owns 16 consecutive entries, counts them per digit in its own column of cnt[digit][thread], one block-wide exclusive scan
-// over the 16 x 1024 counters gives every (digit, thread) its first output slot.  Ties keep the row order: the same roles every run.
+// any order is exact for the RESULT; what it decides is how even the load is -- so the 20-bit counts are quantised to 8 bits (exact
+// below 8, then 3 bits of mantissa per power of two: steps of 12 %) and sorted by two stable 4-bit counting passes in LDS: thread t
+// owns 16 consecutive entries, counts them per digit in REGISTERS (sixteen 5-bit counters in two words: no read-modify-write chain
+// through LDS), leaves the counts in its column of cnt[digit][thread]; one block-wide exclusive scan over the 16 x 1024 counters
+// gives every (digit, thread) its first output slot, and an entry's slot is that plus its rank among the thread's earlier entries
+// of the same digit -- the counter's value when it was counted.  Ties keep the row order: the same roles every run.
 // The split of the heaviest rows follows row_roles_kernel statement by statement (on the exact counts).
 constexpr int NN_CONTROL_MAX_ROWS = 16384;
 __global__ __launch_bounds__(1024) void pass_control_kernel(unsigned int* __restrict__ hits, int rows, unsigned int* __restrict__ exact, int min_part, int total_div,
                                                             int32_t* __restrict__ roles)
 {
-    __shared__ unsigned short key[NN_CONTROL_MAX_ROWS];        // quantised count, inverted: ascending = heaviest first
-    __shared__ unsigned short ids[2][NN_CONTROL_MAX_ROWS];     // ping-pong: the order so far
-    __shared__ unsigned short cnt[16 * 1024];                  // [digit][thread]
+    __shared__ __attribute__((aligned(16))) unsigned char key[NN_CONTROL_MAX_ROWS];        // quantised count, inverted: ascending = heaviest first
+    __shared__ __attribute__((aligned(16))) unsigned short ids[2][NN_CONTROL_MAX_ROWS];    // ping-pong: the order so far
+    __shared__ __attribute__((aligned(16))) unsigned short cnt[16 * 1024];                 // [digit][thread]
     __shared__ int wsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     auto block_sum = [&](int v) {
@@ -383,37 +562,91 @@ __global__ __launch_bounds__(1024) void pass_control_kernel(unsigned int* __rest
         for (int k = 0; k < 16; ++k) s += wsum[k];
         return s;
     };
-    // ---- read + zero the counters, quantise ----
+    // ---- read + zero the counters (thread t: rows 16 t .. 16 t + 15, four 16-byte loads in flight), quantise ----
     unsigned long long mine = 0ull;
-    for (int r = t; r < NN_CONTROL_MAX_ROWS; r += 1024) {
-        unsigned int h = 0u;
-        if (r < rows) {
-            h = hits[r];
-            hits[r] = 0u;                                          // (the next launch counts afresh)
-            h = h > 0xfffffu ? 0xfffffu : h;
-            exact[r] = h;
-            mine += h;
+    {
+        unsigned int h[16];
+        const int r0 = t * 16;
+        if (r0 + 16 <= rows) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = reinterpret_cast<const uint4*>(hits + r0)[q];
+                h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<uint4*>(hits + r0)[q] = uint4{0u, 0u, 0u, 0u};   // (the next launch counts afresh)
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { h[e] = r0 + e < rows ? hits[r0 + e] : 0u; if (r0 + e < rows) hits[r0 + e] = 0u; }
         }
-        unsigned int q = h;
-        if (h >= 128u) { const int e = 31 - __builtin_clz(h); q = 128u + (unsigned int)(e - 7) * 64u + ((h >> (e - 6)) & 63u); }   // <= 959
-        key[r] = (unsigned short)(r < rows ? 1023u - q : 1023u);   // (rows beyond the cloud sort behind everything; they are never dealt)
-        ids[0][r] = (unsigned short)r;
+        unsigned int packed[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            h[e] = h[e] > 0xfffffu ? 0xfffffu : h[e];
+            mine += h[e];
+            unsigned int q = h[e];
+            if (h[e] >= 8u) { const int ex = 31 - __builtin_clz(h[e]); q = 8u + (unsigned int)(ex - 3) * 8u + ((h[e] >> (ex - 3)) & 7u); }   // <= 143
+            const unsigned int kq = r0 + e < rows ? 255u - q : 255u;   // (entries beyond the cloud sort behind everything; they are never dealt)
+            packed[e >> 2] |= kq << (8 * (e & 3));
+        }
+        if (r0 + 16 <= rows) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<uint4*>(exact + r0)[q] = uint4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) if (r0 + e < rows) exact[r0 + e] = h[e];
+        }
+        *reinterpret_cast<uint4*>(key + r0) = uint4{packed[0], packed[1], packed[2], packed[3]};
+        unsigned int idp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) idp[e] = (unsigned int)(r0 + 2 * e) | ((unsigned int)(r0 + 2 * e + 1) << 16);
+        reinterpret_cast<uint4*>(&ids[0][r0])[0] = uint4{idp[0], idp[1], idp[2], idp[3]};
+        reinterpret_cast<uint4*>(&ids[0][r0])[1] = uint4{idp[4], idp[5], idp[6], idp[7]};
     }
-    // (the sum of the counters: at most 16 384 x 2^20 = 2^34 -- in two 20-bit halves through the int reduction)
+    // (the sum of the counters: at most 16 384 x 2^20 = 2^34 -- in two halves through the int reduction)
     const unsigned long long total = ((unsigned long long)(unsigned int)block_sum((int)(mine >> 17)) << 17) + (unsigned long long)(unsigned int)block_sum((int)(mine & 0x1ffffull));
     __syncthreads();
-    // ---- three stable counting passes of 4 bits ----
+    // ---- two stable counting passes of 4 bits ----
     int cur = 0;
-    for (int shift = 0; shift < 12; shift += 4) {
+#pragma unroll 1
+    for (int shift = 0; shift < 8; shift += 4) {
+        // the thread's sixteen entries (two 16-byte reads), their digits, and -- in two words of sixteen 5-bit fields (<= 16 each) --
+        // how many of each digit: an entry's rank among the thread's earlier entries of its digit is the field's value as it is counted
+        unsigned int id16[16], rk = 0u, dg16[2] = {0u, 0u};
+        {
+            const uint4 a = reinterpret_cast<const uint4*>(&ids[cur][t * 16])[0], b = reinterpret_cast<const uint4*>(&ids[cur][t * 16])[1];
+            const unsigned int wds[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int d = 0; d < 16; ++d) cnt[d * 1024 + t] = 0;
-        // (own column: no atomics)
-        for (int e = 0; e < 16; ++e) { const int d = (key[ids[cur][t * 16 + e]] >> shift) & 15; cnt[d * 1024 + t] = (unsigned short)(cnt[d * 1024 + t] + 1); }
+            for (int e = 0; e < 16; ++e) id16[e] = (wds[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+        }
+        unsigned long long c_lo = 0ull, c_hi = 0ull;   // digits 0..11 in c_lo (5 bits each), 12..15 in c_hi
+        unsigned int kv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) kv[e] = key[id16[e]];   // (independent reads: one LDS latency for all)
+        unsigned int ranks[2] = {0u, 0u};   // sixteen 4-bit ranks ... a rank can be 15 at most (the sixteenth entry of one digit)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const unsigned int d = (kv[e] >> shift) & 15u;
+            const unsigned int sh5 = 5u * (d < 12u ? d : d - 12u);
+            const unsigned long long cw = d < 12u ? c_lo : c_hi;
+            const unsigned int r = (unsigned int)(cw >> sh5) & 31u;
+            if (d < 12u) c_lo += 1ull << sh5; else c_hi += 1ull << sh5;
+            ranks[e >> 3] |= r << (4 * (e & 7));
+            dg16[e >> 3] |= d << (4 * (e & 7));
+        }
+        (void)rk;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[d * 1024 + t] = (unsigned short)((d < 12 ? (c_lo >> (5 * d)) : (c_hi >> (5 * (d - 12)))) & 31ull);
         __syncthreads();
         // exclusive scan of the 16 384 counters in (digit, thread) order: thread t scans entries [16 t, 16 t + 16)
+        unsigned int cw8[8];
+        {
+            const uint4 a = reinterpret_cast<const uint4*>(&cnt[t * 16])[0], b = reinterpret_cast<const uint4*>(&cnt[t * 16])[1];
+            cw8[0] = a.x; cw8[1] = a.y; cw8[2] = a.z; cw8[3] = a.w; cw8[4] = b.x; cw8[5] = b.y; cw8[6] = b.z; cw8[7] = b.w;
+        }
         int loc[16], run = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { loc[e] = run; run += cnt[t * 16 + e]; }
+        for (int e = 0; e < 16; ++e) { loc[e] = run; run += (int)((cw8[e >> 1] >> (16 * (e & 1))) & 0xffffu); }
         int v = run;   // inclusive scan of the threads' sums
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); v += lane >= o ? u : 0; }
@@ -423,16 +656,22 @@ __global__ __launch_bounds__(1024) void pass_control_kernel(unsigned int* __rest
 #pragma unroll
         for (int k = 0; k < 16; ++k) base += k < w ? wsum[k] : 0;
         const int excl = base + v - run;
+        {
+            unsigned int o8[8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) cnt[t * 16 + e] = (unsigned short)(excl + loc[e]);   // (< 16 384: fits)
-        __syncthreads();
-        for (int e = 0; e < 16; ++e) {
-            const unsigned short id = ids[cur][t * 16 + e];
-            const int d = (key[id] >> shift) & 15;
-            const unsigned short pos = cnt[d * 1024 + t];
-            cnt[d * 1024 + t] = (unsigned short)(pos + 1);
-            ids[cur ^ 1][pos] = id;
+            for (int e = 0; e < 8; ++e) o8[e] = (unsigned int)(excl + loc[2 * e]) | ((unsigned int)(excl + loc[2 * e + 1]) << 16);   // (< 16 384: fits)
+            reinterpret_cast<uint4*>(&cnt[t * 16])[0] = uint4{o8[0], o8[1], o8[2], o8[3]};
+            reinterpret_cast<uint4*>(&cnt[t * 16])[1] = uint4{o8[4], o8[5], o8[6], o8[7]};
         }
+        __syncthreads();
+        unsigned int pos[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const unsigned int d = (dg16[e >> 3] >> (4 * (e & 7))) & 15u;
+            pos[e] = (unsigned int)cnt[d * 1024 + t] + ((ranks[e >> 3] >> (4 * (e & 7))) & 15u);   // (independent reads)
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ids[cur ^ 1][pos[e]] = (unsigned short)id16[e];
         __syncthreads();
         cur ^= 1;
     }
@@ -597,6 +836,14 @@ hipError_t launch_morton_order(const PrepBuffers& b, const float* X, int n, int 
     return hipGetLastError();
 }
 
+hipError_t launch_curve_order_small(const PrepBuffers& b, const float* X, int n, int n_pad, const unsigned int* enc, int32_t* perm_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_curve_keys_enc_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, n, n_pad, enc, b.keys[0], b.vals[0]);
+    if (hipError_t e = sort_pairs(b, n, 0, 31, st)) return e;
+    return hipMemcpyAsync(perm_out, b.vals[1], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+}
+
 hipError_t launch_gather_sorted(const float* Qs, int m, int m_pad, const int32_t* perm, float* out, int32_t* perm_pad, hipStream_t st)
 {
     if (m_pad <= 0) return hipSuccess;
@@ -734,6 +981,42 @@ size_t model_boxes_bytes(int m_pad)
 {
     const size_t chunks = (size_t)(m_pad + 7) / 8, supers = (chunks + 63) / 64, thirds = (supers + 63) / 64;
     return (chunks + supers + thirds) * 8 * sizeof(float);
+}
+
+// chunk boxes and chunk samples of a model that is searched flat, in ONE launch (the upper box levels are read by the hierarchical
+// search only): thread c does chunk c's box and -- the samples array is padded to a multiple of 8 chunks -- sample c
+__global__ void model_boxes_samples_kernel(const float* __restrict__ Qs, int m_pad, int ns_pad, float* __restrict__ boxes, float* __restrict__ samples)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ns_pad) return;
+    float lo[3], hi[3], sv[3] = {inf_<float>(), inf_<float>(), inf_<float>()};
+    bool have = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = inf_<float>(); hi[a] = -inf_<float>(); }
+    for (int k = 0; k < 8; ++k) {
+        const int j = c * 8 + k;
+        if (j >= m_pad) break;
+        const float p[3] = {Qs[j], Qs[(size_t)m_pad + j], Qs[2 * (size_t)m_pad + j]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (p[a] < inf_<float>() && p[a] > -inf_<float>()) { lo[a] = __builtin_fminf(lo[a], p[a]); hi[a] = __builtin_fmaxf(hi[a], p[a]); }
+        if (!have && p[0] < inf_<float>() && p[0] > -inf_<float>()) { sv[0] = p[0]; sv[1] = p[1]; sv[2] = p[2]; have = true; }   // (model_samples_kernel's rule)
+    }
+    if (c * 8 < m_pad) {
+        float* o = boxes + (size_t)c * 8;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+    }
+    samples[c] = sv[0];
+    samples[(size_t)ns_pad + c] = sv[1];
+    samples[2 * (size_t)ns_pad + c] = sv[2];
+}
+
+hipError_t launch_model_boxes_samples(const void* Qs_soa, int m_pad, float* boxes, float* samples, hipStream_t st)
+{
+    if (m_pad <= 0) return hipSuccess;
+    const int ns_pad = ((m_pad / 8) + 7) / 8 * 8;
+    hipLaunchKernelGGL(model_boxes_samples_kernel, dim3((ns_pad + 255) / 256), dim3(256), 0, st, (const float*)Qs_soa, m_pad, ns_pad, boxes, samples);
+    return hipGetLastError();
 }
 
 hipError_t launch_model_boxes(const void* Qs_soa, int m_pad, float* boxes, hipStream_t st)

@@ -759,36 +759,10 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
                 __syncthreads();   // the super list is complete (and, after a processed round, the chunk list's reset is seen)
                 int SH = *scount;
                 if (tb == t_lo && tg == 0 && fuse.samples != nullptr && fuse.refine_min > 0) {
-                  float B_listed = Bs;   // the bound the super list was made with
-                  for (int rr = 0; rr < fuse.refine_rounds && SH >= fuse.refine_min; ++rr) {
-                    if (rr > 0) {
-                        // A SECOND ROUND (round 4): the first one has brought the bounds down -- to a fraction where they were loose -- and
-                        // most of the super boxes just listed no longer pass.  The list is made again with the new bound (the survivors
-                        // are compacted through the still empty chunk hit list) and the samples of THOSE boxes are taken -- every k-th of
-                        // a list a fraction as long: several times denser where the row's neighbours are.  Only while the bound at least
-                        // halves (the listed area goes with the bound): near-final bounds skip it.
-                        const float B2 = wave_minmax<true>(__builtin_fmaxf(best[0], best[1]));
-                        if (!(B2 < 0.5f * B_listed)) break;
-                        B_listed = B2;
-                        int* tmp = reinterpret_cast<int*>(lds_raw);
-                        int* tmpcount = hcount + 3;
-                        if (threadIdx.x == 0) *tmpcount = 0;
-                        __syncthreads();
-                        for (int k0 = 0; k0 < SH; k0 += NWS * 64) {
-                            const int k = k0 + (int)threadIdx.x;
-                            const int sidx = k < SH ? shits[k] : s_lo;
-                            const float4* bp = reinterpret_cast<const float4*>(sboxes + (size_t)sidx * 8);
-                            append(k < SH && near_box(bp[0], bp[1], B2), sidx, tmp, tmpcount);
-                            if constexpr (DIAG) wk_upper += 64u;
-                        }
-                        __syncthreads();
-                        const int SH2 = *tmpcount;
-                        for (int k = threadIdx.x; k < SH2; k += NWS * 64) shits[k] = tmp[k];
-                        if (threadIdx.x == 0) *scount = SH2;
-                        __syncthreads();
-                        SH = SH2;
-                        if (SH < fuse.refine_min) break;
-                    }
+                  // (round 4 tried a SECOND round -- the super boxes listed again with the bound the first round has left, compacted, their
+                  // samples taken several times denser: 10 M x 10 M 4.884 against 4.891 ms per iteration with one round, the share of one
+                  // rank of eight 16.5-16.8 against 16.6-16.7 ms per 30 iterations, same box: nothing; profiles/r4/r4_03_s5_ab_*.txt.  Removed.)
+                  if (SH >= fuse.refine_min) {
                     // REFINEMENT ROUND (a pass whose bounds are loose lists many super boxes): before any chunk is listed, the row's
                     // points are measured against the chunk samples of the super boxes just listed -- every k-th of them, at most
                     // refine_cnt -- staged over the (still empty) chunk hit list.  Any model point gives a valid bound; these lie

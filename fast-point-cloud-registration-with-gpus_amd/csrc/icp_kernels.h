@@ -64,7 +64,6 @@ struct NNTuning {
     int speculate = 1;       // ICP_NN_SPECULATE=0: resident launches without their speculative hit list
     int f64_sparse = 1;      // ICP_F64_SPARSE=0: ICP_F64 clouds on the dense thread-per-point kernel
     int sort = -1;           // ICP_SORT=0 / 1: spatially sorted views never / always (-1: by the extent test)
-    int refine_rounds = 2;   // ICP_NN_REFINE_ROUNDS=1: the hierarchical search takes ONE refinement round (round 3's form; A/B runs)
     // ICP_NN_PHASES=file[:pass[:slots[:wipe]]] -- per-wave phase stamps of the matching kernels (tools/phase_report.py); the
     // context owns the log
     long long* phase_log = nullptr;
@@ -280,6 +279,15 @@ hipError_t launch_morton_order(const PrepBuffers& b, const float* X_soa, int n, 
                                double* totals_dev, hipStream_t st);
 hipError_t launch_gather_sorted(const float* Qs_soa, int m, int m_pad, const int32_t* perm, float* out_soa, int32_t* perm_pad, hipStream_t st);
 hipError_t launch_slot_map(const int32_t* perm, int n, int n_pad, int32_t* out, hipStream_t st);
+// round 4, the set-up of a cloud in a handful of launches (icp_k_setup.hip): exact duplicates by hashing (table: a power of two of
+// >= 2 n 32-bit words, never cleared; gen: the upload's number), the scan copy in the same pass; group extents summed in fixed
+// point relative to the bounding cube the layout kernel left in enc[6] (out[2 * which] given order, [2 * which + 1] `order`);
+// the curve order of a small cloud; chunk boxes + samples of a flat model in one launch
+hipError_t launch_duplicates_hashed(const float* X_soa, int n, int n_pad, unsigned int* table, unsigned int table_entries, unsigned int gen, unsigned char* voided,
+                                    int* count_dev, float* scan_out_soa, hipStream_t st);
+hipError_t launch_extents_fixed(const float* X_soa, int n, int n_pad, const int32_t* order, int group, const unsigned int* enc, unsigned long long* out, int which, hipStream_t st);
+hipError_t launch_curve_order_small(const PrepBuffers& b, const float* X_soa, int n, int n_pad, const unsigned int* enc, int32_t* perm_out, hipStream_t st);
+hipError_t launch_model_boxes_samples(const void* Qs_soa, int m_pad, float* boxes, float* samples, hipStream_t st);
 size_t model_samples_bytes(int m_pad);
 // fp64 form of the sparse search: chunk boxes {lo.xyz, hi.xyz, -, -} and one sample per chunk, in double, of the model itself
 size_t model_boxes_f64_bytes(int m_pad);
@@ -345,7 +353,10 @@ hipError_t launch_transform_error(int precision, void* P_soa, int n, int n_pad, 
 hipError_t launch_finalize(double* mom_out, const double* mom_partials, int mom_blocks, const double* err_partials,
                            int err_blocks, int rows_have_err /* slot 0 of the rows carries error shares */, hipStream_t st, double* scratch = nullptr /* >= 256 x ICP_NMOM doubles: many rows are added in two stages */);
 
-hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st, unsigned int* nonfinite = nullptr);
+// soa2 (optional): a second copy of the result (the pristine moving cloud); enc (optional, fp32): the cloud's bounding cube as six
+// ordered-integer words {~ord(min xyz), ord(max xyz)}, zero before the launch
+hipError_t launch_aos_to_soa(int precision, const void* aos, int n, int n_pad, void* soa, hipStream_t st, unsigned int* nonfinite = nullptr, void* soa2 = nullptr,
+                             unsigned int* enc = nullptr);
 hipError_t launch_soa_to_aos(int precision, const void* soa, int n, int n_pad, void* aos, hipStream_t st);
 
 // model-on-model 4 nearest neighbours (self / rank 0 dropped)

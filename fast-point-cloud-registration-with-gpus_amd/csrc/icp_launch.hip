@@ -49,7 +49,6 @@ NNTuning nn_tuning_from_env()
     t.speculate = env_int("ICP_NN_SPECULATE", 1) ? 1 : 0;
     t.f64_sparse = env_int("ICP_F64_SPARSE", 1) ? 1 : 0;
     t.sort = env_int("ICP_SORT", -1);
-    t.refine_rounds = env_int("ICP_NN_REFINE_ROUNDS", t.refine_rounds);
     return t;
 }
 
@@ -440,7 +439,6 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             // The switches of those A/B runs are gone with round 4.)
             fuse.refine_min = 12;
             fuse.refine_cnt = 256;
-            fuse.refine_rounds = tune.refine_rounds;
             fuse.round_supers = 16;
             if (hier && fuse.records == nullptr) return hipErrorInvalidValue;   // (the hierarchical search fetches its hits from the records)
             if (pl.order && ta && !fuse.resident && opt->row_order != nullptr && opt->row_hits != nullptr) {

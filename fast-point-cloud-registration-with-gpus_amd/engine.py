@@ -190,6 +190,14 @@ class Context:
                    "icp_get_work_counters")
         return dict(zip(self.WORK_SLOTS, (int(x) for x in out)))
 
+    def diag_row_roles(self, hits, min_part=2048, total_div=4096, control=True):
+        """the roles of an ordered launch's blocks from its rows' hit counters, by the device kernels the loop uses (icp_diag_row_roles)"""
+        h = np.ascontiguousarray(hits, dtype=np.uint32).copy()
+        roles = np.zeros(h.size + 4096, dtype=np.int32)
+        capi.check(self._lib.icp_diag_row_roles(self._h, h.ctypes.data_as(C.POINTER(C.c_uint32)), int(h.size), int(min_part), int(total_div), 1 if control else 0,
+                                                roles.ctypes.data_as(C.POINTER(C.c_int32))), "icp_diag_row_roles")
+        return roles, h
+
     def nn_launch_info(self):
         v = [C.c_int(0) for _ in range(5)]
         capi.check(self._lib.icp_nn_launch_info(self._h, *[C.byref(x) for x in v]), "icp_nn_launch_info")

@@ -45,6 +45,13 @@ int icp_get_work_counters(icp_ctx* ctx, uint64_t* out_slots, int reset);
  * (>= 1 each, their sum <= blocks whatever the counts hold), *target = hits per block the split aims at.  The kernel computes
  * exactly this in every block; no device is involved here (no reference counterpart: its kernels are thread-per-point). */
 int icp_share_rows_plan(const uint32_t* hits, int rows, int blocks, int model_points, int min_hits, int32_t* parts, uint32_t* target);
+/* ordered + split rows (large clouds): the roles a launch's blocks get from the hit counters of the launch before,
+ * computed ON THE DEVICE by the kernels the loop uses -- control != 0: the single-workgroup launch (rows <= 16 384: quantised
+ * counting sort + roles), else keys + rocPRIM radix sort + roles.  roles_out: rows + ICP_ROLES_EXTRA entries, each
+ * row | part << 21 | log2(parts) << 27, or -1 for a block nothing needs; hits_io is read AND zeroed, as by the loop.
+ * min_part / total_div: the smallest part of a split row in hits, and what the counters' sum is divided by for the target. */
+#define ICP_ROLES_EXTRA 4096
+int icp_diag_row_roles(icp_ctx* ctx, uint32_t* hits_io, int rows, int min_part, int total_div, int control, int32_t* roles_out);
 
 #ifdef __cplusplus
 }

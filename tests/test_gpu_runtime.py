@@ -414,3 +414,40 @@ def test_a_numeric_failure_keeps_the_loop_readable(pkg, form):
         assert st["passes"] == 0 and st["iterations"] == 0 and np.array_equal(st["T"], np.eye(4))
         assert np.array_equal(c.loop_indices(), np.arange(64, dtype=np.int32))   # the pass itself completed: a point is its own match
         assert np.array_equal(c.get_moving(), P)
+
+
+@pytest.mark.parametrize("rows", [9768, 16384, 1500, 257])
+def test_row_roles_of_the_single_workgroup_launch(ctx, pkg, rows):
+    """ordered + split rows: the roles of a launch's blocks, by the single-workgroup control kernel (round 4) and by the
+    keys + radix sort + roles chain it replaces -- every row exactly once (a split row: parts = 2^k blocks, parts 0..2^k-1), the
+    heaviest rows first, spare blocks -1, the counters zeroed.  Any assignment is exact; this is what keeps it a complete one."""
+    rng = np.random.default_rng(rows)
+    hits = (rng.pareto(1.5, rows) * 150).astype(np.uint32)
+    hits[rng.integers(0, rows, 7)] = rng.integers(100_000, 900_000, 7)       # a few very heavy rows: they get split
+    hits[rng.integers(0, rows, 50)] = 0
+    ROW, PART, LG = (1 << 21) - 1, 63, 7
+    seen = {}
+    for control in (True, False):
+        roles, left = ctx.diag_row_roles(hits, min_part=2048, total_div=4096, control=control)
+        assert not left.any()                                                # read AND zeroed
+        live = roles[roles >= 0]
+        row, part, parts = live & ROW, (live >> 21) & PART, 1 << ((live >> 27) & LG)
+        assert roles.size == rows + 4096 and (roles[live.size:] == -1).all() # the roles come first, the spare blocks after them
+        count = np.bincount(row, minlength=rows)
+        first = {}
+        for r, p, ps in zip(row.tolist(), part.tolist(), parts.tolist()):
+            first.setdefault(r, (ps, set()))[1].add(p)
+            assert first[r][0] == ps
+        assert len(first) == rows                                            # every row has a role
+        for r, (ps, got) in first.items():
+            assert got == set(range(ps)) and count[r] == ps                  # ... and all of its parts, once each
+        split = {r: ps for r, (ps, _) in first.items() if ps > 1}
+        assert split and all(hits[r] >= 2048 for r in split)                 # only heavy rows are split
+        assert max(split, key=lambda r: split[r]) in np.argsort(hits)[-8:]   # the most parts go to one of the heaviest
+        # heaviest first: the order of the unsplit rows follows the counts (the control kernel's to its 12 % quantisation)
+        order = [r for r in row.tolist() if first[r][0] == 1]
+        h = hits[order].astype(np.float64)
+        tol = 1.0 if not control else 1.15
+        assert (h[1:] <= np.maximum(h[:-1] * tol, h[:-1] + 1)).all()
+        seen[control] = split
+    assert set(seen[True]) == set(seen[False])                               # both forms split the same rows (exact counts decide)
