@@ -295,7 +295,11 @@ struct icp_ctx {
     bool model_sorted = false, moving_sorted = false;
     // scratch of the device-side preparation (duplicate flags, Morton order, extent test)
     DevBuf prep_keys[2], prep_vals[2], prep_tmp, prep_small, prep_ext, prep_voided, prep_perm;
-    struct PrepSmall { float box[4]; double totals[4]; int voided; int pad_; unsigned int enc[6]; unsigned int pad2_[2]; unsigned long long fixed[4]; };
+    struct PrepSmall { float box[4]; double totals[4]; int voided; int pad_; unsigned int enc[6]; unsigned int ticket; unsigned int pad2_; unsigned long long fixed[4]; };
+    icp::PrepReport* h_prep = nullptr;   // pinned, coherent: where the short set-up's last launch leaves its sums (the host spins on its seq word)
+    unsigned int prep_seq = 0;
+    void* h_stage = nullptr;             // pinned, mapped: small clouds are laid out straight from here (no separate copy command)
+    size_t h_stage_cap = 0;
     // round 4, the short set-up of clouds of up to kPrepSmallMax points: exact duplicates by hashing (a table that is never cleared:
     // entries carry the upload's generation), and the spatial-order decision remembered per (cloud kind, size, group) -- a sensor's next
     // scan has the order of the one before: while the given order's summed group extent stays within a quarter of the remembered one
@@ -526,10 +530,26 @@ int upload_cloud(icp_ctx* c, const void* aos, int count, int pad, int precision,
     const size_t es = icp::elem_size(precision);
     HIP_TRY(dst.ensure(3 * (size_t)pad * es));
     if (count <= 0) return ICP_OK;
-    HIP_TRY(c->stage.ensure(3 * (size_t)count * es));
-    HIP_TRY(hipMemcpyAsync(c->stage.p, aos, 3 * (size_t)count * es, hipMemcpyHostToDevice, c->stream));
+    const size_t bytes = 3 * (size_t)count * es;
+    const void* src = nullptr;
+    if (deferred && bytes <= (4u << 20)) {
+        // a small cloud whose set-up ends with a wait anyway: copied by this thread into pinned, mapped memory and laid out straight
+        // from there by the layout kernel (one pass over PCIe) -- no copy command, no runtime staging of a pageable source
+        if (bytes > c->h_stage_cap) {
+            if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
+            const size_t want = std::max(bytes, (size_t)1 << 20);
+            HIP_TRY(hipHostMalloc(&c->h_stage, want, hipHostMallocMapped | hipHostMallocCoherent));
+            c->h_stage_cap = want;
+        }
+        std::memcpy(c->h_stage, aos, bytes);
+        src = c->h_stage;
+    } else {
+        HIP_TRY(c->stage.ensure(bytes));
+        HIP_TRY(hipMemcpyAsync(c->stage.p, aos, bytes, hipMemcpyHostToDevice, c->stream));
+        src = c->stage.p;
+    }
     *(volatile unsigned int*)c->h_nonfinite = 0u;
-    HIP_TRY(icp::launch_aos_to_soa(precision, c->stage.p, count, pad, dst.p, c->stream, c->h_nonfinite, soa2, enc));
+    HIP_TRY(icp::launch_aos_to_soa(precision, src, count, pad, dst.p, c->stream, c->h_nonfinite, soa2, enc));
     if (deferred) return ICP_OK;
     // the staging buffer is reused by the next upload: order them on the stream, and make sure the
     // pageable host source has been consumed before returning
@@ -619,27 +639,54 @@ static int decide_order_small(icp_ctx* c, const icp::PrepBuffers& pb, const void
     const bool trivial = count <= group || force == 0;                       // never sorted: nothing to measure
     const bool fast = !trivial && force < 0 && memo.valid && memo.count == count && memo.group == group && !memo.sorted;
     bool have_sorted = false;
+    unsigned int seq = 0;
     auto sorted_extents = [&](int which) -> int {
         HIP_TRY(icp::launch_curve_order_small(pb, (const float*)X_soa, count, pad, small->enc, (int32_t*)c->prep_perm.p, c->stream));
-        HIP_TRY(icp::launch_extents_fixed((const float*)X_soa, count, pad, (const int32_t*)c->prep_perm.p, group, small->enc, small->fixed, which, c->stream));
+        seq = ++c->prep_seq ? c->prep_seq : ++c->prep_seq;
+        HIP_TRY(icp::launch_extents_fixed((const float*)X_soa, count, pad, (const int32_t*)c->prep_perm.p, group, small->enc, small->fixed, which, c->stream,
+                                          &small->ticket, &small->voided, c->h_prep, seq));
         have_sorted = true;
         return ICP_OK;
     };
+    // the launch's last block leaves the sums in pinned memory: the host spins on the sequence word (a copy back and a stream
+    // synchronisation cost 15-20 us more); should the word never come, the runtime says why
+    struct Report { unsigned long long fixed[4]; int voided; };
+    auto wait_report = [&](Report& h) -> int {
+        if (seq != 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const volatile unsigned int* w = &c->h_prep->seq;
+            bool there = false;
+            for (unsigned spins = 1; !(there = *w == seq); ++spins)
+                if ((spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+            if (there) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                for (int k = 0; k < 4; ++k) h.fixed[k] = c->h_prep->fixed[k];
+                h.voided = c->h_prep->voided;
+                return ICP_OK;
+            }
+        }
+        icp_ctx::PrepSmall full{};
+        HIP_TRY(hipMemcpyAsync(&full, c->prep_small.p, sizeof full, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 4; ++k) h.fixed[k] = full.fixed[k];
+        h.voided = full.voided;
+        return ICP_OK;
+    };
     if (!trivial) {
-        if (fast) HIP_TRY(icp::launch_extents_fixed((const float*)X_soa, count, pad, nullptr, group, small->enc, small->fixed, 0, c->stream));
-        else if (int rc = sorted_extents(0)) return rc;
+        if (fast) {
+            seq = ++c->prep_seq ? c->prep_seq : ++c->prep_seq;
+            HIP_TRY(icp::launch_extents_fixed((const float*)X_soa, count, pad, nullptr, group, small->enc, small->fixed, 0, c->stream, &small->ticket, &small->voided, c->h_prep, seq));
+        } else if (int rc = sorted_extents(0)) return rc;
     }
-    icp_ctx::PrepSmall h{};
-    HIP_TRY(hipMemcpyAsync(&h, c->prep_small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    Report h{};
+    if (int rc = wait_report(h)) return rc;
     if (int rc = check_nonfinite(c, count)) return rc;
     constexpr double kFix = 1.0 / 68719476736.0;   // 2^-36
     double given = (double)h.fixed[0] * kFix, sorted = (double)h.fixed[1] * kFix;
     if (fast && !(given <= 1.25 * memo.given_rel)) {
         // the cloud is not what the one before was: measure the curve order after all (a second short round trip, once)
         if (int rc = sorted_extents(1)) return rc;
-        HIP_TRY(hipMemcpyAsync(&h, c->prep_small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (int rc = wait_report(h)) return rc;
         given = (double)h.fixed[2] * kFix;
         sorted = (double)h.fixed[3] * kFix;
     }
@@ -767,6 +814,8 @@ int icp_create(int device, icp_ctx** out)
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_nonfinite, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_final, ICP_NMOM * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) std::memset(c->h_final, 0, ICP_NMOM * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_prep, sizeof(icp::PrepReport), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) std::memset(c->h_prep, 0, sizeof(icp::PrepReport));
     if (e == hipSuccess) {
         // mailbox: fine-grained device memory written through the PCIe BAR when the machine allows it (every block
         // polls its own memory), else pinned host memory polled by block 0 and relayed (ICP_MAILBOX=host forces that)
@@ -866,6 +915,8 @@ void icp_destroy(icp_ctx* c)
     if (c->h_mom) (void)hipHostFree(c->h_mom);
     if (c->h_nonfinite) (void)hipHostFree(c->h_nonfinite);
     if (c->h_final) (void)hipHostFree(c->h_final);
+    if (c->h_prep) (void)hipHostFree(c->h_prep);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_mail) { if (c->mail_in_bar) (void)hipFree(c->h_mail); else (void)hipHostFree(c->h_mail); }
     if (c->relay) (void)hipFree(c->relay);
     if (c->h_mom_partials) (void)hipHostFree(c->h_mom_partials);

@@ -285,7 +285,11 @@ hipError_t launch_slot_map(const int32_t* perm, int n, int n_pad, int32_t* out, 
 // the curve order of a small cloud; chunk boxes + samples of a flat model in one launch
 hipError_t launch_duplicates_hashed(const float* X_soa, int n, int n_pad, unsigned int* table, unsigned int table_entries, unsigned int gen, unsigned char* voided,
                                     int* count_dev, float* scan_out_soa, hipStream_t st);
-hipError_t launch_extents_fixed(const float* X_soa, int n, int n_pad, const int32_t* order, int group, const unsigned int* enc, unsigned long long* out, int which, hipStream_t st);
+// (ticket / voided_count / report / seq: the launch's last block leaves the four sums, the duplicate count and `seq` in pinned host
+// memory -- the host spins on report->seq; all NULL: nothing is reported)
+struct PrepReport { unsigned long long fixed[4]; int voided; unsigned int seq; };
+hipError_t launch_extents_fixed(const float* X_soa, int n, int n_pad, const int32_t* order, int group, const unsigned int* enc, unsigned long long* out, int which, hipStream_t st,
+                                unsigned int* ticket = nullptr, const int* voided_count = nullptr, PrepReport* report = nullptr, unsigned int seq = 0);
 hipError_t launch_curve_order_small(const PrepBuffers& b, const float* X_soa, int n, int n_pad, const unsigned int* enc, int32_t* perm_out, hipStream_t st);
 hipError_t launch_model_boxes_samples(const void* Qs_soa, int m_pad, float* boxes, float* samples, hipStream_t st);
 size_t model_samples_bytes(int m_pad);
