@@ -20,18 +20,12 @@ template <> struct SpHit<true> { using type = int; };
 // Returns how far the hit got (wave-uniform; only the work-counting instantiation looks at it): 0 = rejected by the
 // per-point box test, 1 = by the xy early-out, 2 = the eight distances were evaluated in full.
 constexpr bool SP_XY_EARLY_OUT = false;
-// level 0 of a hit on its own (wave-uniform answer): may the chunk's bounding box hold a winner for any of the wave's points?
-__device__ __forceinline__ bool hit_box_test(const float* sb, const f2 px, const f2 py, const f2 pz, const float (&best)[2])
-{
-    const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
-    return __builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) != 0ull;
-}
-template <bool PERM, bool BOX_DONE = false /* the caller has made the box test (hit_box_test) */>
+template <bool PERM>
 __device__ __forceinline__ int scan_hit(const float* sb, int ch, const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
                                         float (&bq)[2][3])
 {
     constexpr int C = 8;
-    if constexpr (!BOX_DONE) {
+    {
         // level 0: the chunk's bounding box against each of the lane's points (ties pass: the hits are unordered)
         const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
         if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull) return 0;

@@ -22,8 +22,22 @@ __global__ void aos_to_soa_kernel(const F* __restrict__ aos, int n, int n_pad, F
     const bool in = i < n_pad;
     const int s = i < n ? i : n - 1;  // padding replicates the last real point
     F x = F(0), y = F(0), z = F(0);
+    // the block's 256 points are 768 contiguous values: fetched as 16-byte vectors, coalesced (the source may be pinned HOST memory read
+    // over PCIe -- the short set-up -- where three strided 4-byte loads per thread were 15 us for 196 KB), handed out through LDS; a block
+    // that reaches beyond the cloud (its tail, the padding) reads its points one by one
+    __shared__ __attribute__((aligned(16))) F buf[768];
+    const size_t b0 = (size_t)blockIdx.x * 256;
+    const bool whole = b0 + 256 <= (size_t)n;
+    if (whole) {
+        constexpr int PER = 16 / (int)sizeof(F), NV = 768 / PER;
+        using V = typename Vec16<F>::type;
+        const V* src = reinterpret_cast<const V*>(aos + 3 * b0);
+        for (int k = threadIdx.x; k < NV; k += 256) reinterpret_cast<V*>(buf)[k] = src[k];
+    }
+    __syncthreads();
     if (in) {
-        x = aos[3 * (size_t)s + 0]; y = aos[3 * (size_t)s + 1]; z = aos[3 * (size_t)s + 2];
+        if (whole) { x = buf[3 * threadIdx.x]; y = buf[3 * threadIdx.x + 1]; z = buf[3 * threadIdx.x + 2]; }
+        else { x = aos[3 * (size_t)s + 0]; y = aos[3 * (size_t)s + 1]; z = aos[3 * (size_t)s + 2]; }
         soa[i] = x;
         soa[(size_t)n_pad + i] = y;
         soa[2 * (size_t)n_pad + i] = z;

@@ -291,10 +291,27 @@ __device__ __forceinline__ unsigned int hash3(unsigned int a, unsigned int b, un
 __global__ void prep_dup_insert_kernel(const float* __restrict__ X, int n, int n_pad, unsigned int* __restrict__ table, unsigned int mask, unsigned int gen)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = X[i], y = X[(size_t)n_pad + i], z = X[2 * (size_t)n_pad + i];
-    if (x != x || y != y || z != z) return;   // (NaN equals nothing; such a cloud is refused anyway)
+    const bool in = i < n;
+    const float x = in ? X[i] : 0.f, y = in ? X[(size_t)n_pad + i] : 0.f, z = in ? X[2 * (size_t)n_pad + i] : 0.f;
+    const bool live = in && !(x != x || y != y || z != z);   // (NaN equals nothing; such a cloud is refused anyway)
     const unsigned int bx = canon_bits(x), by = canon_bits(y), bz = canon_bits(z), me = (gen << 24) | (unsigned int)i;
+    // One insert per wave and coordinate triple: the hall scan's 4 361 no-return points all hash to ONE slot, and thousands of atomics on
+    // one address were 60 us of a 107 us set-up.  The lanes of a wave are consecutive indices, so the lowest lane of a group of equal
+    // points holds the group's minimum within the wave: it alone goes to the table (a loop over the wave's distinct points).
+    bool leader = false;
+    {
+        const int lane = (int)(threadIdx.x & 63);
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
+        while (todo != 0ull) {
+            const int first = (int)__builtin_ctzll(todo);
+            const unsigned int fx = (unsigned int)__builtin_amdgcn_readlane((int)bx, first), fy = (unsigned int)__builtin_amdgcn_readlane((int)by, first),
+                               fz = (unsigned int)__builtin_amdgcn_readlane((int)bz, first);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(live && bx == fx && by == fy && bz == fz) & todo;
+            if (lane == first) leader = true;
+            todo &= ~same;
+        }
+    }
+    if (!leader) return;
     unsigned int h = hash3(bx, by, bz) & mask;
     for (unsigned int probes = 0; probes <= mask; ++probes) {
         unsigned int v = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

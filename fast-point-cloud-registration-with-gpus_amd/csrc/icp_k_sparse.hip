@@ -38,9 +38,6 @@ namespace icp {
 // HIER: two-level search (large models): boxes of 64 chunks are tested first, lane-parallel like the chunks, and only
 // the chunks of the surviving ones after them -- compiled apart for the same reason (the extra level costs a small
 // model more than it saves)
-#ifndef SP_PAIR_HITS
-#define SP_PAIR_HITS 1
-#endif
 template <int TAIL, bool DIAG, bool PERM, bool HIER = false, int NWS = SP_NW>
 __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(const float* __restrict__ P, int n_pad,
                                                               const float* __restrict__ Q, int m_pad, int seg_len,
@@ -605,28 +602,11 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
                     if (real[t] && v < 0x7f800000u && v < __float_as_uint(best[t])) { best[t] = __uint_as_float(v + 1u); bj[t] = -1; }
                 }
             }
-            int rr = 0;
-            if constexpr (SP_PAIR_HITS && HIER) {
-                // Two hits at a time (round 4): both box tests first -- their LDS reads and arithmetic are independent, where one hit
-                // after the other exposes an LDS round trip per rejected hit (three of four) -- and when the first of the pair goes on
-                // to the exact arithmetic (which may lower the bounds) the second is tested once more, so that nothing is evaluated that
-                // the one-by-one order would have rejected (round 3 hoisted the tests of a whole batch: +11 % evaluated in full)
-                for (; rr + 1 < cnt; rr += 2) {
-                    const float* s0 = stage + rr * STG;
-                    const float* s1 = s0 + STG;
-                    const bool a = hit_box_test(s0, px, py, pz, best);
-                    bool b = hit_box_test(s1, px, py, pz, best);
-                    const int ch0 = PERM ? 0 : __builtin_amdgcn_readfirstlane((int)hits[hb + rr * NWS + w]);
-                    const int ch1 = PERM ? 0 : __builtin_amdgcn_readfirstlane((int)hits[hb + (rr + 1) * NWS + w]);
-                    if (a) {
-                        scan_hit<PERM, true>(s0, ch0, px, py, pz, best, bj, bq);
-                        if (b) b = hit_box_test(s1, px, py, pz, best);
-                    }
-                    if (b) scan_hit<PERM, true>(s1, ch1, px, py, pz, best, bj, bq);
-                    if constexpr (DIAG) { wk_hit[0] += 2u; wk_hit[1] += (a ? 1u : 0u) + (b ? 1u : 0u); wk_hit[2] += (a ? 1u : 0u) + (b ? 1u : 0u); }
-                }
-            }
-            for (; rr < cnt; ++rr) {
+            // (round 4 tried the hits two at a time -- both box tests first, their LDS reads independent, the second made once more when
+            // the first went on to the exact arithmetic: 10 M x 10 M 4.93 against 4.90 ms per iteration one by one, the share of one rank of
+            // eight 16.6 against 16.8 ms per 30 iterations, same box -- nothing: four blocks to a CU already cover an LDS round trip.
+            // profiles/r4/r4_06_s5_ab_*.txt.  Removed.)
+            for (int rr = 0; rr < cnt; ++rr) {
                 int stage_reached;
                 if constexpr (PERM) {
                     stage_reached = scan_hit<true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
