@@ -77,7 +77,8 @@ static inline void bar_fence()
 // The compact rows of a pass added up, rows in block order: four 4-double accumulators take a row's sixteen slots at once.
 // Every slot is still the sum of its 256 values in block order, starting from zero -- the bits of the scalar loop -- but the
 // sixteen chains advance together instead of one after the other (hall: 256 rows, once per pass, on the path between the last
-// row's arrival and the next message).  Slot 0 carries the row's tag in its low mantissa bits: masked off as it is loaded.
+// row's arrival and the next message).  The first slot of every 32-byte sector (0, 4, 8, 12) carries the row's tag in its low
+// mantissa bits (round 4: one store per row, no drain -- tail_reduce_store): masked off as it is loaded.
 __attribute__((target("avx"))) static void add_compact_rows_avx(const double* rows, int count, unsigned long long tag_mask, double (&out)[16])
 {
     const __m256d keep = _mm256_castsi256_pd(_mm256_set_epi64x(-1ll, -1ll, -1ll, (long long)~tag_mask));
@@ -85,9 +86,9 @@ __attribute__((target("avx"))) static void add_compact_rows_avx(const double* ro
     for (int b = 0; b < count; ++b) {
         const double* r = rows + (size_t)b * 16;
         a0 = _mm256_add_pd(a0, _mm256_and_pd(_mm256_loadu_pd(r), keep));
-        a1 = _mm256_add_pd(a1, _mm256_loadu_pd(r + 4));
-        a2 = _mm256_add_pd(a2, _mm256_loadu_pd(r + 8));
-        a3 = _mm256_add_pd(a3, _mm256_loadu_pd(r + 12));
+        a1 = _mm256_add_pd(a1, _mm256_and_pd(_mm256_loadu_pd(r + 4), keep));
+        a2 = _mm256_add_pd(a2, _mm256_and_pd(_mm256_loadu_pd(r + 8), keep));
+        a3 = _mm256_add_pd(a3, _mm256_and_pd(_mm256_loadu_pd(r + 12), keep));
     }
     _mm256_storeu_pd(out, a0); _mm256_storeu_pd(out + 4, a1); _mm256_storeu_pd(out + 8, a2); _mm256_storeu_pd(out + 12, a3);
 }
@@ -1812,13 +1813,13 @@ static int loop_complete_body(icp_ctx* c, int* done)
         const size_t stride = compact ? (size_t)icp::NN_CROW : (size_t)ICP_NMOM, tag_slot = compact ? 0 : ICP_NMOM - 1;
         constexpr unsigned long long kTagMask = (1ull << icp::NN_CROW_TAG_BITS) - 1ull;
         // the tag a row carries now: a double of its own (full rows), or the low mantissa bits of slot 0 (compact rows)
+        // (compact rows: a tag in every 32-byte sector -- slots 0, 4, 8, 12; the row's tag is what all four agree on, else "none")
         auto row_tag = [&](int b) -> double {
             const volatile double* p = c->h_mom_partials + (size_t)b * stride + tag_slot;
             if (!compact) return *p;
-            unsigned long long bits;
-            const double v = *p;
-            std::memcpy(&bits, &v, sizeof bits);
-            return (double)(bits & kTagMask);
+            const volatile unsigned long long* q = reinterpret_cast<const volatile unsigned long long*>(p);
+            const unsigned long long t0 = q[0] & kTagMask, t1 = q[4] & kTagMask, t2 = q[8] & kTagMask, t3 = q[12] & kTagMask;
+            return (t0 == t1 && t0 == t2 && t0 == t3) ? (double)t0 : -1.0;
         };
         auto tag_value = [&](double tag) { return compact ? (double)((unsigned long long)tag & kTagMask) : tag; };
         auto start_sum = [&]() {
@@ -1830,13 +1831,16 @@ static int loop_complete_body(icp_ctx* c, int* done)
         auto add_row = [&](int b) {
             const double* row = c->h_mom_partials + (size_t)b * stride;
             if (compact) {   // {error share + tag, sum p, sum q, sum q p^T} -> slots ICP_MOM_SP .. ICP_MOM_SQP + 8, ICP_MOM_ERR
-                for (int k = 1; k < icp::NN_CROW; ++k) mom[ICP_MOM_SP - 1 + k] += row[k];
-                unsigned long long bits;
-                std::memcpy(&bits, &row[0], sizeof bits);
-                bits &= ~kTagMask;
-                double e;
-                std::memcpy(&e, &bits, sizeof e);
-                mom[ICP_MOM_ERR] += e;
+                auto untagged = [&](int k) {
+                    unsigned long long bits;
+                    std::memcpy(&bits, &row[k], sizeof bits);
+                    if ((k & 3) == 0) bits &= ~kTagMask;   // (the first slot of every 32-byte sector carries the tag)
+                    double v;
+                    std::memcpy(&v, &bits, sizeof v);
+                    return v;
+                };
+                for (int k = 1; k < icp::NN_CROW; ++k) mom[ICP_MOM_SP - 1 + k] += untagged(k);
+                mom[ICP_MOM_ERR] += untagged(0);
             } else {
                 for (int k = 0; k < ICP_NMOM - 1; ++k) mom[k] += row[k];  // the last slot is the completion tag
             }
@@ -1872,6 +1876,9 @@ static int loop_complete_body(icp_ctx* c, int* done)
                 while (left > 0) {
                     for (int r = 0; r < L.mom_blocks; ++r) {
                         if (seen[r] || (tags[(size_t)r * stride] & tag_bits_mask) != want_bits) continue;
+                        // (compact rows: every 32-byte sector carries the tag; the row is there when all four do)
+                        if (compact && ((tags[(size_t)r * stride + 4] & tag_bits_mask) != want_bits || (tags[(size_t)r * stride + 8] & tag_bits_mask) != want_bits ||
+                                        (tags[(size_t)r * stride + 12] & tag_bits_mask) != want_bits)) continue;
                         seen[r] = 1;
                         --left;
                         if (compact) __builtin_prefetch(reinterpret_cast<const char*>(c->h_mom_partials + (size_t)r * stride) + 64);

@@ -197,9 +197,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void nn_match_row64_f64(c
             if (w == 0) {
                 if (TAIL == 1 && tail.compact != 0) {
                     double* row = tail.rows + (size_t)blockIdx.x * NN_CROW;
-                    if (lane >= 1 && lane < NN_CROW) __hip_atomic_store(&row[lane], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(&row[0], crow_pack(err_row, row_tag_lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // (never taken: the fp64 path keeps the full row format; kept in the format's own form -- tail_reduce_store)
+                    if (lane < NN_CROW) __hip_atomic_store(&row[lane], (lane & 3) == 0 ? crow_pack(lane == 0 ? err_row : 0.0, row_tag_lo) : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else {
                     double* row = tail.rows + (size_t)blockIdx.x * ICP_NMOM;
                     if (lane < ICP_NMOM - 1) row[lane] = lane == ICP_MOM_ERR ? err_row : 0.0;

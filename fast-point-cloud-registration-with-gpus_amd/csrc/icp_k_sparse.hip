@@ -212,8 +212,10 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
     const bool from_slots = fuse.slot_state != nullptr && fuse.slot_valid != 0;   // (the same values, without the chain of gathers)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int i = fresh(pi[t]);
-        real[t] = i < fuse.n;
+        // (a slot holds a real point iff its own number is below n: the slot map permutes [0, n) and leaves the padding slots to
+        // themselves -- prep_slot_map_kernel -- so the test does not wait for the map's load, one dependent trip to memory less
+        // in every block's front end; the point's number itself is needed at the stores only)
+        real[t] = ibase + t * 64 < fuse.n;
         sok[t] = false;
         sq[t][0] = sq[t][1] = sq[t][2] = 0.f;
         if (from_slots) {
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
         } else {
             // no previous match (cold start): the model point at the same RELATIVE index -- consecutive scans of one
             // sensor, or a cloud and its moved copy, keep their order, and any valid index is a valid bound
+            const int i = fresh(pi[t]);
             int j = !real[t] ? -1 : fuse.seed_idx ? fuse.seed_idx[i] : (int)(((long long)i * fuse.m) / fuse.n);
             sok[t] = (unsigned)j < (unsigned)fuse.m;  // a seed is trusted only if it is a real model index
             j = sok[t] ? j : 0;
@@ -423,9 +426,8 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
             if (w == 0 && SP_PART == 0) {
                 if (TAIL == 1 && tail.compact != 0) {
                     double* row = tail.rows + (size_t)row_ * NN_CROW;
-                    if (lane >= 1 && lane < NN_CROW) __hip_atomic_store(&row[lane], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(&row[0], crow_pack(err_row, row_tag_lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // (one store, a tag in every 32-byte sector: tail_reduce_store)
+                    if (lane < NN_CROW) __hip_atomic_store(&row[lane], (lane & 3) == 0 ? crow_pack(lane == 0 ? err_row : 0.0, row_tag_lo) : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else {
                     double* row = tail.rows + (size_t)row_ * ICP_NMOM;
                     if (lane < ICP_NMOM - 1) row[lane] = lane == ICP_MOM_ERR ? err_row : 0.0;
