@@ -17,10 +17,11 @@ with pkg.Context(0) as ctx:
     rows = ctx.nn_launch_info()["blocks"]
     ctx.set_work_counting(True)
     ctx.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=K, tol=0.0, fixed_iterations=True)
-    prev = {k: 0 for k in ctx.get_work_counters()}
+    ctx.get_work_counters(reset=True)
     for p in range(1, K + 1):
         ctx.loop_run(1)
-        w = ctx.get_work_counters()
-        d = {k: w[k] - prev[k] for k in w}; prev = w
+        d = ctx.get_work_counters(reset=True)   # (zeroed by the read: one pass's work)
         print(f"pass {p:2d}: per row: boxes tested in the find {d['find_boxes'] / rows:8.0f} (+ upper levels {d['upper_boxes'] / rows:6.0f}), chunks listed {d['hits_box'] / rows:7.0f}, "
               f"past the per-point box test {d['hits_xy'] / rows:6.0f}, evaluated in full {d['hits_full'] / rows:6.0f}, sample groups {d['sample_groups'] / rows:5.0f}, block passes {d['block_passes'] / rows:5.2f}", flush=True)
+        if os.environ.get("S5_RAW"):   # (an experimental build that reuses slots 8..11: see the file that names it)
+            print("         raw slots 8..11:", d['spec_lists'], d['spec_covered'], d['spec_hits'], d['list_hits'], " hits_full", d['hits_full'], flush=True)
