@@ -371,6 +371,7 @@ struct NNFuse {
     unsigned int* row_hits;    // ... and adds the hits of its lists to row_hits[row]
     int refine_min, refine_cnt; // hierarchical search: a pass that lists at least refine_min super boxes takes a refinement round over <= refine_cnt of their chunk samples (0: never)
     int round_supers;          // hierarchical search: super boxes per round of the chunk find (<= 64: the hit list holds their chunks)
+    int xcd_shift;             // ordered rows: 2^xcd_shift consecutive positions of the order go to blocks of ONE XCD (0: position = block index)
     const float* records;      // hierarchical search: one 160-byte record per chunk (model_records_kernel) -- a hit is fetched from it -- or NULL
     float* seed_pub;           // resident launch with shared rows: [rows][3][128] -- whichever block closes a split row leaves the matches' coordinates
                                // here (they seed the next pass and are what its error is measured against) for the row's other blocks

@@ -481,8 +481,20 @@ __global__ void prep_slot_map_kernel(const int32_t* __restrict__ perm, int n, in
     if (k < n_pad) out[k] = k < n ? perm[k] : k;
 }
 
+// The order's weight classes (round 4): a count's class is its leading one and `bits` (0..3) bits behind it -- exact below 8 --, i.e.
+// classes 2^-bits wide; the rows of one class keep the order they have on the Hilbert curve.  Heaviest-first is about the END of a
+// launch (no long row left for last); an exact order bought that with neighbours on the curve -- rows that list mostly the same
+// chunks -- scattered over the launch and over the eight XCDs, every one of which then fetched every record for itself.
+__device__ __forceinline__ unsigned int order_class(unsigned int h, int bits)
+{
+    if (h < 8u) return h;
+    const int ex = 31 - __builtin_clz(h);
+    const unsigned int cmask = (bits >= 0 && bits < 3) ? (7u << (3 - bits)) & 7u : 7u;
+    return 8u + (unsigned int)(ex - 3) * 8u + ((h >> (ex - 3)) & 7u & cmask);   // <= 143 (20-bit counts)
+}
+
 __global__ void row_order_keys_kernel(unsigned int* __restrict__ hits, int rows, unsigned int* __restrict__ keys, int32_t* __restrict__ vals,
-                                      unsigned long long* __restrict__ total_add, unsigned long long* __restrict__ total_zero)
+                                      unsigned long long* __restrict__ total_add, unsigned long long* __restrict__ total_zero, int coarse)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned int h = 0u;
@@ -490,7 +502,9 @@ __global__ void row_order_keys_kernel(unsigned int* __restrict__ hits, int rows,
         h = hits[r];
         hits[r] = 0u;                                          // (the next launch counts afresh)
         h = h > 0xfffffu ? 0xfffffu : h;
-        keys[r] = 0xfffffu - h;                                // ascending sort of this = descending hits; ties keep the row order (stable)
+        // bits 20..27: the class, inverted (the sort looks at these alone: ascending = heaviest class first, and it is stable -- the rows
+        // of a class keep the curve's order); bits 0..19: the exact count, for the split of the head (row_roles_kernel)
+        keys[r] = ((255u - order_class(h, coarse)) << 20) | h;
         vals[r] = r;
     }
     // the sum of the counters (the target of the split rows derives from it): two words, this launch adds to one and clears
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(1024) void row_roles_kernel(const unsigned int* __r
     __shared__ int wsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int head = rows < NN_ORDER_HEAD ? rows : NN_ORDER_HEAD;
-    const unsigned int h = t < head ? 0xfffffu - keys[t] : 0u;
+    const unsigned int h = t < head ? keys[t] & 0xfffffu : 0u;
     auto block_sum = [&](int v) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -578,7 +592,7 @@ __global__ __launch_bounds__(1024) void row_roles_kernel(const unsigned int* __r
 // The split of the heaviest rows follows row_roles_kernel statement by statement (on the exact counts).
 constexpr int NN_CONTROL_MAX_ROWS = 16384;
 __global__ __launch_bounds__(1024) void pass_control_kernel(unsigned int* __restrict__ hits, int rows, unsigned int* __restrict__ exact, int min_part, int total_div,
-                                                            int32_t* __restrict__ roles)
+                                                            int32_t* __restrict__ roles, int coarse)
 {
     __shared__ __attribute__((aligned(16))) unsigned char key[NN_CONTROL_MAX_ROWS];        // quantised count, inverted: ascending = heaviest first
     __shared__ __attribute__((aligned(16))) unsigned short ids[2][NN_CONTROL_MAX_ROWS];    // ping-pong: the order so far
@@ -618,8 +632,7 @@ __global__ __launch_bounds__(1024) void pass_control_kernel(unsigned int* __rest
         for (int e = 0; e < 16; ++e) {
             h[e] = h[e] > 0xfffffu ? 0xfffffu : h[e];
             mine += h[e];
-            unsigned int q = h[e];
-            if (h[e] >= 8u) { const int ex = 31 - __builtin_clz(h[e]); q = 8u + (unsigned int)(ex - 3) * 8u + ((h[e] >> (ex - 3)) & 7u); }   // <= 143
+            const unsigned int q = order_class(h[e], coarse);   // <= 143
             const unsigned int kq = r0 + e < rows ? 255u - q : 255u;   // (entries beyond the cloud sort behind everything; they are never dealt)
             packed[e >> 2] |= kq << (8 * (e & 3));
         }
@@ -756,7 +769,7 @@ size_t row_order_temp_bytes(int rows)
 {
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned int*)nullptr, (unsigned int*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
-                                    (unsigned int)(rows > 0 ? rows : 1), 0, 20);
+                                    (unsigned int)(rows > 0 ? rows : 1), 20, 28);
     return bytes;
 }
 
@@ -765,16 +778,16 @@ hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int ro
     if (rows <= 0 || rows >= (1 << NN_ROLE_ROW_BITS) || b.roles == nullptr || b.totals == nullptr) return hipErrorInvalidValue;
     if (rows <= NN_CONTROL_MAX_ROWS && b.control) {
         // one workgroup does it all (the exact counts go through keys[0], which the sort below would use)
-        hipLaunchKernelGGL(pass_control_kernel, dim3(1), dim3(1024), 0, st, hits, rows, b.keys[0], b.min_part, b.total_div, b.roles);
+        hipLaunchKernelGGL(pass_control_kernel, dim3(1), dim3(1024), 0, st, hits, rows, b.keys[0], b.min_part, b.total_div, b.roles, b.coarse);
         *roles_out = b.roles;
         return hipGetLastError();
     }
     unsigned long long* tot = b.totals + (b.seq & 1ull);
-    hipLaunchKernelGGL(row_order_keys_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, hits, rows, b.keys[0], b.vals[0], tot, b.totals + ((b.seq + 1ull) & 1ull));
+    hipLaunchKernelGGL(row_order_keys_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, hits, rows, b.keys[0], b.vals[0], tot, b.totals + ((b.seq + 1ull) & 1ull), b.coarse);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t bytes = b.temp_bytes;
-    e = rocprim::radix_sort_pairs(b.temp, bytes, b.keys[0], b.keys[1], b.vals[0], b.vals[1], (unsigned int)rows, 0, 20, st);
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.keys[0], b.keys[1], b.vals[0], b.vals[1], (unsigned int)rows, 20, 28, st);   // (the class bits alone: one pass)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(row_roles_kernel, dim3((rows + NN_ORDER_EXTRA + 1023) / 1024), dim3(1024), 0, st, b.keys[1], b.vals[1], rows,
                        (const unsigned long long*)tot, b.min_part, b.total_div, b.roles);

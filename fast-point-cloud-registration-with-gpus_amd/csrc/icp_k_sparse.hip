@@ -178,7 +178,19 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
         // ordered rows (many more rows than the machine holds blocks): the blocks take the rows heaviest first, and the
         // heaviest of all are split over several blocks (launch_row_order deals the roles; NN_ORDER_*, icp_kernels.h)
         if (fuse.row_order != nullptr) {
-            const int ro = fuse.row_order[blockIdx.x];   // (one word for the whole block)
+            // Blocks b and b + 8 run on one XCD (observed dispatch order; speed only): G = 2^xcd_shift CONSECUTIVE positions of the order --
+            // rows of one weight class in Hilbert order, i.e. neighbours that list mostly the same chunks, and the parts of a split row --
+            // go to blocks of one XCD, which then fetches their records into its L2 once instead of every XCD fetching every record;
+            // every XCD still gets every eighth group, so the heaviest-first order holds per XCD.
+            int bpos = (int)blockIdx.x;
+            {
+                const int sh = fuse.xcd_shift, span = 8 << sh;
+                if (sh > 0 && bpos < ((int)gridDim.x / span) * span) {
+                    const int x = bpos & 7, i = bpos >> 3;
+                    bpos = ((((i >> sh) << 3) + x) << sh) + (i & ((1 << sh) - 1));
+                }
+            }
+            const int ro = fuse.row_order[bpos];   // (one word for the whole block)
             if (ro < 0) return;                          // a spare block the split rows did not need
             if (threadIdx.x == 0) {
                 role[0] = ro & ((1 << NN_ROLE_ROW_BITS) - 1);

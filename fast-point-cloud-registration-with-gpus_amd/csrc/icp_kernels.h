@@ -237,6 +237,13 @@ unsigned int share_rows_plan(const unsigned int* hits, int rows, int blocks, int
 // interleave the model's super boxes (part p takes those whose number is p modulo parts), fold their minima into the row's
 // 64-bit keys and the last to arrive closes the row -- the protocol of the segment blocks.  Any assignment is exact.
 constexpr int NN_ORDER_EXTRA = 4096;   // blocks of an ordered launch beyond its rows
+// (round 4) the order is by weight CLASSES -- a count's leading one and NN_ORDER_CLASS_BITS bits behind it; the rows of a class keep the
+// curve's order -- and 2^NN_ORDER_XCD_SHIFT consecutive positions of it go to blocks of one XCD (blocks b and b + 8 share one): neighbours
+// on the curve list mostly the same chunks, and run side by side behind ONE L2.  10 M x 10 M: 10.6 -> 3.1 GB fetched per pass (raw
+// FETCH_SIZE), 4.88 -> 4.77 ms per iteration; classes of 0 / 1 / 2 bits, groups of 8 / 16 / 32: the same within 0.5 %
+// (profiles/r4/r4_12_s5_order_classes_xcd_groups.txt)
+constexpr int NN_ORDER_CLASS_BITS = 1;
+constexpr int NN_ORDER_XCD_SHIFT = 4;
 constexpr int NN_ORDER_HEAD = 1024;    // rows (the heaviest) that may be split
 constexpr int NN_ROLE_ROW_BITS = 21, NN_ROLE_PART_BITS = 6;   // role = row | part << 21 | log2(parts) << 27
 // the hierarchical search fetches a hit from one 160-byte record per chunk (icp_kernels.hip, model_records_kernel)
@@ -255,6 +262,7 @@ struct RowOrderBuffers {
     int min_part;            // no part is meant to be smaller than this many hits (0: no row is split)
     int total_div;           // the target: the sum of the counters over this (4 x the blocks the machine holds at once)
     int control = 1;         // up to 16 384 rows: ONE single-workgroup launch (LDS counting sort + roles) instead of keys + rocPRIM sort + roles
+    int coarse = NN_ORDER_CLASS_BITS;   // the order's weight classes: bits kept behind a count's leading one (0..3; order_class) -- rows of one class keep the curve's order
 };
 size_t row_order_temp_bytes(int rows);
 // reads AND zeroes hits[rows] (the next launch counts afresh); *roles_out = the roles of rows + NN_ORDER_EXTRA blocks (device pointer)

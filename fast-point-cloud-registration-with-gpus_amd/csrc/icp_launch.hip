@@ -444,6 +444,7 @@ static hipError_t launch_nn_v2(const NNPlan& pl, const void* P, const void* Q, v
             if (pl.order && ta && !fuse.resident && opt->row_order != nullptr && opt->row_hits != nullptr) {
                 fuse.row_order = opt->row_order;
                 fuse.row_hits = opt->row_hits;
+                fuse.xcd_shift = NN_ORDER_XCD_SHIFT;
                 g = dim3(pl.blocks_x + NN_ORDER_EXTRA, 1);   // (the roles of the blocks beyond the rows: parts of split rows, or none)
             }
             if (fuse.resident) {

@@ -444,10 +444,14 @@ def test_row_roles_of_the_single_workgroup_launch(ctx, pkg, rows):
         split = {r: ps for r, (ps, _) in first.items() if ps > 1}
         assert split and all(hits[r] >= 2048 for r in split)                 # only heavy rows are split
         assert max(split, key=lambda r: split[r]) in np.argsort(hits)[-8:]   # the most parts go to one of the heaviest
-        # heaviest first: the order of the unsplit rows follows the counts (the control kernel's to its 12 % quantisation)
+        # heaviest first, by weight classes (a count's leading one and one bit behind it: NN_ORDER_CLASS_BITS); the rows of a class
+        # keep their order on the curve -- neighbours run side by side
         order = [r for r in row.tolist() if first[r][0] == 1]
         h = hits[order].astype(np.float64)
-        tol = 1.0 if not control else 1.15
-        assert (h[1:] <= np.maximum(h[:-1] * tol, h[:-1] + 1)).all()
-        seen[control] = split
-    assert set(seen[True]) == set(seen[False])                               # both forms split the same rows (exact counts decide)
+        assert (h[1:] < np.maximum(h[:-1] * 1.5, h[:-1] + 1)).all()
+        cls = [int(v) if v < 8 else (int(v).bit_length(), (int(v) >> (int(v).bit_length() - 2)) & 1) for v in hits[order]]
+        for k in range(1, len(order)):
+            if cls[k] == cls[k - 1]: assert order[k] > order[k - 1]
+        seen[control] = (split, roles.copy())
+    assert set(seen[True][0]) == set(seen[False][0])                         # both forms split the same rows (exact counts decide)
+    assert np.array_equal(seen[True][1], seen[False][1])                     # ... and deal the same roles: same classes, both sorts stable
