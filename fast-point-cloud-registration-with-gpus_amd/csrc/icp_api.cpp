@@ -1105,7 +1105,12 @@ int icp_set_model(icp_ctx* c, const void* xyz, int m, int precision)
     c->have_model = false;     // (until the upload has been accepted)
     c->have_scan_copy = false;
     c->have_records = false;
-    const int group2 = (precision == ICP_F32 && m > 0 && icp::nn_plan(128, m, precision, c->num_cus, c->tune).hier) ? 512 : 0;   // (the model's size decides the search form)
+    // (the model's size decides the search form -- together with the CLOUD's: a model of 2^16 .. 2^17 points is searched through the
+    // hierarchy by a cloud of more rows than shared 8-wave blocks serve, flat by a smaller one, and the model is set before the cloud is
+    // known: it gets the upper levels and the records whenever SOME cloud would ask for them.  Round 3 built them by the plan of a
+    // one-row cloud; a 65 536-point grid against itself then failed with "invalid argument" at its first pass.)
+    const int group2 = (precision == ICP_F32 && m > 0 && (icp::nn_plan(128, m, precision, c->num_cus, c->tune).hier ||
+                                                          icp::nn_plan(1 << 22, m, precision, c->num_cus, c->tune).hier)) ? 512 : 0;
     const bool short_setup = precision == ICP_F32 && m > 0 && m <= icp_ctx::kPrepSmallMax && group2 == 0;
     icp::PrepBuffers pb{};
     if (short_setup) {

@@ -99,6 +99,18 @@ __device__ __forceinline__ f2 pk_sub_bcast(f2 q, f2 p)
     return r;
 }
 
+// (q.lo - p.S, q.hi - p.S): ONE of the lane's two points (half S of p) against two model points -- src1's half by op_sel, negated
+template <int S>
+__device__ __forceinline__ f2 pk_sub_sel(f2 q, f2 p)
+{
+    f2 r;
+    if constexpr (S == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(q), "v"(p));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(q), "v"(p));
+    return r;
+}
+
 template <int HI>
 __device__ __forceinline__ f2 pk_dist2(f2 qx, f2 qy, f2 qz, f2 px, f2 py, f2 pz)
 {

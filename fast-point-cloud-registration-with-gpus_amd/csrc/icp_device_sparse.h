@@ -20,15 +20,81 @@ template <> struct SpHit<true> { using type = int; };
 // Returns how far the hit got (wave-uniform; only the work-counting instantiation looks at it): 0 = rejected by the
 // per-point box test, 1 = by the xy early-out, 2 = the eight distances were evaluated in full.
 constexpr bool SP_XY_EARLY_OUT = false;
-template <bool PERM>
+
+// ONE of the lane's two points (half S of px, py, pz; its best / bj / bq) against the chunk, two MODEL points per packed operation:
+// half the arithmetic of the two-point form.  scan_hit takes it when only the row's first 64 slots, or only its last 64, ask for the
+// chunk (the halves are the two halves of the row's stretch of the Hilbert curve: spatially apart).  Same roundings (every
+// difference, product and sum is the one the two-point form computes for that pair), same tie rule.
+template <bool PERM, int S>
+__device__ __forceinline__ void scan_hit_half(const float* sb, int ch, const f2 px, const f2 py, const f2 pz, float& best, int& bj, float (&bq)[3])
+{
+    constexpr int C = 8;
+    const float *qxp = sb + 8, *qyp = sb + 16, *qzp = sb + 24;
+    const float4 qxa = *reinterpret_cast<const float4*>(qxp), qxb = *reinterpret_cast<const float4*>(qxp + 4);
+    const float4 qya = *reinterpret_cast<const float4*>(qyp), qyb = *reinterpret_cast<const float4*>(qyp + 4);
+    const float4 qza = *reinterpret_cast<const float4*>(qzp), qzb = *reinterpret_cast<const float4*>(qzp + 4);
+    f2 d[C / 2];   // d[k] = {model point 2k, model point 2k+1}
+    {
+        f2 ax, ay, az;
+        ax = pk_sub_sel<S>(f2{qxa.x, qxa.y}, px); ay = pk_sub_sel<S>(f2{qya.x, qya.y}, py); az = pk_sub_sel<S>(f2{qza.x, qza.y}, pz); d[0] = (ax * ax + ay * ay) + az * az;
+        ax = pk_sub_sel<S>(f2{qxa.z, qxa.w}, px); ay = pk_sub_sel<S>(f2{qya.z, qya.w}, py); az = pk_sub_sel<S>(f2{qza.z, qza.w}, pz); d[1] = (ax * ax + ay * ay) + az * az;
+        ax = pk_sub_sel<S>(f2{qxb.x, qxb.y}, px); ay = pk_sub_sel<S>(f2{qyb.x, qyb.y}, py); az = pk_sub_sel<S>(f2{qzb.x, qzb.y}, pz); d[2] = (ax * ax + ay * ay) + az * az;
+        ax = pk_sub_sel<S>(f2{qxb.z, qxb.w}, px); ay = pk_sub_sel<S>(f2{qyb.z, qyb.w}, py); az = pk_sub_sel<S>(f2{qzb.z, qzb.w}, pz); d[3] = (ax * ax + ay * ay) + az * az;
+    }
+    float c0 = fmin_(fmin_(d[0].x, d[0].y), fmin_(d[1].x, d[1].y));   // the chunk's own minimum
+    c0 = fmin_(c0, fmin_(fmin_(d[2].x, d[2].y), fmin_(d[3].x, d[3].y)));
+    auto dk = [&](int k) { return (k & 1) ? d[k >> 1].y : d[k >> 1].x; };
+    if constexpr (PERM) {
+        const bool cand = c0 <= best;
+        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
+            const int* qo = reinterpret_cast<const int*>(sb + 32);
+            int o0 = 0x7fffffff, k0 = 0;
+#pragma unroll
+            for (int kk = C - 1; kk >= 0; --kk) {
+                const int oj = qo[kk];
+                const bool e0 = (dk(kk) == c0) & (oj < o0);
+                o0 = e0 ? oj : o0; k0 = e0 ? kk : k0;
+            }
+            const bool take = cand & ((c0 < best) | (bj < 0) | (o0 < bj));   // bj < 0: nothing to tie with yet
+            best = take ? c0 : best;
+            bj = take ? o0 : bj;
+            if (take) { bq[0] = qxp[k0]; bq[1] = qyp[k0]; bq[2] = qzp[k0]; }
+        }
+    } else {
+        const bool take = (c0 < best) | ((c0 == best) & (ch < (bj >> 3)));   // bj = -1: nothing to tie with
+        if (__builtin_amdgcn_ballot_w64(take) != 0ull) {
+            int k0 = C - 1;
+#pragma unroll
+            for (int kk = C - 2; kk >= 0; --kk) k0 = (dk(kk) == c0) ? kk : k0;
+            best = take ? c0 : best;
+            bj = take ? ch * C + k0 : bj;
+            if (take) { bq[0] = qxp[k0]; bq[1] = qyp[k0]; bq[2] = qzp[k0]; }
+        }
+    }
+}
+
+template <bool PERM, bool HALVES = false>
 __device__ __forceinline__ int scan_hit(const float* sb, int ch, const f2 px, const f2 py, const f2 pz, float (&best)[2], int (&bj)[2],
                                         float (&bq)[2][3])
 {
     constexpr int C = 8;
     {
         // level 0: the chunk's bounding box against each of the lane's points (ties pass: the hits are unordered)
+        if constexpr (HALVES) {
+            // (the test of box_may_improve<1, true>, its two verdicts kept apart)
+            const f2 gx = px - f2{__builtin_amdgcn_fmed3f(px.x, sb[0], sb[3]), __builtin_amdgcn_fmed3f(px.y, sb[0], sb[3])};
+            const f2 gy = py - f2{__builtin_amdgcn_fmed3f(py.x, sb[1], sb[4]), __builtin_amdgcn_fmed3f(py.y, sb[1], sb[4])};
+            const f2 gz = pz - f2{__builtin_amdgcn_fmed3f(pz.x, sb[2], sb[5]), __builtin_amdgcn_fmed3f(pz.y, sb[2], sb[5])};
+            f2 L = (gx * gx + gy * gy) + gz * gz;
+            L = L * f2{0.99999905f, 0.99999905f};
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(L.x <= best[0]), m1 = __builtin_amdgcn_ballot_w64(L.y <= best[1]);
+            if ((m0 | m1) == 0ull) return 0;
+            if (m1 == 0ull) { scan_hit_half<PERM, 0>(sb, ch, px, py, pz, best[0], bj[0], bq[0]); return 2; }
+            if (m0 == 0ull) { scan_hit_half<PERM, 1>(sb, ch, px, py, pz, best[1], bj[1], bq[1]); return 2; }
+        } else {
         const f2 pxa[1] = {px}, pya[1] = {py}, pza[1] = {pz};
         if (__builtin_amdgcn_ballot_w64(box_may_improve<1, true>(sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], pxa, pya, pza, best)) == 0ull) return 0;
+        }
     }
     const float *qxp = sb + 8, *qyp = sb + 16, *qzp = sb + 24;
     f2 d[C];  // first dx*dx + dy*dy (the inner sum of the reference's association), then the distances

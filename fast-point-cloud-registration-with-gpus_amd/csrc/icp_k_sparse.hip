@@ -623,10 +623,10 @@ __global__ __launch_bounds__(NWS * 64, NWS == 16 ? 1 : 4) void nn_match_sparse(c
             for (int rr = 0; rr < cnt; ++rr) {
                 int stage_reached;
                 if constexpr (PERM) {
-                    stage_reached = scan_hit<true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
+                    stage_reached = scan_hit<true, true>(stage + rr * STG, 0, px, py, pz, best, bj, bq);
                 } else {
                     const int ch = __builtin_amdgcn_readfirstlane((int)hits[hb + rr * NWS + w]);
-                    stage_reached = scan_hit<false>(stage + rr * STG, ch, px, py, pz, best, bj, bq);
+                    stage_reached = scan_hit<false, true>(stage + rr * STG, ch, px, py, pz, best, bj, bq);
                 }
                 if constexpr (DIAG) {
                     ++wk_hit[0];

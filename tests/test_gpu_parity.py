@@ -671,6 +671,35 @@ def test_largest_clouds_that_stay_resident(ctx, pkg, orc, width):
     assert ctx.nn_launch_info()["threads"] == 512
 
 
+def test_mid_size_model_is_searched_by_what_the_cloud_asks_for(pkg, orc):
+    """a model of 2^16 points is searched flat by a small cloud and through the box hierarchy by one of more rows than the shared
+    8-wave blocks serve (65 536 points: 512 rows) -- the model is set BEFORE the cloud is known and must carry the upper levels and
+    the records either way (round 3 built them by a one-row plan: the second case failed at its first pass).  Both against the oracle."""
+    D = pkg.datasets.synthetic_grid(256, np.float32)
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    orc.set_threads(os.cpu_count() or 1)
+    try:
+        want_big = orc.icp_p2p_f32x(D, M, 2, 0.0, fixed=True)
+        small = np.ascontiguousarray(D[:: 16])
+        want_small = orc.icp_p2p_f32x(small, M, 2, 0.0, fixed=True)
+    finally:
+        orc.set_threads(1)
+    with pkg.Context(0) as c:
+        c.set_model(M)
+        for cloud, want, threads in ((small, want_small, None), (D, want_big, 256), (small, want_small, None)):   # (and back again)
+            c.set_moving(cloud)
+            c.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=2, tol=0.0, fixed_iterations=True)
+            done = False
+            while not done:
+                _, done = c.loop_run(1 << 20)
+            st, idx = c.loop_state(), c.loop_indices()
+            assert st["iterations"] == want["iterations"] == 2
+            assert np.array_equal(idx, want["idx"])
+            assert rel(st["T"], want["T"]) < TOL_T
+            if threads is not None:
+                assert c.nn_launch_info()["threads"] == threads        # 4-wave blocks: the hierarchical, ordered form
+
+
 def _two_ranks_on_one_device(pkg, golden, metric, dtype, env=None, max_iter=100, tol=1e-6):
     """two processes on cuda:0, each with a shard of the hall scan, meeting once per iteration in shared host memory
     (icp_comm_init_local); returns what each rank ended with"""
