@@ -438,7 +438,7 @@ class S5(Workload):
     workload = "synthetic 10M-point cloud point-to-point ICP, moving cloud sharded over the ranks (BASELINE configs[4])"
     kernel = ("nn_match_sparse<1, ..., HIER, 4> (rows of 128 points, 4 waves per block and four blocks to a CU -- 8 waves for the cold first "
               "pass of a context without history --, three-level box hierarchy over the Hilbert-ordered view of the model, rows taken "
-              "heaviest first, the heaviest split over 2..64 blocks, a refinement round over local samples before the chunks are listed), "
+              "heaviest weight class first -- a class keeps the curve's order, sixteen consecutive rows to an XCD --, the heaviest split over 2..64 blocks, a refinement round over local samples before the chunks are listed, a chunk asked for by one half of a row evaluated for that half), "
               "ONE launch per pass")
     scaling = "strong"
     regime = "fixed"
