@@ -1117,6 +1117,33 @@ def test_configs4_full_size_properties(ctx, pkg):
     assert np.array_equal(ctx.get_indices(), cold)
 
 
+def test_configs4_share_against_the_kernel_that_executes_every_pair(pkg, monkeypatch):
+    """BASELINE configs[4] at its full model size, ALL correspondences of a share (rank 5 of 32: 312 500 moving points against the
+    whole 10 M-point model, 3.1e12 pairs): the hierarchical search -- cold, then seeded by its own matches -- against the dense packed
+    kernel of a context created under ICP_NN_SPARSE=0, which executes every pair (no boxes, no bounds, no order, no views): the two
+    share the arithmetic of a pair and the tie rule and nothing of the search.  Beyond the CPU oracle's reach (hours); the oracle
+    pins both kernels on the smaller configs."""
+    N = 10_000_000
+    W = int(np.ceil(np.sqrt(N)))
+    D = pkg.datasets.synthetic_grid(W, np.float32)[:N]
+    M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
+    lo, cnt = pkg.shard_range(N, 5, 32)
+    P = np.ascontiguousarray(D[lo:lo + cnt])
+    del D
+    monkeypatch.delenv("ICP_NN_SPARSE", raising=False)
+    with pkg.Context(0) as c:
+        c.set_model(M); c.set_moving(P)
+        assert c.nn_launch_info()["threads"] == 256                     # the hierarchical form: 4-wave blocks
+        c.nn_match_resident(); cold = c.get_indices()
+        c.nn_match_bench(1, seeded=True); seeded = c.get_indices()
+    monkeypatch.setenv("ICP_NN_SPARSE", "0")
+    with pkg.Context(0) as c:
+        c.set_model(M); c.set_moving(P)
+        c.nn_match_resident(); dense = c.get_indices()
+    monkeypatch.delenv("ICP_NN_SPARSE", raising=False)
+    assert np.array_equal(cold, dense) and np.array_equal(seeded, dense)
+
+
 def test_configs4_share_loop_ordered_rows_and_padding(pkg, monkeypatch):
     """the same share (1.25 M points: 9766 rows, the last one partly filled) through five iterations of the loop: the launches
     take the rows heaviest first (sorted by the hits of the launch before) or in index order -- the same bits; the error
