@@ -787,7 +787,7 @@ hipError_t launch_row_order(const RowOrderBuffers& b, unsigned int* hits, int ro
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t bytes = b.temp_bytes;
-    e = rocprim::radix_sort_pairs(b.temp, bytes, b.keys[0], b.keys[1], b.vals[0], b.vals[1], (unsigned int)rows, 20, 28, st);   // (the class bits alone: one pass)
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.keys[0], b.keys[1], b.vals[0], b.vals[1], (unsigned int)rows, 20, 28, st);   // (the class bits alone; stable)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(row_roles_kernel, dim3((rows + NN_ORDER_EXTRA + 1023) / 1024), dim3(1024), 0, st, b.keys[1], b.vals[1], rows,
                        (const unsigned long long*)tot, b.min_part, b.total_div, b.roles);
