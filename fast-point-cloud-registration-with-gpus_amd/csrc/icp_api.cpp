@@ -2052,6 +2052,10 @@ bool share_wants_resident(const icp_ctx* c)
     // registration is ONE resident kernel with shared rows (Bunny.csv, registrations repeated in one context: 32.9 -> 30.7 us per
     // iteration, profiles/r2/r2_03_bunny_shared_rows.txt).  ICP_SHARE_AUTO=0: armed throughout, as in round 2.
     if (c->share_auto && c->share_cold_seq >= 1 && c->loop.H.applied == 0 && !c->loop.matched) return true;
+    // Round 4: the FIRST registration does not stay armed to its end either -- its cold pass has left counts (share_cold_seq == 1),
+    // and from its second pass on it is one resident kernel dealt by them: 33.1 -> 31.7 us per iteration for that one registration
+    // (profiles/r4/r4_12_bunny_first_registration_anatomy.txt, ICP_SHARE_RESIDENT_AFTER=2; = 3, 4: the same).
+    if (c->share_auto && c->share_resident_after < 0 && c->share_cold_seq == 1 && c->loop.matched && c->loop.H.applied >= 1) return true;
     return c->share_resident_after >= 0 && c->loop.H.applied + 1 >= c->share_resident_after;
 }
 

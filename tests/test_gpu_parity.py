@@ -136,16 +136,17 @@ def test_matching_full_size_properties(ctx, pkg, golden):
     assert np.array_equal(d2(B, M[perm], idx2), best)
 
 
-@pytest.mark.parametrize("form", ["armed_shared", "armed_then_resident", "resident_second_registration", "waves16"])
+@pytest.mark.parametrize("form", ["default", "armed_shared", "armed_then_resident", "resident_second_registration", "waves16"])
 def test_bunny_registration_full_size_against_the_oracle(pkg, orc, golden, monkeypatch, form):
     """BASELINE configs[1] at full size (Bunny.csv against its moved copy, 35 947^2): nine fixed iterations through the loop the
     plan picks for this size -- rows of 128 as 8-wave blocks, one armed launch per pass, the spare blocks of every launch
     dealt to the heavy rows -- through the resident forms of the same (taking over after four passes; from the first pass of a
     second registration) and through the 16-wave blocks of rounds 1-2: correspondences bit-exact against the oracle's run
     (all threads of the host), transform within the tolerance"""
-    env = {"armed_shared": {}, "armed_then_resident": {"ICP_SHARE_RESIDENT_AFTER": "4"}, "resident_second_registration": {"ICP_RESIDENT": "2"},
-           "waves16": {"ICP_NN_WAVES128": "16"}}[form]
-    for k in ("ICP_NN_SHARE", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_WAVES128", "ICP_NN_SHARE_RESIDENT", "ICP_SHARE_RESIDENT_AFTER"):
+    # (default, round 4: a context's first registration is armed for its cold pass and one resident kernel from the second pass on)
+    env = {"default": {}, "armed_shared": {"ICP_SHARE_AUTO": "0"}, "armed_then_resident": {"ICP_SHARE_RESIDENT_AFTER": "4"},
+           "resident_second_registration": {"ICP_RESIDENT": "2"}, "waves16": {"ICP_NN_WAVES128": "16"}}[form]
+    for k in ("ICP_NN_SHARE", "ICP_RESIDENT", "ICP_ARMED", "ICP_NN_WAVES128", "ICP_NN_SHARE_RESIDENT", "ICP_SHARE_RESIDENT_AFTER", "ICP_SHARE_AUTO"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
