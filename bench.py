@@ -455,8 +455,18 @@ class S5(Workload):
         self.Wd = int(np.ceil(np.sqrt(N)))
         D = self.pkg.datasets.synthetic_grid(self.Wd, np.float32)[:N]
         self.Q = self.pkg.datasets.make_model_gpu(D, *self.pkg.datasets.P2P_GPU)
-        lo, cnt = self.pkg.shard_range(N, self.rank, self.world)
-        self.P = np.ascontiguousarray(D[lo:lo + cnt])
+        if self.world > 1 and getattr(self.args, "s5_shard", "blocks") == "blocks":
+            # N > 1: the cloud is dealt to the ranks in blocks of 16 384 points along a Hilbert curve (128 rows of neighbours each), not
+            # cut into contiguous eighths -- the work per point varies over this pair, and the eighths take 16 to 30 ms per registration
+            # against 20 to 25 for dealt blocks (profiles/r4/r4_14_s5_shares_of_eight.txt); a registration is as slow as its slowest
+            # rank.  Any partition of the moving points is the same registration.  (--s5-shard contiguous: icp_shard_range, as before)
+            idx = self.pkg.distributed.shard_cyclic_index(N, self.rank, self.world, 16384, self.pkg.distributed.curve_order(D))
+            self.P = np.ascontiguousarray(D[idx]); cnt = len(idx)
+            self.shard_form = "blocks of 16 384 points along a Hilbert curve, dealt to the ranks (distributed.shard_cyclic_index)"
+        else:
+            lo, cnt = self.pkg.shard_range(N, self.rank, self.world)
+            self.P = np.ascontiguousarray(D[lo:lo + cnt])
+            self.shard_form = "contiguous ranges (icp_shard_range)" if self.world > 1 else "one rank: the whole cloud"
         self.slice_D = np.ascontiguousarray(D[: min(N, 100_000)])
         del D
         self.n, self.m, self.n_global = cnt, N, N
@@ -874,6 +884,7 @@ def leg_main(args, rank, local_rank, world):
             "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": wl.dtype, "data": wl.data,
             "config": {"workload": wl.workload, "moving_points_per_gpu": wl.n, "model_points": wl.m,
                        "global_moving_points": wl.n_global,
+                       **({"shards": wl.shard_form} if getattr(wl, "shard_form", None) else {}),
                        "ranks_compute": ("ONE registration: the moving cloud is sharded over the ranks (%s), the model replicated" %
                                          ("--shard strong: the config's own cloud split" if wl.scaling == "strong" else
                                           "--shard weak: a whole config-sized shard per rank")) if (sharded and world > 1) else
@@ -1072,6 +1083,9 @@ def main():
     ap.add_argument("--no-rccl", action="store_true", help="N > 1: skip the leg that measures the other route")
     ap.add_argument("--shard", choices=("strong", "weak"), default="strong",
                     help="hall, N > 1: strong = the 16 384 moving points split over the ranks (north_star); weak = a hall-sized shard per rank")
+    ap.add_argument("--s5-shard", dest="s5_shard", choices=("blocks", "contiguous"), default="blocks",
+                    help="s5, N > 1: blocks = the cloud dealt to the ranks in blocks of 16 384 points along a Hilbert curve (even loads); "
+                         "contiguous = icp_shard_range's ranges (round 3: the eighths take 16 to 30 ms per registration)")
     ap.add_argument("--repeats", type=int, default=None, help="repeats of the K-step region (default: >= 25 for short regions, see timed_steps)")
     ap.add_argument("--no-s5", action="store_true", help="hall: skip the brief configs[4] leg beside the line")
     ap.add_argument("--no-fresh-pair", action="store_true")

@@ -176,3 +176,29 @@ def test_local_communicator_three_ranks(tmp_path, pkg, orc):
     M = pkg.datasets.make_model_gpu(pkg.datasets.synthetic_grid(31, np.float32), *pkg.datasets.P2P_GPU)
     ref = orc.icp_p2p_f32x(D, M, 40, 1e-6)
     assert int(r[0]["iterations"]) == ref["iterations"] and np.abs(ref["T"] - r[0]["T"]).max() < 1e-9
+
+
+def test_dealt_shards_are_a_partition_of_compact_blocks(pkg):
+    """distributed.curve_order / shard_cyclic_index (what bench.py --config s5 --gpus N deals the moving cloud by): the order is a Hilbert
+    curve (on a full lattice every step goes to a face neighbour), the ranks' shares partition the cloud whatever the sizes, a block
+    is a contiguous stretch of the curve, and no rank gets the same corner of every cell (the digit-sum dealing)"""
+    d = pkg.distributed
+    b = 4
+    g = np.arange(1 << b)
+    A = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    o = d.curve_order(A, bits=b)
+    assert np.array_equal(np.sort(o), np.arange(len(A)))
+    assert (np.abs(np.diff(A[o], axis=0)).sum(1) == 1).all()
+    for n, world, block in ((10_007, 8, 128), (4096, 3, 1024), (100, 8, 16384), (65_536, 1, 512)):
+        order = np.random.default_rng(n).permutation(n)
+        shares = [d.shard_cyclic_index(n, r, world, block, order) for r in range(world)]
+        assert np.array_equal(np.sort(np.concatenate(shares)), np.arange(n))
+        pos = np.empty(n, dtype=np.int64); pos[order] = np.arange(n)
+        for s in shares:                     # every share: whole blocks of the order (the last one may be short), ascending
+            p = pos[s]
+            assert (np.diff(p) > 0).all() and all((p[k] // block == p[k + 1] // block) or (p[k + 1] % block == 0) for k in range(len(p) - 1))
+    owners = np.array([[r for r in range(8) if bidx * 64 in set(d.shard_cyclic_index(64 * 512, r, 8, 64).tolist())][0] for bidx in range(512)])
+    for level in (1, 8, 64):                 # the eight children of a cell of any level go to eight different ranks ...
+        kids = owners.reshape(-1, 8, level)[:, :, 0]
+        assert all(len(set(row.tolist())) == 8 for row in kids)
+    assert len(set(owners[::8].tolist())) == 8   # ... and the FIRST child of the cells of a level does not always go to the same one

@@ -1000,7 +1000,8 @@ def test_million_point_self_match_is_the_identity(ctx, pkg):
         assert int(((d[:, 0] + d[:, 1]) + d[:, 2]).argmin()) == int(idx[i])
 
 
-def test_two_ranks_large_model_sharded_like_configs4(pkg, orc):
+@pytest.mark.parametrize("deal", [False, True])
+def test_two_ranks_large_model_sharded_like_configs4(pkg, orc, deal):
     """BASELINE configs[4] in small: a synthetic grid cloud large enough for the hierarchical search (131 769 model points,
     replicated), the MOVING cloud split over two ranks (both on cuda:0 here; too many rows for a resident kernel each is
     not required; here 2 x 96 rows so that both resident kernels fit the one GPU they share), one sum per iteration through the node-local communicator:
@@ -1011,10 +1012,12 @@ def test_two_ranks_large_model_sharded_like_configs4(pkg, orc):
         f"sys.path.insert(0, {ROOT!r})\n"
         "from __graft_entry__ import load_package\n"
         "pkg = load_package()\n"
-        "rank, world, idh = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]\n"
+        "rank, world, idh, deal = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])\n"
         "M = pkg.datasets.synthetic_grid(363, np.float32)\n"
         "D = pkg.datasets.make_model_gpu(M[np.random.default_rng(7).integers(0, 363 * 363, 24000)], (0.03, -0.02, 0.01), (0.02, -0.01, 0.015))\n"
         "Ds, begin = pkg.distributed.shard(D, rank, world)\n"
+        "if deal:   # blocks of 1024 points along a Hilbert curve, dealt to the ranks (what bench.py --config s5 --gpus N does)\n"
+        "    sel = pkg.distributed.shard_cyclic_index(len(D), rank, world, 1024, pkg.distributed.curve_order(D)); Ds = np.ascontiguousarray(D[sel])\n"
         "with pkg.Context(0) as ctx:\n"
         "    ctx.set_model(M); ctx.set_moving(Ds)\n"
         "    ctx.comm_init_local(bytes.fromhex(idh), rank, world)\n"
@@ -1026,7 +1029,7 @@ def test_two_ranks_large_model_sharded_like_configs4(pkg, orc):
         "    ctx.comm_destroy()\n"
         "print(json.dumps(dict(it=st['iterations'], T=st['T'].tolist(), err=st['err'].tolist(), begin=int(begin), idx=idx.tolist())))\n")
     idh = pkg.Context.comm_random_id().hex()
-    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", idh], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", idh, str(int(deal))], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (o, e) in zip(procs, outs):
@@ -1038,7 +1041,15 @@ def test_two_ranks_large_model_sharded_like_configs4(pkg, orc):
     want = orc.icp_p2p_f32x(D, M, 4, 1e-9, fixed=True)
     assert_same_run(got[0]["it"], np.array(got[0]["err"]), np.array(got[0]["T"]), want, 1e-9, fp32=True)
     if got[0]["it"] == want["iterations"]:
-        assert np.array_equal(np.concatenate([got[0]["idx"], got[1]["idx"]]), want["idx"])
+        if deal:   # (a dealt shard's correspondences back in the cloud's order: the two shares are a partition of it)
+            order = pkg.distributed.curve_order(D)
+            sel = [pkg.distributed.shard_cyclic_index(len(D), r, 2, 1024, order) for r in range(2)]
+            assert np.array_equal(np.sort(np.concatenate(sel)), np.arange(len(D)))
+            full = np.empty(len(D), dtype=np.int64)
+            for r in range(2): full[sel[r]] = got[r]["idx"]
+            assert np.array_equal(full, want["idx"])
+        else:
+            assert np.array_equal(np.concatenate([got[0]["idx"], got[1]["idx"]]), want["idx"])
 
 
 def test_sticky_pin_lands_on_the_device_numa_node(pkg):

@@ -24,6 +24,9 @@ D = pkg.datasets.synthetic_grid(W, np.float32)[:NPTS]
 M = pkg.datasets.make_model_gpu(D, *pkg.datasets.P2P_GPU)
 lo, cnt = pkg.shard_range(NPTS, rank, world); hi = lo + cnt
 P = np.ascontiguousarray(D[lo:hi])
+if os.environ.get("S5_SHARD_BLOCK"):   # (dealt in blocks of that many points, round-robin: distributed.shard_cyclic_index; S5_SHARD_CURVE=1: along a Z-order curve)
+    order = pkg.distributed.curve_order(D, bits=int(os.environ.get("S5_CURVE_BITS", 10))) if os.environ.get("S5_SHARD_CURVE") else None
+    P = np.ascontiguousarray(D[pkg.distributed.shard_cyclic_index(NPTS, rank, world, int(os.environ["S5_SHARD_BLOCK"]), order)])
 print(f"model {len(M)} points, moving shard [{lo}, {hi}) = {len(P)} points (rank {rank} of {world})", flush=True)
 SAVE = os.path.join(ROOT, "gpurun_out", f"s5_idx_{NPTS}_{rank}_{world}.npy")
 if DENSE:
