@@ -2,7 +2,7 @@
 """bench.py -- the hot path's measurements on MI355X, one JSON line per run.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config hall|hall_plane|bunny|s5|cpu_f64] [--shard strong|weak]
-                    [--repeats R] [--no-s5] [--no-rccl] [--no-cpu-baseline] [--no-fresh-pair]
+                    [--s5-shard blocks|contiguous] [--repeats R] [--no-s5] [--no-rccl] [--no-cpu-baseline] [--no-fresh-pair]
 
 N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* from the environment), or plainly as `python bench.py --gpus N`, in which case this process starts
@@ -38,6 +38,9 @@ Workloads (`--config`; every BASELINE.json config has one; each line carries `ro
   s5          configs[4]: synthetic z = x^2 - y^2 grid truncated to --points (10 M) points against its moved copy; the
               MOVING cloud is sharded over the ranks (strong scaling), the model replicated.  A step = one iteration of
               the whole cloud; the timed region is ONE registration of K fixed iterations from the initial pose.
+              N > 1 (`--s5-shard blocks`, the default): the cloud is DEALT to the ranks in blocks of 16 384 points along a Hilbert
+              curve -- the work per point varies over this pair, contiguous eighths (`--s5-shard contiguous`, icp_shard_range)
+              take 16 to 30 ms per registration and the registration waits for the slowest; dealt blocks take 20 to 24.5.
   cpu_f64     configs[0]: src/ICP_CPU.c's own run -- synthetic grid WIDTH x WIDTH (--width, 32 -> 1024 points), fp64,
               tol 1e-5, MAX_ITER 200 -- through the fp64 path (ICP_F64); same regime as hall.
 The only data that crosses ranks is the loop's 32-double moment vector, summed once per iteration.  hall: `value` is measured
