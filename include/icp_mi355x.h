@@ -245,7 +245,10 @@ void icp_host_loop_destroy(icp_host_loop* h);
 int icp_host_loop_advance(icp_host_loop* h, const double* mom /*ICP_NMOM*/, int* done, double* R9, double* t3);
 int icp_host_loop_note_applied(icp_host_loop* h);
 int icp_host_loop_state(icp_host_loop* h, int* iterations, int* passes, double* err, int err_cap, double* T16);
-/* contiguous shard [begin, begin+count) of n moving points for `rank` of `world` */
+/* contiguous shard [begin, begin+count) of n moving points for `rank` of `world`.  Any partition of the moving points is the same
+ * registration, and a registration is as slow as its slowest rank: where the work per point varies over a LARGE cloud (BASELINE
+ * configs[4]: contiguous eighths take 16 to 30 ms) deal compact blocks of the cloud to the ranks instead (distributed.curve_order +
+ * shard_cyclic_index of the Python mirror) -- every rank simply passes its own points to icp_set_moving. */
 int icp_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t* count);
 /* symmetric 3x3 eigen-solve used for the normals (upper triangle of row-major A read);
  * w ascending, Z[i*3+k] = component i of eigenvector k */
