@@ -701,6 +701,35 @@ def test_mid_size_model_is_searched_by_what_the_cloud_asks_for(pkg, orc):
                 assert c.nn_launch_info()["threads"] == threads        # 4-wave blocks: the hierarchical, ordered form
 
 
+@pytest.mark.parametrize("n,m", [(32768, 65536), (32769, 65536), (57344, 65536), (57345, 65536), (65536, 65535), (70000, 65537),
+                                 (57345, 131071), (70000, 131072), (16384, 131073), (33000, 524288)])
+def test_borders_of_the_plans_size_classes_against_the_dense_kernel(pkg, monkeypatch, n, m):
+    """(cloud, model) sizes on both sides of the borders where the plan changes form -- rows of 64 / 128, 8-wave shared rows / 16-wave
+    blocks, flat / hierarchical search by the cloud's rows AND by the model's size, 16-bit / 32-bit hit lists --: two fixed iterations
+    through the form the library picks against the dense kernel of a context created under ICP_NN_SPARSE=0, which executes every pair:
+    the same correspondences, the same transform (tools/size_sweep.py runs 102 such pairs; round 4 found one border unguarded)."""
+    G = pkg.datasets.synthetic_grid(725, np.float32)
+    M = pkg.datasets.make_model_gpu(np.ascontiguousarray(G[:m]), *pkg.datasets.P2P_GPU)
+    P = np.ascontiguousarray(G[np.sort(np.random.default_rng(n + m).choice(len(G), n, replace=False))])
+    got = {}
+    for dense in (False, True):
+        monkeypatch.delenv("ICP_NN_SPARSE", raising=False)
+        if dense:
+            monkeypatch.setenv("ICP_NN_SPARSE", "0")
+        with pkg.Context(0) as c:
+            c.set_model(M); c.set_moving(P)
+            c.loop_begin(pkg.ICP_POINT_TO_POINT, max_iter=2, tol=0.0, fixed_iterations=True)
+            done = False
+            while not done:
+                _, done = c.loop_run(1 << 20)
+            got[dense] = (c.loop_state(), c.loop_indices())
+    monkeypatch.delenv("ICP_NN_SPARSE", raising=False)
+    (sa, ia), (sb, ib) = got[False], got[True]
+    assert sa["iterations"] == sb["iterations"] == 2
+    assert np.array_equal(ia, ib)
+    assert np.allclose(sa["T"], sb["T"], rtol=0, atol=1e-5)
+
+
 def _two_ranks_on_one_device(pkg, golden, metric, dtype, env=None, max_iter=100, tol=1e-6):
     """two processes on cuda:0, each with a shard of the hall scan, meeting once per iteration in shared host memory
     (icp_comm_init_local); returns what each rank ended with"""
