@@ -730,6 +730,37 @@ def test_borders_of_the_plans_size_classes_against_the_dense_kernel(pkg, monkeyp
     assert np.allclose(sa["T"], sb["T"], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("form,n,m", [("plane", 33000, 65536), ("plane", 57345, 65537), ("plane", 70000, 131072),
+                                      ("f64", 16384, 65536), ("f64", 16385, 131071), ("f64", 33000, 4096)])
+def test_borders_of_the_size_classes_point_to_plane_and_fp64(pkg, monkeypatch, form, n, m):
+    """the same for the point-to-plane loop (normals estimated on the device; the 28-sum row tail of every kernel family) and for the
+    fp64 path (rows of 64 on the sparse structure up to 16 384 points and models below 2^17, the dense thread-per-point kernel beyond)"""
+    dt = np.float64 if form == "f64" else np.float32
+    G = pkg.datasets.synthetic_grid(725, np.float32)
+    M = pkg.datasets.make_model_gpu(np.ascontiguousarray(G[:m]), *pkg.datasets.P2P_GPU).astype(dt)
+    P = np.ascontiguousarray(G[np.sort(np.random.default_rng(n + m).choice(len(G), n, replace=False))]).astype(dt)
+    metric = pkg.ICP_POINT_TO_PLANE if form == "plane" else pkg.ICP_POINT_TO_POINT
+    got = {}
+    for dense in (False, True):
+        monkeypatch.delenv("ICP_NN_SPARSE", raising=False)
+        if dense:
+            monkeypatch.setenv("ICP_NN_SPARSE", "0")
+        with pkg.Context(0) as c:
+            c.set_model(M); c.set_moving(P)
+            if form == "plane":
+                c.estimate_normals()
+            c.loop_begin(metric, max_iter=2, tol=0.0, fixed_iterations=True)
+            done = False
+            while not done:
+                _, done = c.loop_run(1 << 20)
+            got[dense] = (c.loop_state(), c.loop_indices())
+    monkeypatch.delenv("ICP_NN_SPARSE", raising=False)
+    (sa, ia), (sb, ib) = got[False], got[True]
+    assert sa["iterations"] == sb["iterations"] == 2
+    assert np.array_equal(ia, ib)
+    assert np.allclose(sa["T"], sb["T"], rtol=0, atol=1e-5)
+
+
 def _two_ranks_on_one_device(pkg, golden, metric, dtype, env=None, max_iter=100, tol=1e-6):
     """two processes on cuda:0, each with a shard of the hall scan, meeting once per iteration in shared host memory
     (icp_comm_init_local); returns what each rank ended with"""
